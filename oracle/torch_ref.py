@@ -1,0 +1,328 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the reference's hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
+Nothing under convnets_amd/ imports it; the product path fails loudly without the HIP library.
+
+What it restates (all citations are into /root/reference/src):
+  * the layer factory + shape tracker        basemodel.py:725-816, 966-1067
+  * init_params                              basemodel.py:85-108  (ConvNet variant :1110-1129)
+  * ResNet / ResBlock / ResBottleneck        resnet.py:29-36, 53-117, 119-196
+  * VGGNet                                   vggnet.py:30-35, 55-103
+  * ConvNet                                  basemodel.py:1070-1108
+  * the fp32 training-step sequence          basemodel.py:245-288 (zero_grad, forward, CE(sum),
+                                             backward, Adam step; clipping is off by default)
+The arithmetic itself lives in third-party torch (reference pins torch==1.6.0+cu101,
+requirements.txt:18; here torch 2.10 CPU / oneDNN): this restatement calls the same stock
+torch.nn layers the reference's factory returns, so on identical weights it is bit-identical to
+the reference classes.  Pinning: tests/test_oracle_vs_reference.py (runs only where
+/root/reference exists) proves state_dict-key equality and bitwise-equal logits/grads against the
+imported reference classes, and tests/golden/*.npz (made by tests/golden/make_golden.py from the
+reference classes) pins it on the GPU box where the reference cannot travel.
+
+LeNet-5 and AlexNet do not exist in the reference; they are written here in the
+reference's template_net.py style on the same factory, and their oracle is this file itself.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class RefSettings:
+    """Attribute bag with the defaults of settings.py:177-222 that the hot path reads."""
+
+    def __init__(self, kind, input_size, num_classes, batch_size=256, batch_norm=True,
+                 learning_rate=0.01, weight_decay=1e-4, dropout_rate=0.5, init_params=True,
+                 mixed_precision=False, seed=21):
+        self.kind = kind
+        self.input_size = tuple(input_size)
+        self.num_classes = num_classes
+        self.batch_size = batch_size
+        self.batch_norm = batch_norm
+        self.learning_rate = learning_rate
+        self.weight_decay = weight_decay
+        self.dropout_rate = dropout_rate
+        self.init_params = init_params
+        self.mixed_precision = mixed_precision
+        self.seed = seed
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class RefBaseModel(nn.Module):
+    """basemodel.py:28-56 (state), :725-816 (shape tracker), :966-1042 (factories)."""
+
+    def __init__(self, setting):
+        super().__init__()
+        self.setting = setting
+        self.in_channels, self.height, self.width = setting.input_size
+        self.cost_function = nn.CrossEntropyLoss(reduction='sum')   # basemodel.py:46
+        self.optimizer = None
+
+    # basemodel.py:58-67 (Adam with L2 weight decay; scheduler/scaler are not on the step path)
+    def init_optimizer(self):
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=self.setting.learning_rate,
+                                          weight_decay=self.setting.weight_decay)
+
+    # basemodel.py:85-108
+    def init_params(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0, std=0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # basemodel.py:725-781 (formula :770-771)
+    def save_conv_outshape(self, layer):
+        kh, kw = _pair(layer.kernel_size)
+        sh, sw = _pair(layer.stride)
+        ph, pw = _pair(layer.padding)
+        dh, dw = _pair(layer.dilation) if hasattr(layer, 'dilation') else (1, 1)
+        self.height = int(np.floor(1 + (self.height + 2 * ph - dh * (kh - 1) - 1) / sh))
+        self.width = int(np.floor(1 + (self.width + 2 * pw - dw * (kw - 1) - 1) / sw))
+        if isinstance(layer, nn.Conv2d):
+            self.in_channels = layer.out_channels
+        return self.in_channels, self.height, self.width
+
+    # basemodel.py:783-810
+    def save_adapt_outshape(self, layer):
+        self.height, self.width = _pair(layer.output_size)
+        return self.in_channels, self.height, self.width
+
+    def num_flat_features(self):                                   # basemodel.py:812-816
+        return self.in_channels * self.height * self.width
+
+    def conv2d(self, in_channels=None, num_filters=None, set_output=True, **kwargs):   # :966-979
+        if in_channels is None:
+            in_channels = self.in_channels
+        layer = nn.Conv2d(in_channels, num_filters, **kwargs, bias=not self.setting.batch_norm)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
+
+    def conv2d_block(self, in_channels=None, num_filters=None, set_output=True, activation=True,
+                     **kwargs):                                                        # :999-1015
+        layers = [self.conv2d(in_channels, num_filters, set_output, **kwargs)]
+        if self.setting.batch_norm:
+            layers += [nn.BatchNorm2d(num_features=num_filters)]
+        if activation:
+            layers += [nn.ReLU(inplace=True)]
+        return nn.Sequential(*layers)
+
+    def maxpool2d(self, set_output=True, **kwargs):                                    # :1017-1024
+        layer = nn.MaxPool2d(**kwargs)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
+
+    def adapt_avgpool2d(self, set_output=True, **kwargs):                              # :1035-1042
+        layer = nn.AdaptiveAvgPool2d(**kwargs)
+        if set_output:
+            self.save_adapt_outshape(layer)
+        return layer
+
+    def forward(self, x):                                          # resnet.py:110-117 et al.
+        x = self.features(x)
+        x = torch.flatten(x, start_dim=1)
+        return self.classifier(x)
+
+
+class RefResBlock(nn.Module):                                      # resnet.py:119-156
+    def __init__(self, network, num_filters, expansion, dim_synch=None, **kwargs):
+        super().__init__()
+        self.dim_synch = dim_synch
+        self.res_block = nn.Sequential(
+            network.conv2d_block(num_filters=num_filters, kernel_size=3, padding=1, **kwargs),
+            network.conv2d_block(num_filters=num_filters * expansion, activation=False,
+                                 kernel_size=3, padding=1))
+
+    def forward(self, x):
+        identity = x
+        output = self.res_block(x)
+        if self.dim_synch is not None:
+            identity = self.dim_synch(identity)
+        output += identity
+        return F.relu(output)
+
+
+class RefResBottleneck(nn.Module):                                 # resnet.py:158-196
+    def __init__(self, network, num_filters, expansion, dim_synch=None, **kwargs):
+        super().__init__()
+        self.dim_synch = dim_synch
+        self.res_bottleneck = nn.Sequential(
+            network.conv2d_block(num_filters=num_filters, kernel_size=1),
+            network.conv2d_block(num_filters=num_filters, kernel_size=3, padding=1, **kwargs),
+            network.conv2d_block(num_filters=num_filters * expansion, activation=False,
+                                 kernel_size=1))
+
+    def forward(self, x):
+        identity = x
+        output = self.res_bottleneck(x)
+        if self.dim_synch is not None:
+            identity = self.dim_synch(identity)
+        output += identity
+        return F.relu(output)
+
+
+class RefResNet(RefBaseModel):                                     # resnet.py:17-117
+    config = {
+        '18': ('basic', [(64, 2, 1), (128, 2, 2), (256, 2, 2), (512, 2, 2)]),
+        '34': ('basic', [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]),
+        '26': ('bottleneck', [(64, 2, 1), (128, 2, 2), (256, 2, 2), (512, 2, 2)]),
+        '50': ('bottleneck', [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]),
+        '101': ('bottleneck', [(64, 3, 1), (128, 4, 2), (256, 23, 2), (512, 3, 2)]),
+        '152': ('bottleneck', [(64, 3, 1), (128, 8, 2), (256, 36, 2), (512, 3, 2)]),
+    }
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        kind, cfg = self.config[str(setting.kind)]
+        block_type = RefResBottleneck if kind == 'bottleneck' else RefResBlock
+        expansion = 4 if kind == 'bottleneck' else 1
+        layers = [self.conv2d_block(num_filters=64, kernel_size=7, stride=2, padding=3),
+                  self.maxpool2d(kernel_size=3, stride=2, padding=1)]
+        for num_filters, num_repeat, stride in cfg:
+            layers += [self.residual_block(block_type, num_filters, expansion, stride)]
+            for _ in range(1, num_repeat):
+                layers += [self.residual_block(block_type, num_filters, expansion)]
+        layers += [self.adapt_avgpool2d(output_size=1)]
+        self.features = nn.Sequential(*layers)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+    def residual_block(self, block_type, num_filters, expansion, stride=1):   # resnet.py:85-98
+        if stride != 1 or self.in_channels != num_filters * expansion:
+            dim_synch = self.conv2d_block(self.in_channels, num_filters * expansion,
+                                          set_output=False, activation=False, kernel_size=1,
+                                          stride=stride)
+        else:
+            dim_synch = None
+        return block_type(self, num_filters=num_filters, expansion=expansion, dim_synch=dim_synch,
+                          stride=stride)
+
+
+class RefVGGNet(RefBaseModel):                                     # vggnet.py:17-103
+    config = {
+        '11': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+        '13': [64, 64, 'M', 128, 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+        '16': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M',
+               512, 512, 512, 'M'],
+        '19': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
+               512, 512, 512, 512, 'M'],
+    }
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        layers = []
+        for element in self.config[str(setting.kind)]:
+            if element == 'M':
+                layers += [self.maxpool2d(kernel_size=2, stride=2)]
+            else:
+                layers += [self.conv2d_block(num_filters=element, kernel_size=3, padding=1)]
+        layers += [self.adapt_avgpool2d(output_size=1)]
+        self.features = nn.Sequential(*layers)
+        p = setting.dropout_rate
+        self.classifier = nn.Sequential(
+            nn.Dropout(p=p), nn.Linear(self.num_flat_features(), 4096), nn.ReLU(inplace=True),
+            nn.Dropout(p=p), nn.Linear(4096, 4096), nn.ReLU(inplace=True),
+            nn.Dropout(p=p), nn.Linear(4096, setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
+class RefConvNet(RefBaseModel):                                    # basemodel.py:1070-1108
+    def __init__(self, setting):
+        super().__init__(setting)
+        self.features = nn.Sequential(
+            self.conv2d_block(num_filters=32, kernel_size=3),
+            self.maxpool2d(kernel_size=2, stride=2),
+            self.conv2d_block(num_filters=64, kernel_size=5, stride=2, padding=1),
+            self.maxpool2d(kernel_size=2, stride=2))
+        self.classifier = nn.Sequential(
+            nn.Linear(self.num_flat_features(), 2048), nn.ReLU(inplace=True),
+            nn.Dropout(p=setting.dropout_rate), nn.Linear(2048, setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
+class RefLeNet5(RefBaseModel):
+    """LeNet-5 (BASELINE.json config 1) in template_net.py:17-66 style; not in the reference (F5).
+    conv5x5(6) pad 2 -> pool2 -> conv5x5(16) -> pool2 -> 400-120-84-classes, ReLU + max-pool as
+    the reference's factory offers (its avgpool/tanh-free vocabulary)."""
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        self.features = nn.Sequential(
+            self.conv2d_block(num_filters=6, kernel_size=5, padding=2),
+            self.maxpool2d(kernel_size=2, stride=2),
+            self.conv2d_block(num_filters=16, kernel_size=5),
+            self.maxpool2d(kernel_size=2, stride=2))
+        self.classifier = nn.Sequential(
+            nn.Linear(self.num_flat_features(), 120), nn.ReLU(inplace=True),
+            nn.Linear(120, 84), nn.ReLU(inplace=True),
+            nn.Dropout(p=setting.dropout_rate), nn.Linear(84, setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
+class RefAlexNet(RefBaseModel):
+    """AlexNet (BASELINE.json config 2: 11x11/4, 5x5 p2, three 3x3 p1) in the reference's
+    template style with its GAP-free 6x6 flatten; single-tower channel plan 64/192/384/256/256."""
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        self.features = nn.Sequential(
+            self.conv2d_block(num_filters=64, kernel_size=11, stride=4, padding=2),
+            self.maxpool2d(kernel_size=3, stride=2),
+            self.conv2d_block(num_filters=192, kernel_size=5, padding=2),
+            self.maxpool2d(kernel_size=3, stride=2),
+            self.conv2d_block(num_filters=384, kernel_size=3, padding=1),
+            self.conv2d_block(num_filters=256, kernel_size=3, padding=1),
+            self.conv2d_block(num_filters=256, kernel_size=3, padding=1),
+            self.maxpool2d(kernel_size=3, stride=2))
+        p = setting.dropout_rate
+        self.classifier = nn.Sequential(
+            nn.Dropout(p=p), nn.Linear(self.num_flat_features(), 4096), nn.ReLU(inplace=True),
+            nn.Dropout(p=p), nn.Linear(4096, 4096), nn.ReLU(inplace=True),
+            nn.Linear(4096, setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
+def ref_training_step(model, inputs, targets):
+    """One iteration of the loop body basemodel.py:245-288, fp32 branch (:273-284):
+    zero_grad -> forward -> CE(sum) -> score -> backward -> (clipping off) -> optimizer.step.
+    Returns (loss, correct) like training_step() :204-215 / score() :111-128."""
+    model.train()
+    model.optimizer.zero_grad()
+    outputs = model(inputs)
+    loss = model.cost_function(outputs, targets)
+    with torch.no_grad():
+        correct = int((outputs.argmax(dim=1) == targets).sum())
+    loss.backward()
+    model.optimizer.step()
+    return float(loss.detach()), correct
+
+
+def synthetic_batch(batch_size, input_size, num_classes, seed=21):
+    """x ~ N(0,1) like the reference's own timing tensor (basemodel.py:646); uniform targets."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.randn(batch_size, *input_size, generator=g)
+    y = torch.randint(0, num_classes, (batch_size,), generator=g)
+    return x, y
+
+
+MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
+          'alexnet': RefAlexNet}
