@@ -1,0 +1,12 @@
+"""convnets_amd -- MI355X-native conv / batch-norm / max-pool / ReLU training path behind the layer
+factory of milan-pavlovic-ai/ConvNets.  The compute lives in libcnk.so
+(include/cnk.h, convnets_amd/csrc/); this package is the host-side mirror of the reference's
+factory, models and training step.  There is no CPU fallback."""
+from .settings import Settings, DeviceMngr                      # noqa: F401
+from .basemodel import MultiClassBaseModel                      # noqa: F401
+from .resnet import ResNet, ResBlock, ResBottleneck             # noqa: F401
+from .vggnet import VGGNet                                      # noqa: F401
+from .convnet import ConvNet, LeNet5, AlexNet                   # noqa: F401
+from .optim import FlatAdam                                     # noqa: F401
+
+MODELS = {'resnet': ResNet, 'vgg': VGGNet, 'convnet': ConvNet, 'lenet5': LeNet5, 'alexnet': AlexNet}

@@ -1,0 +1,89 @@
+"""ctypes binding of libcnk.so -- the C-ABI of include/cnk.h (built by convnets_amd/build.py).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.  The
+oracle (oracle/) is never imported from here.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libcnk.so')
+
+CNK_F32, CNK_BF16 = 0, 1
+PASS_FWD, PASS_DGRAD, PASS_WGRAD = 0, 1, 2
+CLS = dict(conv3x3_fwd=1, conv3x3_dgrad=2, conv3x3_wgrad=4, conv1x1_fwd=8, conv1x1_dgrad=16,
+           conv1x1_wgrad=32, bn_fwd=64, bn_bwd=128, other=256)
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('N', 'H', 'W', 'Cin', 'Cout', 'kh', 'kw', 'stride_h', 'stride_w', 'pad_h', 'pad_w',
+                 'dtype')]
+
+
+_vp, _i32, _i64, _f32, _sz = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
+                              ctypes.c_size_t)
+_dp = ctypes.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol declared in include/cnk.h
+SIGNATURES = {
+    'cnk_version': (ctypes.c_int, []),
+    'cnk_last_error': (ctypes.c_char_p, []),
+    'cnk_conv2d_out_hw': (ctypes.c_int, [_dp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    'cnk_conv2d_packed_bytes': (_sz, [_dp, ctypes.c_int]),
+    'cnk_conv2d_workspace_bytes': (_sz, [_dp, ctypes.c_int]),
+    'cnk_conv2d_pack_weights': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp]),
+    'cnk_conv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'cnk_conv2d_wgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
+    'cnk_bn_workspace_bytes': (_sz, [_i64, _i32]),
+    'cnk_bn_fwd_train': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
+                                        _f32, _f32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
+    'cnk_bn_fwd_eval': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32,
+                                       ctypes.c_int, ctypes.c_int, _vp]),
+    'cnk_bn_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                  _i64, _i32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
+    'cnk_maxpool2d_fwd': (ctypes.c_int, [_vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
+    'cnk_maxpool2d_bwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
+    'cnk_relu_fwd': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp]),
+    'cnk_relu_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
+    'cnk_add_relu_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
+    'cnk_gap_fwd': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_gap_bwd': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_nchw_to_nhwc': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32,
+                                     _vp]),
+    'cnk_prof_begin': (ctypes.c_int, [_i32]),
+    'cnk_prof_collect': (ctypes.c_int, [_i32, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double)]),
+    'cnk_prof_end': (ctypes.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libcnk.so and types every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'convnets_amd: %s is missing -- the HIP library is the product; there is no CPU '
+                'fallback. Build it with `python -m convnets_amd.build` (needs hipcc).' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class CnkError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise CnkError('libcnk error %d: %s' % (rc, load().cnk_last_error().decode()))

@@ -1,0 +1,205 @@
+"""Host-side mirror of the reference's MultiClassBaseModel for the hot path (src/basemodel.py).
+
+Same method names, keyword arguments and error behaviour as the reference's layer factory
+(:966-1042), shape tracker (:725-816), init_params (:85-108) and training-step sequence
+(:180-215, :231-346), so model definitions written against the reference read the same here.
+What differs is what the factory RETURNS: subclasses of the stock modules whose forward runs the
+hand-written HIP kernels (convnets_amd/layers.py).  Out of scope: fit()'s
+epoch driver, checkpoints, sklearn reports, plotting, tuner.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import layers, ops
+from .optim import FlatAdam
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class MultiClassBaseModel(nn.Module):
+    def __init__(self, setting):
+        super().__init__()
+        self.setting = setting
+        self.model_name = self.__class__.__name__ + str(setting.kind)
+        self.in_channels, self.height, self.width = setting.input_size      # basemodel.py:41-43
+        self.cost_function = nn.CrossEntropyLoss(reduction='sum')           # basemodel.py:46
+        self.optimizer = None
+        self.grad_reducer = None          # data-parallel hook (convnets_amd/dp.py); None on 1 GPU
+
+    # ---- optimizer / init (basemodel.py:58-108) ------------------------------------------------
+    def init_optimizer(self):
+        """Adam(lr, weight_decay) as basemodel.py:64-67, over a flat HBM arena.  The reference's
+        ReduceLROnPlateau / GradScaler belong to fit() (out of scope; bf16 needs no loss scaling)."""
+        self.optimizer = FlatAdam(self.parameters(), lr=self.setting.learning_rate,
+                                  weight_decay=self.setting.weight_decay)
+        return self.optimizer
+
+    def init_params(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0, std=0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        ops.bump_weights_epoch()
+        return out
+
+    # ---- step pieces (basemodel.py:111-229) -----------------------------------------------------
+    @torch.no_grad()
+    def score(self, outputs, targets):
+        """Count of correct predictions (basemodel.py:119-121) -- kept on the device; the caller
+        decides when to pay the host sync."""
+        return (outputs.argmax(dim=1) == targets).sum()
+
+    def gradient_clipping(self):
+        if self.setting.grad_clip_norm:
+            torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=self.setting.gc_max_norm)
+        if self.setting.grad_clip_value:
+            torch.nn.utils.clip_grad_value_(self.parameters(), clip_value=self.setting.gc_value)
+
+    def forward_step(self, batch):
+        inputs, targets = self.setting.device.move(batch)
+        outputs = self(inputs)
+        loss = self.cost_function(outputs, targets)
+        return loss, self.score(outputs, targets)
+
+    @torch.enable_grad()
+    def training_step(self, batch):
+        return self.forward_step(batch)
+
+    @torch.no_grad()
+    def validation_step(self, batch):
+        return self.forward_step(batch)
+
+    def train_batch(self, batch):
+        """One iteration of the reference's loop body (basemodel.py:245-288): zero_grad, forward,
+        CE(sum) loss, backward, [gradient all-reduce], clipping (off by default), optimizer step.
+        Returns (loss, correct) as DEVICE scalars."""
+        self.optimizer.zero_grad()
+        if self.grad_reducer is not None:
+            self.grad_reducer.begin_step()
+        loss, score = self.training_step(batch)
+        loss.backward()
+        if self.grad_reducer is not None:
+            self.grad_reducer.finish_step()
+        self.gradient_clipping()
+        self.optimizer.step()
+        return loss.detach(), score
+
+    @torch.enable_grad()
+    def train_model(self, dataloader):
+        """basemodel.py:231-302 with the two per-step host syncs (:121, :287) replaced by
+        device-side accumulation and ONE sync per epoch; returned values are identical."""
+        self.train()
+        if self.optimizer is None:
+            self.init_optimizer()
+        epoch_loss = torch.zeros((), dtype=torch.float64, device=self.setting.device.device)
+        epoch_score = torch.zeros((), dtype=torch.int64, device=self.setting.device.device)
+        for batch in dataloader:
+            loss, score = self.train_batch(batch)
+            epoch_loss += loss.double()
+            epoch_score += score
+            if self.setting.sanity_check:
+                break
+        n = len(dataloader.dataset)
+        return epoch_loss.item() / n, epoch_score.item() / n
+
+    @torch.no_grad()
+    def valid_model(self, dataloader):
+        """basemodel.py:304-346."""
+        self.eval()
+        epoch_loss = torch.zeros((), dtype=torch.float64, device=self.setting.device.device)
+        epoch_score = torch.zeros((), dtype=torch.int64, device=self.setting.device.device)
+        for batch in dataloader:
+            loss, score = self.validation_step(batch)
+            epoch_loss += loss.double()
+            epoch_score += score
+            if self.setting.sanity_check:
+                break
+        n = len(dataloader.dataset)
+        return epoch_loss.item() / n, epoch_score.item() / n
+
+    # ---- shape tracker (basemodel.py:725-816) ---------------------------------------------------
+    def save_conv_outshape(self, layer):
+        kh, kw = _pair(layer.kernel_size)
+        sh, sw = _pair(layer.stride)
+        ph, pw = _pair(layer.padding)
+        dh, dw = _pair(layer.dilation) if hasattr(layer, 'dilation') else (1, 1)
+        self.height = int(np.floor(1 + (self.height + 2 * ph - dh * (kh - 1) - 1) / sh))
+        self.width = int(np.floor(1 + (self.width + 2 * pw - dw * (kw - 1) - 1) / sw))
+        if isinstance(layer, nn.Conv2d):
+            self.in_channels = layer.out_channels
+        return self.in_channels, self.height, self.width
+
+    def save_adapt_outshape(self, layer):
+        self.height, self.width = _pair(layer.output_size)
+        return self.in_channels, self.height, self.width
+
+    def num_flat_features(self):
+        return self.in_channels * self.height * self.width
+
+    def get_learning_rate(self):
+        return self.optimizer.param_groups[0]['lr']
+
+    def update_learning_rate(self):
+        self.optimizer.param_groups[0]['lr'] = self.setting.learning_rate
+
+    # ---- layer factory: THE drop-in boundary (basemodel.py:966-1042) ----------------------------
+    def conv2d(self, in_channels=None, num_filters=None, set_output=True, **kwargs):
+        if in_channels is None:
+            in_channels = self.in_channels
+        layer = layers.Conv2d(in_channels, num_filters, **kwargs, bias=not self.setting.batch_norm)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
+
+    def conv2d_depthwise(self, in_channels=None, num_filters=None, set_output=True, **kwargs):
+        raise NotImplementedError('conv2d_depthwise (basemodel.py:981-997) is outside the hot path: '
+                                  'LeNet/AlexNet/VGG/ResNet use groups=1 (SURVEY.md section 8f, n4)')
+
+    def conv2d_block(self, in_channels=None, num_filters=None, set_output=True, activation=True,
+                     **kwargs):
+        mods = [self.conv2d(in_channels, num_filters, set_output, **kwargs)]
+        if self.setting.batch_norm:
+            mods += [layers.BatchNorm2d(num_features=num_filters)]
+        if activation:
+            mods += [layers.ReLU(inplace=True)]
+        return layers.ConvBlock(*mods)
+
+    def maxpool2d(self, set_output=True, **kwargs):
+        layer = layers.MaxPool2d(**kwargs)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
+
+    def avgpool2d(self, set_output=True, **kwargs):
+        raise NotImplementedError('avgpool2d (basemodel.py:1026-1033) is used only by DenseNet, '
+                                  'outside the hot path (SURVEY.md section 2, row 12)')
+
+    def adapt_avgpool2d(self, set_output=True, **kwargs):
+        layer = layers.AdaptiveAvgPool2d(**kwargs)
+        if set_output:
+            self.save_adapt_outshape(layer)
+        return layer
+
+    # ---- forward: features -> flatten -> classifier (resnet.py:110-117 et al.) -------------------
+    def forward(self, x):
+        if x.dim() != 4 or tuple(x.shape[1:]) != tuple(self.setting.input_size):
+            raise ValueError('expected input [N,%d,%d,%d], got %s' % (*self.setting.input_size, tuple(x.shape)))
+        x = ops.nchw_to_nhwc(x, self.setting.compute_dtype)     # NCHW fp32 batch -> NHWC compute dtype
+        x = self.features(x)
+        x = torch.flatten(x, start_dim=1).float()               # head runs in fp32
+        return self.classifier(x)

@@ -1,0 +1,318 @@
+// extern "C" entry points of include/cnk.h: argument checks, kernel-family dispatch, error text,
+// optional HIP-event timing.  No allocation, no synchronisation (except cnk_prof_collect).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+// ---- kernel families (other translation units) ---------------------------------------------------
+bool igemm_supported(const cnk_conv_desc* d, int pass);
+int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, hipStream_t s);
+int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, hipStream_t s);
+int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
+bool wgrad_mfma_supported(const cnk_conv_desc* d);
+size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
+int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int direct_fwd(const cnk_conv_desc* d, const void* x, const void* w_t, const float* bias, void* y, hipStream_t s);
+int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s);
+size_t direct_wgrad_workspace(const cnk_conv_desc* d);
+int direct_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+size_t colsum_workspace(int64_t M, int C);
+int colsum(const void* a, float* out, int64_t M, int C, int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int pack_direct(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
+int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, const signed char* kh, const signed char* kw, int transpose, hipStream_t s);
+size_t bn_workspace_bytes(int64_t M, int C);
+int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* rm, float* rv, float* sm, float* si, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
+int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
+int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
+int maxpool_dispatch(bool bwd, const void* a, const void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
+template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
+int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
+int nchw_to_nhwc_dispatch(const float* x, void* y, int N, int C, int H, int W, int dtype, hipStream_t s);
+int adam_dispatch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
+
+// ---- error text -----------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void cnk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- HIP-event timing -----------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+std::mutex g_prof_mu;
+int g_prof_mask = 0;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void cnk_prof_start(int cls, hipStream_t s, double flops, double bytes) {
+    if (!(g_prof_mask & cls)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    r.e0 = get_event(); r.e1 = get_event();
+    (void)hipEventRecord(r.e0, s);
+    g_prof.push_back(r);
+}
+void cnk_prof_stop(int cls, hipStream_t s) {
+    if (!(g_prof_mask & cls)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = g_prof.size(); i-- > 0;)
+        if (g_prof[i].cls == cls) {
+            (void)hipEventRecord(g_prof[i].e1, s);
+            break;
+        }
+}
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+static inline size_t esize(int dtype) { return dtype == CNK_BF16 ? 2 : 4; }
+
+static int check_desc(const cnk_conv_desc* d, const char* fn) {
+    CNK_CHECK_ARG(d, "%s: null descriptor", fn);
+    CNK_CHECK_ARG(d->dtype == CNK_F32 || d->dtype == CNK_BF16, "%s: bad dtype %d", fn, d->dtype);
+    CNK_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive dims", fn);
+    CNK_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0, "%s: bad kernel/stride/pad", fn);
+    CNK_CHECK_ARG(d->H + 2 * d->pad_h >= d->kh && d->W + 2 * d->pad_w >= d->kw, "%s: kernel larger than padded input", fn);
+    int64_t Ho = (d->H + 2 * d->pad_h - d->kh) / d->stride_h + 1, Wo = (d->W + 2 * d->pad_w - d->kw) / d->stride_w + 1;
+    CNK_CHECK_ARG((int64_t)d->N * d->H * d->W < (1ll << 31) && (int64_t)d->N * Ho * Wo < (1ll << 31), "%s: pixel count exceeds 2^31", fn);
+    return 0;
+}
+
+static int conv_cls(const cnk_conv_desc* d, int pass) {
+    if (d->kh == 3 && d->kw == 3) return pass == 0 ? CNK_CLS_CONV3X3_FWD : pass == 1 ? CNK_CLS_CONV3X3_DGRAD : CNK_CLS_CONV3X3_WGRAD;
+    if (d->kh == 1 && d->kw == 1) return pass == 0 ? CNK_CLS_CONV1X1_FWD : pass == 1 ? CNK_CLS_CONV1X1_DGRAD : CNK_CLS_CONV1X1_WGRAD;
+    return CNK_CLS_OTHER;
+}
+static void conv_cost(const cnk_conv_desc* d, double* flops, double* bytes) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    double M = (double)d->N * Ho * Wo;
+    *flops = 2.0 * M * d->Cout * d->Cin * d->kh * d->kw;
+    *bytes = ((double)d->N * d->H * d->W * d->Cin + M * d->Cout) * esize(d->dtype) + (double)d->Cout * d->Cin * d->kh * d->kw * esize(d->dtype);
+}
+
+extern "C" {
+
+int cnk_version(void) { return 100; }
+const char* cnk_last_error(void) { return g_err; }
+
+int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo) {
+    *Ho = (d->H + 2 * d->pad_h - d->kh) / d->stride_h + 1;
+    *Wo = (d->W + 2 * d->pad_w - d->kw) / d->stride_w + 1;
+    return 0;
+}
+
+size_t cnk_conv2d_packed_bytes(const cnk_conv_desc* d, int pass) {
+    size_t n = (size_t)d->Cout * d->Cin * d->kh * d->kw;
+    if (pass != CNK_PASS_FWD && pass != CNK_PASS_DGRAD) return 0;
+    return igemm_supported(d, pass) ? n * esize(d->dtype) : n * sizeof(float);
+}
+
+size_t cnk_conv2d_workspace_bytes(const cnk_conv_desc* d, int pass) {
+    if (pass != CNK_PASS_WGRAD) return 0;
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    size_t a = wgrad_mfma_supported(d) ? wgrad_mfma_workspace(d) : direct_wgrad_workspace(d);
+    a = (a + 255) & ~(size_t)255;
+    return a + colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout);
+}
+
+int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_pack_weights")) return rc;
+    CNK_CHECK_ARG(w, "cnk_conv2d_pack_weights: null weight");
+    bool direct_done = false;
+    if (w_fwd) {
+        if (igemm_supported(d, CNK_PASS_FWD)) {
+            signed char kh[32], kw[32];
+            for (int t = 0; t < d->kh * d->kw; ++t) { kh[t] = (signed char)(t / d->kw); kw[t] = (signed char)(t % d->kw); }
+            if (int rc = pack_taps(d, w, w_fwd, d->kh * d->kw, kh, kw, 0, S(stream))) return rc;
+        } else {
+            if (int rc = pack_direct(d, w, w_fwd, S(stream))) return rc;
+            direct_done = true;
+        }
+    }
+    if (w_dgrad) {
+        if (igemm_supported(d, CNK_PASS_DGRAD)) {
+            DgradClass cls[16];
+            CNK_CHECK_ARG(d->stride_h * d->stride_w <= 16, "cnk_conv2d_pack_weights: stride too large");
+            int nc = dgrad_classes(d, cls);
+            size_t off = 0;
+            for (int c = 0; c < nc; ++c) {
+                CNK_CHECK_ARG(cls[c].ntaps <= 32, "cnk_conv2d_pack_weights: too many taps");
+                if (int rc = pack_taps(d, w, (char*)w_dgrad + off * esize(d->dtype), cls[c].ntaps, cls[c].kh, cls[c].kw, 1, S(stream))) return rc;
+                off += (size_t)cls[c].ntaps * d->Cin * d->Cout;
+            }
+        } else if (!(direct_done && w_dgrad == w_fwd)) {
+            if (int rc = pack_direct(d, w, w_dgrad, S(stream))) return rc;
+        }
+    }
+    return 0;
+}
+
+int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (int rc = check_desc(d, "cnk_conv2d_fwd")) return rc;
+    CNK_CHECK_ARG(x && w_fwd && y, "cnk_conv2d_fwd: null pointer");
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
+    if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd(d, x, w_fwd, bias, y, S(stream));
+    return direct_fwd(d, x, w_fwd, bias, y, S(stream));
+}
+
+int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (int rc = check_desc(d, "cnk_conv2d_dgrad")) return rc;
+    CNK_CHECK_ARG(dy && w_dgrad && dx, "cnk_conv2d_dgrad: null pointer");
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
+    if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, S(stream));
+    return direct_dgrad(d, dy, w_dgrad, dx, S(stream));
+}
+
+int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_wgrad")) return rc;
+    CNK_CHECK_ARG(dy && x && dw, "cnk_conv2d_wgrad: null pointer");
+    size_t need = cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD);
+    CNK_CHECK_ARG(workspace && workspace_bytes >= need, "cnk_conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    ProfScope ps(conv_cls(d, 2), S(stream), fl, by);
+    int rc;
+    size_t a;
+    if (wgrad_mfma_supported(d)) {
+        a = wgrad_mfma_workspace(d);
+        rc = wgrad_mfma(d, dy, x, dw, accumulate, workspace, a, S(stream));
+    } else {
+        a = direct_wgrad_workspace(d);
+        rc = direct_wgrad(d, dy, x, dw, accumulate, workspace, a, S(stream));
+    }
+    if (rc) return rc;
+    if (dbias) {
+        int Ho, Wo;
+        cnk_conv2d_out_hw(d, &Ho, &Wo);
+        a = (a + 255) & ~(size_t)255;
+        return colsum(dy, dbias, (int64_t)d->N * Ho * Wo, d->Cout, d->dtype, accumulate, (char*)workspace + a, workspace_bytes - a, S(stream));
+    }
+    return 0;
+}
+
+size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(M, C); }
+
+int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* running_mean, float* running_var, float* save_mean, float* save_invstd, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd, "cnk_bn_fwd_train: null pointer");
+    CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_train: empty tensor");
+    CNK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cnk_bn_fwd_train: running stats must both be given or both NULL");
+    CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_fwd_train: workspace too small");
+    ProfScope ps(CNK_CLS_BN_FWD, S(stream), 0.0, 3.0 * (double)M * C * esize(dtype));
+    return bn_fwd_train(x, gamma, beta, residual, y, running_mean, running_var, save_mean, save_invstd, M, C, eps, momentum, relu, dtype, (float*)workspace, S(stream));
+}
+
+int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var, const void* residual, void* y, int64_t M, int32_t C, float eps, int relu, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && gamma && beta && y && running_mean && running_var, "cnk_bn_fwd_eval: null pointer");
+    CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_eval: empty tensor");
+    return bn_fwd_eval(x, gamma, beta, running_mean, running_var, residual, y, M, C, eps, relu, dtype, S(stream));
+}
+
+int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "cnk_bn_bwd: null pointer");
+    CNK_CHECK_ARG(!relu || y, "cnk_bn_bwd: relu backward needs the forward output");
+    CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd: empty tensor");
+    CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd: workspace too small");
+    ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, 5.0 * (double)M * C * esize(dtype));
+    return bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, M, C, relu, dtype, (float*)workspace, S(stream));
+}
+
+int cnk_maxpool2d_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y, "cnk_maxpool2d_fwd: null pointer");
+    CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && H + 2 * ph >= kh && W + 2 * pw >= kw, "cnk_maxpool2d_fwd: bad geometry");
+    return maxpool_dispatch(false, x, nullptr, y, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+}
+int cnk_maxpool2d_bwd(const void* dy, const void* x, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+    CNK_CHECK_ARG(dy && x && dx, "cnk_maxpool2d_bwd: null pointer");
+    CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && H + 2 * ph >= kh && W + 2 * pw >= kw, "cnk_maxpool2d_bwd: bad geometry");
+    return maxpool_dispatch(true, dy, x, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+}
+
+int cnk_relu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y && n >= 0, "cnk_relu_fwd: bad arguments");
+    return eltwise_dispatch<0>(x, nullptr, y, n, dtype, S(stream));
+}
+int cnk_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream) {
+    CNK_CHECK_ARG(dy && y && dx && n >= 0, "cnk_relu_bwd: bad arguments");
+    return eltwise_dispatch<1>(dy, y, dx, n, dtype, S(stream));
+}
+int cnk_add_relu_fwd(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
+    CNK_CHECK_ARG(a && b && y && n >= 0, "cnk_add_relu_fwd: bad arguments");
+    return eltwise_dispatch<2>(a, b, y, n, dtype, S(stream));
+}
+
+int cnk_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y && N > 0 && HW > 0 && C > 0, "cnk_gap_fwd: bad arguments");
+    return gap_dispatch(false, x, y, N, HW, C, dtype, S(stream));
+}
+int cnk_gap_bwd(const float* dy, void* dx, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
+    CNK_CHECK_ARG(dy && dx && N > 0 && HW > 0 && C > 0, "cnk_gap_bwd: bad arguments");
+    return gap_dispatch(true, dy, dx, N, HW, C, dtype, S(stream));
+}
+
+int cnk_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int32_t N, int32_t C, int32_t H, int32_t W, int dtype, void* stream) {
+    CNK_CHECK_ARG(x_nchw && y_nhwc && N > 0 && C > 0 && H > 0 && W > 0, "cnk_nchw_to_nhwc: bad arguments");
+    return nchw_to_nhwc_dispatch(x_nchw, y_nhwc, N, C, H, W, dtype, S(stream));
+}
+
+int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+    CNK_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "cnk_adam_step: bad arguments");
+    CNK_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "cnk_adam_step: arenas must be 16-byte aligned");
+    return adam_dispatch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
+
+int cnk_prof_begin(int32_t class_mask) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
+    g_prof.clear();
+    g_prof_mask = class_mask;
+    return 0;
+}
+int cnk_prof_collect(int32_t cls, int64_t* count, double* total_ms, double* total_flops, double* total_bytes) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int64_t n = 0;
+    double ms = 0, fl = 0, by = 0;
+    for (auto& r : g_prof) {
+        if (!(r.cls & cls)) continue;
+        if (hipEventSynchronize(r.e1) != hipSuccess) { cnk_set_error("cnk_prof_collect: event sync failed"); return 3; }
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) { cnk_set_error("cnk_prof_collect: elapsed failed"); return 3; }
+        ms += t; fl += r.flops; by += r.bytes; ++n;
+    }
+    if (count) *count = n;
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (total_bytes) *total_bytes = by;
+    return 0;
+}
+int cnk_prof_end(void) { return cnk_prof_begin(0); }
+
+}  // extern "C"

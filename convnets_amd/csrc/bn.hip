@@ -1,0 +1,430 @@
+// Batch normalisation over NHWC-flattened [M][C] activations, HBM-bound streaming kernels.
+//
+// forward (train):  pass 1  bn_stats      per row-slice partial (count, mean, M2) per channel,
+//                                          16-byte vector loads along C (coalesced), fp32 maths
+//                   pass 1b bn_finalize   merges slices with Chan's parallel-variance update,
+//                                          writes mean / invstd / running stats / scale+shift
+//                   pass 2  bn_apply      y = act(x*scale + shift [+ residual])      (fused ReLU / add)
+// backward:         pass 1  bn_bwd_reduce per-slice sums of dy' and dy'*xhat (dy' = ReLU-masked dy)
+//                   pass 1b bn_bwd_final  dgamma / dbeta (+= when accumulating) and apply coeffs
+//                   pass 2  bn_bwd_apply  dx = a*(dy' - b1 - xhat*b2); optional dresidual = dy'
+// Algorithmic bytes: forward 3*E*s (x twice, y once), backward reads dy,x(,y) twice + writes dx.
+#include "common.h"
+
+namespace {
+
+template <typename T, int VEC> struct VLoad {
+    float f[VEC];
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (VEC == 1) {
+            f[0] = to_f32(p[0]);
+        } else {
+            Vec16<T> v;
+            v.v = *(const decltype(v.v)*)p;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = v.get(i);
+        }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if constexpr (VEC == 1) {
+            p[0] = from_f32<T>(f[0]);
+        } else {
+            Vec16<T> v;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v.set(i, f[i]);
+            *(decltype(v.v)*)p = v.v;
+        }
+    }
+};
+
+struct SliceGeom {
+    int cols;        // vector columns (C / VEC)
+    int cpb;         // vector columns per block (<= 256)
+    int rpb;         // rows per block iteration (256 / cpb)
+    int slice_rows;  // rows per slice
+    int slices;      // grid.x
+    int colgroups;   // grid.y
+};
+
+SliceGeom make_geom(int64_t M, int C, int vec) {
+    SliceGeom g;
+    g.cols = C / vec;
+    g.cpb = g.cols < 256 ? g.cols : 256;
+    g.rpb = 256 / g.cpb;
+    g.colgroups = ceil_div(g.cols, g.cpb);
+    int64_t sr = (int64_t)g.rpb * 32;
+    if (ceil_div64(M, sr) > 2048) sr = ceil_div64(ceil_div64(M, 2048), g.rpb) * g.rpb;
+    g.slice_rows = (int)sr;
+    g.slices = (int)ceil_div64(M, sr);
+    return g;
+}
+
+// workspace layout (floats): [0,C) scale  [C,2C) shift  [2C,3C) coefB1  [3C,4C) coefB2
+//                            then partials: slices * C * 3
+__host__ __device__ inline size_t ws_partials_off(int C) { return (size_t)4 * C; }
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x,
+                                                       float* __restrict__ partial, int64_t M,
+                                                       int C, SliceGeom g) {
+    __shared__ float sh[3][256 * (VEC > 1 ? VEC : 1)];
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    const bool active = trow < g.rpb && vcol < g.cols;
+    const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
+    float s[VEC], ss[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = ss[i] = 0.f;
+    int n = 0;
+    if (active) {
+        for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
+            VLoad<T, VEC> v;
+            v.load(x + m * C + (int64_t)vcol * VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                s[i] += v.f[i];
+                ss[i] += v.f[i] * v.f[i];
+            }
+            ++n;
+        }
+    }
+    // per-thread (n, mean, M2), then Chan merge over the block's row-threads
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float mean = n ? s[i] / n : 0.f;
+        float m2 = n ? ss[i] - s[i] * mean : 0.f;
+        sh[0][tid * VEC + i] = (float)n;
+        sh[1][tid * VEC + i] = mean;
+        sh[2][tid * VEC + i] = m2 > 0.f ? m2 : 0.f;
+    }
+    __syncthreads();
+    if (trow == 0 && vcol < g.cols) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float na = sh[0][tid * VEC + i], ma = sh[1][tid * VEC + i], qa = sh[2][tid * VEC + i];
+            for (int r = 1; r < g.rpb; ++r) {
+                int o = (r * g.cpb + tcol) * VEC + i;
+                float nb = sh[0][o], mb = sh[1][o], qb = sh[2][o];
+                if (nb > 0.f) {
+                    float nt = na + nb, d = mb - ma;
+                    ma += d * (nb / nt);
+                    qa += qb + d * d * (na * nb / nt);
+                    na = nt;
+                }
+            }
+            int c = vcol * VEC + i;
+            float* o = partial + ((size_t)blockIdx.x * C + c) * 3;
+            o[0] = na; o[1] = ma; o[2] = qa;
+        }
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int slices, int C, int64_t M,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, float* save_mean,
+                                   float* save_invstd, float* scale, float* shift, float eps,
+                                   float momentum) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        const float* o = partial + ((size_t)s * C + c) * 3;
+        float nb = o[0], mb = o[1], qb = o[2];
+        if (nb > 0.f) {
+            float nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+    }
+    float var = qa / (float)M;
+    float invstd = rsqrtf(var + eps);
+    // one Newton step: rsqrtf is ~1 ulp, this keeps fp32 parity tight
+    invstd = invstd * (1.5f - 0.5f * (var + eps) * invstd * invstd);
+    save_mean[c] = ma;
+    save_invstd[c] = invstd;
+    if (running_mean) {
+        float unb = M > 1 ? qa / (float)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ma;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - ma * sc;
+}
+
+__global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rmean,
+                                    const float* rvar, float* scale, float* shift, int C, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
+                                                       const T* __restrict__ res, T* __restrict__ y,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       int64_t nvec, int C, int relu) {
+    const int cols = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int c0 = (int)(i % cols) * VEC;
+        VLoad<T, VEC> v, r;
+        v.load(x + i * VEC);
+        if (res) r.load(res + i * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float o = v.f[k] * scale[c0 + k] + shift[c0 + k];
+            if (res) o += r.f[k];
+            if (relu) o = o > 0.f ? o : 0.f;
+            v.f[k] = o;
+        }
+        v.store(y + i * VEC);
+    }
+}
+
+// eval without workspace: coefficients recomputed per element from the running statistics
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_eval_kernel(const T* __restrict__ x,
+                                                      const T* __restrict__ res, T* __restrict__ y,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ rmean,
+                                                      const float* __restrict__ rvar, int64_t nvec,
+                                                      int C, float eps, int relu) {
+    const int cols = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int c0 = (int)(i % cols) * VEC;
+        VLoad<T, VEC> v, r;
+        v.load(x + i * VEC);
+        if (res) r.load(res + i * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            int c = c0 + k;
+            float sc = gamma[c] / sqrtf(rvar[c] + eps);
+            float o = (v.f[k] - rmean[c]) * sc + beta[c];
+            if (res) o += r.f[k];
+            if (relu) o = o > 0.f ? o : 0.f;
+            v.f[k] = o;
+        }
+        v.store(y + i * VEC);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
+    int64_t M, int C, int relu, SliceGeom g) {
+    __shared__ float sh[2][256 * (VEC > 1 ? VEC : 1)];
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    const bool active = trow < g.rpb && vcol < g.cols;
+    const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
+    float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        s1[i] = s2[i] = 0.f;
+        mu[i] = active ? mean[vcol * VEC + i] : 0.f;
+        is[i] = active ? invstd[vcol * VEC + i] : 0.f;
+    }
+    if (active) {
+        for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
+            int64_t off = m * C + (int64_t)vcol * VEC;
+            VLoad<T, VEC> vd, vx, vy;
+            vd.load(dy + off);
+            vx.load(x + off);
+            if (relu) vy.load(y + off);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float d = vd.f[i];
+                if (relu && !(vy.f[i] > 0.f)) d = 0.f;
+                s1[i] += d;
+                s2[i] += d * (vx.f[i] - mu[i]) * is[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sh[0][tid * VEC + i] = s1[i];
+        sh[1][tid * VEC + i] = s2[i];
+    }
+    __syncthreads();
+    if (trow == 0 && vcol < g.cols) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float a = sh[0][tid * VEC + i], b = sh[1][tid * VEC + i];
+            for (int r = 1; r < g.rpb; ++r) {
+                int o = (r * g.cpb + tcol) * VEC + i;
+                a += sh[0][o];
+                b += sh[1][o];
+            }
+            int c = vcol * VEC + i;
+            float* o = partial + ((size_t)blockIdx.x * C + c) * 2;
+            o[0] = a; o[1] = b;
+        }
+    }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int slices, int C, int64_t M,
+                                    const float* __restrict__ gamma,
+                                    const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                    float* coefA, float* coefB1, float* coefB2, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        const float* o = partial + ((size_t)s * C + c) * 2;
+        a += o[0];
+        b += o[1];
+    }
+    dbeta[c] = accumulate ? dbeta[c] + a : a;
+    dgamma[c] = accumulate ? dgamma[c] + b : b;
+    coefA[c] = gamma[c] * invstd[c];
+    coefB1[c] = a / (float)M;
+    coefB2[c] = b / (float)M;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ dx,
+    T* __restrict__ dres, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ coefA, const float* __restrict__ coefB1,
+    const float* __restrict__ coefB2, int64_t nvec, int C, int relu) {
+    const int cols = C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int c0 = (int)(i % cols) * VEC;
+        VLoad<T, VEC> vd, vx, vy, vo;
+        vd.load(dy + i * VEC);
+        vx.load(x + i * VEC);
+        if (relu) vy.load(y + i * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            int c = c0 + k;
+            float d = vd.f[k];
+            if (relu && !(vy.f[k] > 0.f)) d = 0.f;
+            vd.f[k] = d;
+            float xh = (vx.f[k] - mean[c]) * invstd[c];
+            vo.f[k] = coefA[c] * (d - coefB1[c] - xh * coefB2[c]);
+        }
+        vo.store(dx + i * VEC);
+        if (dres) vd.store(dres + i * VEC);
+    }
+}
+
+inline int grid_for(int64_t nvec) {
+    int64_t b = (nvec + 255) / 256;
+    return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+}
+
+template <typename T> constexpr int vec_of() { return ElemTraits<T>::PER16; }
+
+}  // namespace
+
+size_t bn_workspace_bytes(int64_t M, int C) {
+    // worst case geometry: VEC = 1
+    SliceGeom g1 = make_geom(M, C, 1);
+    size_t n = ws_partials_off(C) + (size_t)g1.slices * C * 3;
+    SliceGeom g4 = make_geom(M, C, C % 4 == 0 ? 4 : 1), g8 = make_geom(M, C, C % 8 == 0 ? 8 : 1);
+    size_t n4 = ws_partials_off(C) + (size_t)g4.slices * C * 3;
+    size_t n8 = ws_partials_off(C) + (size_t)g8.slices * C * 3;
+    if (n4 > n) n = n4;
+    if (n8 > n) n = n8;
+    return n * sizeof(float);
+}
+
+template <typename T, int VEC>
+static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* res,
+                          void* y, float* rm, float* rv, float* sm, float* si, int64_t M, int C,
+                          float eps, float mom, int relu, float* ws, hipStream_t s) {
+    SliceGeom g = make_geom(M, C, VEC);
+    float* scale = ws;
+    float* shift = ws + C;
+    float* partial = ws + ws_partials_off(C);
+    hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
+                       (const T*)x, partial, M, C, g);
+    CNK_CHECK_LAUNCH("bn_stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, g.slices, C,
+                       M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
+    CNK_CHECK_LAUNCH("bn_finalize");
+    int64_t nvec = M * C / VEC;
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)x,
+                       (const T*)res, (T*)y, scale, shift, nvec, C, relu);
+    CNK_CHECK_LAUNCH("bn_apply");
+    return 0;
+}
+
+int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y,
+                 float* rm, float* rv, float* sm, float* si, int64_t M, int C, float eps, float mom,
+                 int relu, int dtype, float* ws, hipStream_t s) {
+    if (dtype == CNK_BF16) {
+        if (C % 8 == 0) return bn_fwd_train_t<bf16, 8>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
+        return bn_fwd_train_t<bf16, 1>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
+    }
+    if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
+    return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
+}
+
+template <typename T, int VEC>
+static int bn_eval_t(const void* x, const float* gamma, const float* beta, const float* rm,
+                     const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu,
+                     hipStream_t s) {
+    int64_t nvec = M * C / VEC;
+    hipLaunchKernelGGL((bn_eval_kernel<T, VEC>), dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)x,
+                       (const T*)res, (T*)y, gamma, beta, rm, rv, nvec, C, eps, relu);
+    CNK_CHECK_LAUNCH("bn_eval");
+    return 0;
+}
+
+int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm,
+                const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu,
+                int dtype, hipStream_t s) {
+    if (dtype == CNK_BF16) {
+        if (C % 8 == 0) return bn_eval_t<bf16, 8>(x, gamma, beta, rm, rv, res, y, M, C, eps, relu, s);
+        return bn_eval_t<bf16, 1>(x, gamma, beta, rm, rv, res, y, M, C, eps, relu, s);
+    }
+    if (C % 4 == 0) return bn_eval_t<float, 4>(x, gamma, beta, rm, rv, res, y, M, C, eps, relu, s);
+    return bn_eval_t<float, 1>(x, gamma, beta, rm, rv, res, y, M, C, eps, relu, s);
+}
+
+template <typename T, int VEC>
+static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* gamma,
+                    const float* sm, const float* si, void* dx, void* dres, float* dgamma,
+                    float* dbeta, int accumulate, int64_t M, int C, int relu, float* ws,
+                    hipStream_t s) {
+    SliceGeom g = make_geom(M, C, VEC);
+    float* coefA = ws;
+    float* coefB1 = ws + 2 * C;
+    float* coefB2 = ws + 3 * C;
+    float* partial = ws + ws_partials_off(C);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
+                       (const T*)dy, (const T*)x, (const T*)y, sm, si, partial, M, C, relu, g);
+    CNK_CHECK_LAUNCH("bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, g.slices,
+                       C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
+    CNK_CHECK_LAUNCH("bn_bwd_final");
+    int64_t nvec = M * C / VEC;
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC>), dim3(grid_for(nvec)), dim3(256), 0, s,
+                       (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, sm, si, coefA, coefB1,
+                       coefB2, nvec, C, relu);
+    CNK_CHECK_LAUNCH("bn_bwd_apply");
+    return 0;
+}
+
+int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* sm,
+           const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
+           int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s) {
+    if (dtype == CNK_BF16) {
+        if (C % 8 == 0) return bn_bwd_t<bf16, 8>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+        return bn_bwd_t<bf16, 1>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+    }
+    if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+    return bn_bwd_t<float, 1>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+}

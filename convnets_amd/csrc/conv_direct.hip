@@ -1,0 +1,278 @@
+// Generic NHWC convolution kernels for shapes the MFMA implicit-GEMM tiles do not cover
+// (Cin of 1/3/6/32..., Cout below 64: the LeNet-5 / ConvNet layers and the first layer of
+// AlexNet / VGG / ResNet), plus the weight re-layout kernels.  fp32 accumulation throughout.
+//
+// Direct-path weight image (fwd and dgrad share it): w_t[kh][kw][Cin][Cout] fp32.
+#include "common.h"
+
+namespace {
+
+struct DirectParams {
+    const void* a;      // fwd: x      dgrad: dy     wgrad: dy
+    const void* b;      // fwd: w_t    dgrad: w_t    wgrad: x
+    void* out;          // fwd: y      dgrad: dx     wgrad: slab
+    const float* bias;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw;
+    int M;              // fwd/wgrad: N*Ho*Wo   dgrad: N*H*W
+    int chunk;          // wgrad: pixels per grid.y slice
+    FastDiv fd_a, fd_b; // fwd/wgrad: (Ho*Wo, Wo)   dgrad: (H*W, W)
+};
+
+// y[m][co] = bias[co] + sum_{t,ci} x[src(m,t)][ci] * w_t[t][ci][co]; threads: x = co, y = pixel.
+template <typename T> __global__ void direct_fwd_kernel(const DirectParams p) {
+    int co = blockIdx.y * 64 + threadIdx.x;
+    int m = blockIdx.x * blockDim.y + threadIdx.y;
+    if (m >= p.M || co >= p.Cout) return;
+    uint32_t img = fd_div(m, p.fd_a), rem = m - img * p.fd_a.d;
+    uint32_t ho = fd_div(rem, p.fd_b), wo = rem - ho * p.fd_b.d;
+    const T* x = (const T*)p.a;
+    const float* w = (const float*)p.b;
+    float acc = p.bias ? p.bias[co] : 0.f;
+    for (int r = 0; r < p.KH; ++r) {
+        int ih = (int)ho * p.sh - p.ph + r;
+        if ((unsigned)ih >= (unsigned)p.H) continue;
+        for (int q = 0; q < p.KW; ++q) {
+            int iw = (int)wo * p.sw - p.pw + q;
+            if ((unsigned)iw >= (unsigned)p.W) continue;
+            const T* xp = x + ((size_t)(img * p.H + ih) * p.W + iw) * p.Cin;
+            const float* wp = w + (size_t)(r * p.KW + q) * p.Cin * p.Cout + co;
+            for (int ci = 0; ci < p.Cin; ++ci) acc += to_f32(xp[ci]) * wp[(size_t)ci * p.Cout];
+        }
+    }
+    ((T*)p.out)[(size_t)m * p.Cout + co] = from_f32<T>(acc);
+}
+
+// dx[pix][ci] = sum over taps with (h+p-kh)%s==0 of dy[src][co] * w_t[t][ci][co]; threads: x = ci.
+template <typename T> __global__ void direct_dgrad_kernel(const DirectParams p) {
+    int ci = blockIdx.y * 64 + threadIdx.x;
+    int m = blockIdx.x * blockDim.y + threadIdx.y;
+    if (m >= p.M || ci >= p.Cin) return;
+    uint32_t img = fd_div(m, p.fd_a), rem = m - img * p.fd_a.d;
+    uint32_t h = fd_div(rem, p.fd_b), w0 = rem - h * p.fd_b.d;
+    const T* dy = (const T*)p.a;
+    const float* w = (const float*)p.b;
+    float acc = 0.f;
+    for (int r = 0; r < p.KH; ++r) {
+        int th = (int)h + p.ph - r;
+        if (th < 0 || th % p.sh) continue;
+        int ho = th / p.sh;
+        if (ho >= p.Ho) continue;
+        for (int q = 0; q < p.KW; ++q) {
+            int tw = (int)w0 + p.pw - q;
+            if (tw < 0 || tw % p.sw) continue;
+            int wo = tw / p.sw;
+            if (wo >= p.Wo) continue;
+            const T* dp = dy + ((size_t)(img * p.Ho + ho) * p.Wo + wo) * p.Cout;
+            const float* wp = w + ((size_t)(r * p.KW + q) * p.Cin + ci) * p.Cout;
+            for (int co = 0; co < p.Cout; ++co) acc += to_f32(dp[co]) * wp[co];
+        }
+    }
+    ((T*)p.out)[(size_t)m * p.Cin + ci] = from_f32<T>(acc);
+}
+
+// slab[slice][t][ci][co] = sum over the slice's pixels of dy[m][co] * x[src(m,t)][ci]
+template <typename T> __global__ void direct_wgrad_kernel(const DirectParams p) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = p.KH * p.KW * p.Cin * p.Cout;
+    if (idx >= total) return;
+    int co = idx % p.Cout, r1 = idx / p.Cout;
+    int ci = r1 % p.Cin, t = r1 / p.Cin;
+    int r = t / p.KW, q = t - r * p.KW;
+    const T* dy = (const T*)p.a;
+    const T* x = (const T*)p.b;
+    int m0 = blockIdx.y * p.chunk, m1 = min(p.M, m0 + p.chunk);
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) {
+        uint32_t img = fd_div(m, p.fd_a), rem = m - img * p.fd_a.d;
+        uint32_t ho = fd_div(rem, p.fd_b), wo = rem - ho * p.fd_b.d;
+        int ih = (int)ho * p.sh - p.ph + r, iw = (int)wo * p.sw - p.pw + q;
+        if ((unsigned)ih >= (unsigned)p.H || (unsigned)iw >= (unsigned)p.W) continue;
+        acc += to_f32(dy[(size_t)m * p.Cout + co]) *
+               to_f32(x[((size_t)(img * p.H + ih) * p.W + iw) * p.Cin + ci]);
+    }
+    ((float*)p.out)[(size_t)blockIdx.y * total + idx] = acc;
+}
+
+// partial[slice][c] = sum over the slice's rows of a[m][c]
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ a, float* __restrict__ partial, int M,
+                                      int C, int chunk) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int m0 = blockIdx.y * chunk, m1 = min(M, m0 + chunk);
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) acc += to_f32(a[(size_t)m * C + c]);
+    partial[(size_t)blockIdx.y * C + c] = acc;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                    int slices, int C, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int s = 0; s < slices; ++s) acc += partial[(size_t)s * C + c];
+    out[c] = accumulate ? out[c] + acc : acc;
+}
+
+// ---- weight re-layout -----------------------------------------------------------------------------
+// out[(r*ntaps + t)*Cred + c] = w[co][ci][kh[t]][kw[t]] with (r,c) = (co,ci) [fwd] or (ci,co) [dgrad]
+struct PackParams {
+    const float* w;
+    void* out;
+    int Cout, Cin, KH, KW, ntaps, transpose;
+    signed char kh[32], kw[32];
+};
+template <typename T> __global__ void pack_kernel(const PackParams p) {
+    int R = p.transpose ? p.Cin : p.Cout, Cred = p.transpose ? p.Cout : p.Cin;
+    size_t total = (size_t)R * p.ntaps * Cred;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cred);
+        size_t q = i / Cred;
+        int t = (int)(q % p.ntaps), r = (int)(q / p.ntaps);
+        int co = p.transpose ? c : r, ci = p.transpose ? r : c;
+        float v = p.w[(((size_t)co * p.Cin + ci) * p.KH + p.kh[t]) * p.KW + p.kw[t]];
+        ((T*)p.out)[i] = from_f32<T>(v);
+    }
+}
+// w_t[t][ci][co] = w[co][ci][t]
+__global__ void pack_direct_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout,
+                                   int Cin, int T_) {
+    size_t total = (size_t)Cout * Cin * T_;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int co = (int)(i % Cout);
+        size_t q = i / Cout;
+        int ci = (int)(q % Cin), t = (int)(q / Cin);
+        out[i] = w[((size_t)co * Cin + ci) * T_ + t];
+    }
+}
+
+DirectParams make_params(const cnk_conv_desc* d) {
+    DirectParams p = {};
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
+    p.KH = d->kh; p.KW = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+    return p;
+}
+
+}  // namespace
+
+int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_stride, int Cout,
+                        int Cin, int ntaps, size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci,
+                        int accumulate, hipStream_t s);
+
+int direct_fwd(const cnk_conv_desc* d, const void* x, const void* w_t, const float* bias, void* y,
+               hipStream_t s) {
+    DirectParams p = make_params(d);
+    p.a = x; p.b = w_t; p.out = y; p.bias = bias;
+    p.M = d->N * p.Ho * p.Wo;
+    p.fd_a = make_fastdiv(p.Ho * p.Wo); p.fd_b = make_fastdiv(p.Wo);
+    dim3 block(64, 4), grid(ceil_div(p.M, 4), ceil_div(d->Cout, 64));
+    if (d->dtype == CNK_BF16) hipLaunchKernelGGL(direct_fwd_kernel<bf16>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(direct_fwd_kernel<float>, grid, block, 0, s, p);
+    CNK_CHECK_LAUNCH("direct_fwd");
+    return 0;
+}
+
+int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s) {
+    DirectParams p = make_params(d);
+    p.a = dy; p.b = w_t; p.out = dx;
+    p.M = d->N * d->H * d->W;
+    p.fd_a = make_fastdiv(d->H * d->W); p.fd_b = make_fastdiv(d->W);
+    dim3 block(64, 4), grid(ceil_div(p.M, 4), ceil_div(d->Cin, 64));
+    if (d->dtype == CNK_BF16) hipLaunchKernelGGL(direct_dgrad_kernel<bf16>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(direct_dgrad_kernel<float>, grid, block, 0, s, p);
+    CNK_CHECK_LAUNCH("direct_dgrad");
+    return 0;
+}
+
+static int direct_wgrad_slices(const cnk_conv_desc* d, int* chunk) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    int M = d->N * Ho * Wo;
+    int total = d->kh * d->kw * d->Cin * d->Cout;
+    int blocks = ceil_div(total, 256);
+    int want = ceil_div(2048, blocks);
+    int c = ceil_div(M, want);
+    if (c < 64) c = 64;
+    *chunk = c;
+    return ceil_div(M, c);
+}
+size_t direct_wgrad_workspace(const cnk_conv_desc* d) {
+    int chunk;
+    int slices = direct_wgrad_slices(d, &chunk);
+    return (size_t)slices * d->kh * d->kw * d->Cin * d->Cout * sizeof(float);
+}
+int direct_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate,
+                 void* ws, size_t ws_bytes, hipStream_t s) {
+    DirectParams p = make_params(d);
+    int slices = direct_wgrad_slices(d, &p.chunk);
+    int total = d->kh * d->kw * d->Cin * d->Cout;
+    size_t need = (size_t)slices * total * sizeof(float);
+    CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad(direct): workspace too small (%zu < %zu)", ws_bytes, need);
+    p.a = dy; p.b = x; p.out = ws;
+    p.M = d->N * p.Ho * p.Wo;
+    p.fd_a = make_fastdiv(p.Ho * p.Wo); p.fd_b = make_fastdiv(p.Wo);
+    dim3 block(256), grid(ceil_div(total, 256), slices);
+    if (d->dtype == CNK_BF16) hipLaunchKernelGGL(direct_wgrad_kernel<bf16>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(direct_wgrad_kernel<float>, grid, block, 0, s, p);
+    CNK_CHECK_LAUNCH("direct_wgrad");
+    int T_ = d->kh * d->kw;
+    // slab order [t][ci][co]
+    return launch_wgrad_reduce((const float*)ws, dw, slices, (size_t)total, d->Cout, d->Cin, T_,
+                               (size_t)1, (size_t)d->Cin * d->Cout, (size_t)d->Cout, 0, accumulate, s);
+}
+
+// dbias[c] (+)= sum_m dy[m][c]; workspace: colsum_workspace(M, C)
+static int colsum_slices(int64_t M, int* chunk) {
+    int64_t c = ceil_div64(M, 512);
+    if (c < 64) c = 64;
+    *chunk = (int)c;
+    return (int)ceil_div64(M, c);
+}
+size_t colsum_workspace(int64_t M, int C) {
+    int chunk;
+    return (size_t)colsum_slices(M, &chunk) * C * sizeof(float);
+}
+int colsum(const void* a, float* out, int64_t M, int C, int dtype, int accumulate, void* ws,
+           size_t ws_bytes, hipStream_t s) {
+    int chunk;
+    int slices = colsum_slices(M, &chunk);
+    CNK_CHECK_ARG(ws && ws_bytes >= (size_t)slices * C * sizeof(float), "colsum: workspace too small");
+    dim3 block(64), grid(ceil_div(C, 64), slices);
+    if (dtype == CNK_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16>, grid, block, 0, s, (const bf16*)a, (float*)ws, (int)M, C, chunk);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, s, (const float*)a, (float*)ws, (int)M, C, chunk);
+    CNK_CHECK_LAUNCH("colsum_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, (const float*)ws, out, slices, C, accumulate);
+    CNK_CHECK_LAUNCH("colsum_final");
+    return 0;
+}
+
+int pack_direct(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s) {
+    size_t total = (size_t)d->Cout * d->Cin * d->kh * d->kw;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pack_direct_kernel, dim3(grid), dim3(256), 0, s, w, (float*)out, d->Cout, d->Cin, d->kh * d->kw);
+    CNK_CHECK_LAUNCH("pack_direct");
+    return 0;
+}
+
+// taps: ntaps pairs (kh,kw); transpose=0 -> [Cout][t][Cin], 1 -> [Cin][t][Cout]
+int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, const signed char* kh,
+              const signed char* kw, int transpose, hipStream_t s) {
+    if (ntaps == 0) return 0;
+    PackParams p = {};
+    p.w = w; p.out = out; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->kh; p.KW = d->kw;
+    p.ntaps = ntaps; p.transpose = transpose;
+    for (int t = 0; t < ntaps; ++t) { p.kh[t] = kh[t]; p.kw[t] = kw[t]; }
+    size_t total = (size_t)d->Cout * d->Cin * ntaps;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (d->dtype == CNK_BF16) hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    CNK_CHECK_LAUNCH("pack_taps");
+    return 0;
+}

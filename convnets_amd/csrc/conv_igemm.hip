@@ -1,0 +1,322 @@
+// Implicit-GEMM "gather" convolution on MFMA for gfx950: forward and data-gradient.
+//
+//   C[m][n] = sum_{t,c} A[m][(t,c)] * B[n][(t,c)]
+//     m -> (img, oh, ow) over an output grid; A row m, tap t = src[img][oh*sm+dh[t]][ow*sm+dw[t]][c]
+//     (zero outside the source), B = packed weights [n][t][c] (K contiguous for both operands).
+//   forward : src = x,  sm = stride, dst = y (every pixel),            B = w_fwd [Cout][kh][kw][Cin]
+//   dgrad   : src = dy, sm = 1,      dst = dx pixels of one stride-parity class (oh*s+ph, ow*s+pw),
+//             B = w_dgrad[class] [Cin][taps(class)][Cout]; classes without taps just store zeros.
+//
+// Tile: 128 (m) x BN (n) x 128 bytes of K per step (64 bf16 / 32 fp32 channels of one tap),
+// 256 threads = 4 waves (2 x 2), wave tile 64 x BN/2 from 32x32 MFMA blocks
+// (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for exact fp32).  Global -> registers ->
+// LDS staging, double-buffered LDS, one barrier per K step; LDS rows are 128 B with the 16-byte
+// chunk index XORed by (row>>1)&7 so every ds_read_b128 lane group hits 16 distinct bank slots.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int MAX_TAPS = 32;
+
+struct GatherParams {
+    const void* src;
+    const void* wpk;
+    void* dst;
+    const float* bias;
+    int N, IH, IW, C;
+    int OH, OW;
+    int FH, FW, Nout;
+    int sm_h, sm_w;
+    int dm_h, dm_w, d_h0, d_w0;
+    int ntaps;
+    int M;
+    int tiles_n;
+    int tiles_total;
+    FastDiv fd_ohw, fd_ow;
+    signed char dh[MAX_TAPS], dw[MAX_TAPS];
+};
+
+template <typename T> struct Mma32;
+template <> struct Mma32<bf16> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma32<float> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+        f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
+    constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
+    constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
+    constexpr int NJ = BN / 64;                      // 32-wide MFMA blocks per wave along n
+    constexpr int B_LOADS = BN / 32;                 // 16-B chunks per thread for the B tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                        // [2][128][128 B]
+    unsigned char* Bs = smem + 2 * BM * 128;         // [2][BN][128 B]
+    int* row_dst = (int*)(smem + 2 * BM * 128 + 2 * BN * 128);   // dst pixel per tile row (-1: none)
+
+    // XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
+    // run of tiles so neighbours (same A rows, other n tile; adjacent pixels) share L2 lines.
+    int bid = blockIdx.x;
+    {
+        int nwg = p.tiles_total, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int chunk = tid & 7, lrow = tid >> 3;      // loader role: 8 threads cover one 128-B row
+
+    // per-thread A rows: lrow + 32*i
+    int a_base[4], a_ih[4], a_iw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = tile_m * BM + lrow + 32 * i;
+        if (m < p.M) {
+            uint32_t img = fd_div(m, p.fd_ohw);
+            uint32_t rem = m - img * p.fd_ohw.d;
+            uint32_t oh = fd_div(rem, p.fd_ow);
+            uint32_t ow = rem - oh * p.fd_ow.d;
+            a_base[i] = img * p.IH;
+            a_ih[i] = oh * p.sm_h;
+            a_iw[i] = ow * p.sm_w;
+        } else {
+            a_base[i] = 0;
+            a_ih[i] = -100000;       // never in range
+            a_iw[i] = 0;
+        }
+    }
+    if (tid < BM) {
+        int m = tile_m * BM + tid, v = -1;
+        if (m < p.M) {
+            uint32_t img = fd_div(m, p.fd_ohw);
+            uint32_t rem = m - img * p.fd_ohw.d;
+            uint32_t oh = fd_div(rem, p.fd_ow);
+            uint32_t ow = rem - oh * p.fd_ow.d;
+            v = (img * p.FH + oh * p.dm_h + p.d_h0) * p.FW + ow * p.dm_w + p.d_w0;
+        }
+        row_dst[tid] = v;
+    }
+
+    const T* src = (const T*)p.src;
+    const T* wpk = (const T*)p.wpk;
+    const int csteps = p.C / KSTEP;
+    const int nk = p.ntaps * csteps;
+    const size_t wrow = (size_t)p.ntaps * p.C;
+
+    u32x4 ra[4], rb[B_LOADS];
+    int ld_t = 0, ld_cs = 0;                         // (tap, channel step) of the next load_step
+    auto load_step = [&]() {
+        const int t = ld_t, c0 = ld_cs * KSTEP + chunk * PER16;
+        if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
+        int dh = p.dh[t], dw = p.dw[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+            bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            u32x4 v = {0, 0, 0, 0};
+            if (ok) {
+                size_t off = ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + c0;
+                v = *(const u32x4*)(src + off);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int n = tile_n * BN + lrow + 32 * i;
+            size_t off = (size_t)n * wrow + (size_t)t * p.C + c0;
+            rb[i] = *(const u32x4*)(wpk + off);
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = lrow + 32 * i;
+            *(u32x4*)(As + buf * (BM * 128) + r * 128 + swz(r, chunk)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int r = lrow + 32 * i;
+            *(u32x4*)(Bs + buf * (BN * 128) + r * 128 + swz(r, chunk)) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (nk > 0) {
+        load_step();
+        store_step(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_step();
+        const unsigned char* Ab = As + buf * (BM * 128);
+        const unsigned char* Bb = Bs + buf * (BN * 128);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 fa[2], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r = wm * 64 + i * 32 + l31;
+                fa[i] = *(const u32x4*)(Ab + r * 128 + swz(r, 2 * s + lh));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int r = wn * (BN / 2) + j * 32 + l31;
+                fb[j] = *(const u32x4*)(Bb + r * 128 + swz(r, 2 * s + lh));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) Mma32<T>::run(acc[i][j], fa[i], fb[j]);
+        }
+        if (ks + 1 < nk) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: acc block (i,j), reg r -> row (r&3) + 8*(r>>2) + 4*lh, col l31
+    T* dst = (T*)p.dst;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int col = tile_n * BN + wn * (BN / 2) + j * 32 + l31;
+        float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int pix = row_dst[row];
+                if (pix >= 0) dst[(size_t)pix * p.Nout + col] = from_f32<T>(acc[i][j][r] + bv);
+            }
+    }
+}
+
+template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
+    size_t lds = 2 * BM * 128 + 2 * BN * 128 + BM * sizeof(int);
+    hipLaunchKernelGGL((igemm_gather_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    CNK_CHECK_LAUNCH("igemm_gather");
+    return 0;
+}
+
+template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
+    // BN = 128 when it divides Nout and the grid still fills the chip, else 64
+    int tiles_m = ceil_div(p.M, BM);
+    bool use128 = (p.Nout % 128 == 0) && ((int64_t)tiles_m * (p.Nout / 128) >= 512);
+    int bn = use128 ? 128 : 64;
+    p.tiles_n = p.Nout / bn;
+    p.tiles_total = tiles_m * p.tiles_n;
+    if (p.tiles_total == 0) return 0;
+    return use128 ? launch_gather<T, 128>(p, s) : launch_gather<T, 64>(p, s);
+}
+
+}  // namespace
+
+// ---- host entry points used by api.hip --------------------------------------------------------
+bool igemm_supported(const cnk_conv_desc* d, int pass) {
+    int kstep = d->dtype == CNK_BF16 ? 64 : 32;
+    int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout;
+    int nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
+    if (cred % kstep || nout % 64) return false;
+    if (d->kh * d->kw > MAX_TAPS) return false;
+    return true;
+}
+
+int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
+              hipStream_t s) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    GatherParams p = {};
+    p.src = x; p.wpk = w_fwd; p.dst = y; p.bias = bias;
+    p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cin;
+    p.OH = Ho; p.OW = Wo; p.FH = Ho; p.FW = Wo; p.Nout = d->Cout;
+    p.sm_h = d->stride_h; p.sm_w = d->stride_w;
+    p.dm_h = 1; p.dm_w = 1; p.d_h0 = 0; p.d_w0 = 0;
+    p.ntaps = d->kh * d->kw;
+    for (int r = 0; r < d->kh; ++r)
+        for (int c = 0; c < d->kw; ++c) {
+            p.dh[r * d->kw + c] = (signed char)(r - d->pad_h);
+            p.dw[r * d->kw + c] = (signed char)(c - d->pad_w);
+        }
+    p.M = d->N * Ho * Wo;
+    p.fd_ohw = make_fastdiv(Ho * Wo);
+    p.fd_ow = make_fastdiv(Wo);
+    return d->dtype == CNK_BF16 ? launch_gather_bn<bf16>(p, s) : launch_gather_bn<float>(p, s);
+}
+
+// Enumerates the stride-parity classes of the data gradient in the order the packed dgrad
+// weights use.  Returns the number of classes; taps[c] lists (kh,kw) pairs of class c.
+int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w] */) {
+    int n = 0;
+    for (int ph = 0; ph < d->stride_h; ++ph)
+        for (int pw = 0; pw < d->stride_w; ++pw) {
+            DgradClass& c = out[n++];
+            c.ph = ph; c.pw = pw;
+            c.OH = ph < d->H ? (d->H - ph + d->stride_h - 1) / d->stride_h : 0;
+            c.OW = pw < d->W ? (d->W - pw + d->stride_w - 1) / d->stride_w : 0;
+            c.ntaps = 0;
+            for (int r = 0; r < d->kh; ++r) {
+                int th = ph + d->pad_h - r;
+                if (th % d->stride_h) continue;
+                for (int q = 0; q < d->kw; ++q) {
+                    int tw = pw + d->pad_w - q;
+                    if (tw % d->stride_w) continue;
+                    if (c.ntaps < MAX_TAPS) {
+                        c.kh[c.ntaps] = (signed char)r; c.kw[c.ntaps] = (signed char)q;
+                        c.dh[c.ntaps] = (signed char)(th / d->stride_h);
+                        c.dw[c.ntaps] = (signed char)(tw / d->stride_w);
+                    }
+                    c.ntaps++;
+                }
+            }
+        }
+    return n;
+}
+
+int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                hipStream_t s) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    DgradClass cls[16];
+    CNK_CHECK_ARG(d->stride_h * d->stride_w <= 16, "igemm_dgrad: stride too large");
+    int nc = dgrad_classes(d, cls);
+    size_t esz = d->dtype == CNK_BF16 ? 2 : 4;
+    size_t woff = 0;
+    for (int c = 0; c < nc; ++c) {
+        const DgradClass& k = cls[c];
+        GatherParams p = {};
+        p.src = dy; p.wpk = (const char*)w_dgrad + woff * esz; p.dst = dx; p.bias = nullptr;
+        p.N = d->N; p.IH = Ho; p.IW = Wo; p.C = d->Cout;
+        p.OH = k.OH; p.OW = k.OW; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
+        p.sm_h = 1; p.sm_w = 1;
+        p.dm_h = d->stride_h; p.dm_w = d->stride_w; p.d_h0 = k.ph; p.d_w0 = k.pw;
+        p.ntaps = k.ntaps;
+        for (int t = 0; t < k.ntaps; ++t) { p.dh[t] = k.dh[t]; p.dw[t] = k.dw[t]; }
+        p.M = d->N * k.OH * k.OW;
+        woff += (size_t)k.ntaps * d->Cin * d->Cout;
+        if (p.M == 0) continue;
+        p.fd_ohw = make_fastdiv(k.OH * k.OW);
+        p.fd_ow = make_fastdiv(k.OW);
+        int rc = d->dtype == CNK_BF16 ? launch_gather_bn<bf16>(p, s) : launch_gather_bn<float>(p, s);
+        if (rc) return rc;
+    }
+    return 0;
+}

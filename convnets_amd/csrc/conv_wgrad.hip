@@ -1,0 +1,310 @@
+// Weight-gradient convolution on MFMA for gfx950.
+//
+//   dw[co][t][ci] = sum_m dy[m][co] * xg[m,t][ci],   m = (img, ho, wo),  xg = x at (ho*s+kh-p, wo*s+kw-p)
+//
+// GEMM view: rows = co, cols = ci (one tap per workgroup), reduction over pixels m.  Both operands
+// are stored pixel-major in HBM (NHWC), i.e. with the REDUCTION index strided, so the LDS images
+// are [pixel][channel] and the MFMA fragments are fetched with the gfx950 transposing LDS read
+// (ds_read_b64_tr_b16) for bf16; for fp32 the 32x32x2 MFMA takes one value per lane, which the
+// [pixel][channel] image serves with conflict-free ds_read_b32.  The pixel range is split over
+// workgroups (split-K); each writes an fp32 partial slab [split][co][t][ci] with plain stores and a
+// second kernel sums the slabs in fixed order (deterministic, unlike float atomics), applies the
+// .grad accumulation and re-lays into the master layout [Cout][Cin][kh][kw].
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+    const void* dy;
+    const void* x;
+    float* slab;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw;
+    int M;
+    int ksteps, ksteps_per_split, splits;
+    int tiles_co, tiles_ci, ntaps;
+    FastDiv fd_howo, fd_wo;
+};
+
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16> {
+    static constexpr int KP = 64;      // pixels per K step
+    static constexpr int PAD = 64;     // row padding (bytes): stride == 64 mod 256 -> tr reads conflict-free
+};
+template <> struct WgCfg<float> {
+    static constexpr int KP = 32;
+    static constexpr int PAD = 0;
+};
+
+template <typename T, int BMW, int BNW>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
+    constexpr int PER16 = ElemTraits<T>::PER16;
+    constexpr int KP = WgCfg<T>::KP;
+    constexpr int ROWA = BMW * (int)sizeof(T) + WgCfg<T>::PAD;
+    constexpr int ROWB = BNW * (int)sizeof(T) + WgCfg<T>::PAD;
+    constexpr int CPRA = BMW / PER16, CPRB = BNW / PER16;       // 16-B chunks per row
+    constexpr int PASSA = KP * CPRA / 256, PASSB = KP * CPRB / 256;
+    constexpr int TM = BMW / 64, TN = BNW / 64;                // 32x32 blocks per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                      // [2][KP][ROWA]
+    unsigned char* Bs = smem + 2 * KP * ROWA;      // [2][KP][ROWB]
+
+    int bid = blockIdx.x;
+    const int tiles_nc = p.ntaps * p.tiles_ci;
+    const int per_split = p.tiles_co * tiles_nc;
+    const int split = bid / per_split;
+    bid -= split * per_split;
+    const int tile_co = bid / tiles_nc;
+    const int rest = bid - tile_co * tiles_nc;
+    const int tap = rest / p.tiles_ci, tile_ci = rest - tap * p.tiles_ci;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const T* dy = (const T*)p.dy;
+    const T* x = (const T*)p.x;
+    const int ks0 = split * p.ksteps_per_split;
+    const int ks1 = min(p.ksteps, ks0 + p.ksteps_per_split);
+
+    u32x4 ra[PASSA], rb[PASSB];
+    auto load_step = [&](int ks) {
+        const int m0 = ks * KP;
+#pragma unroll
+        for (int i = 0; i < PASSA; ++i) {
+            int idx = tid + 256 * i, r = idx / CPRA, c = idx - r * CPRA;
+            int m = m0 + r;
+            u32x4 v = {0, 0, 0, 0};
+            if (m < p.M) v = *(const u32x4*)(dy + (size_t)m * p.Cout + tile_co * BMW + c * PER16);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PASSB; ++i) {
+            int idx = tid + 256 * i, r = idx / CPRB, c = idx - r * CPRB;
+            int m = m0 + r;
+            u32x4 v = {0, 0, 0, 0};
+            if (m < p.M) {
+                uint32_t img = fd_div(m, p.fd_howo);
+                uint32_t rem = m - img * p.fd_howo.d;
+                uint32_t ho = fd_div(rem, p.fd_wo);
+                uint32_t wo = rem - ho * p.fd_wo.d;
+                int ih = (int)ho * p.sh - p.ph + kh, iw = (int)wo * p.sw - p.pw + kw;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                    v = *(const u32x4*)(x + ((size_t)(img * p.H + ih) * p.W + iw) * p.Cin +
+                                        tile_ci * BNW + c * PER16);
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PASSA; ++i) {
+            int idx = tid + 256 * i, r = idx / CPRA, c = idx - r * CPRA;
+            *(u32x4*)(As + buf * (KP * ROWA) + r * ROWA + c * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PASSB; ++i) {
+            int idx = tid + 256 * i, r = idx / CPRB, c = idx - r * CPRB;
+            *(u32x4*)(Bs + buf * (KP * ROWB) + r * ROWB + c * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ks0 < ks1) {
+        load_step(ks0);
+        store_step(0);
+    }
+    __syncthreads();
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int buf = (ks - ks0) & 1;
+        if (ks + 1 < ks1) load_step(ks + 1);
+        const unsigned char* Ab = As + buf * (KP * ROWA);
+        const unsigned char* Bb = Bs + buf * (KP * ROWB);
+        if constexpr (sizeof(T) == 2) {
+            // lane l: group g = l>>4 (h = g>>1 selects pixels 8h..8h+7, g&1 the 16-channel half),
+            // q = (l&15)>>2 the pixel row of the 4x16 block whose address this lane supplies,
+            // pp = l&3 the 4-channel column group.  Two reads give k = 8h + {0..3}, {4..7}.
+            const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
+#pragma unroll
+            for (int ss = 0; ss < KP / 16; ++ss) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    int col = wm * (BMW / 2) + i * 32 + 16 * (g & 1) + 4 * pp;
+                    const unsigned char* a0 = Ab + (ss * 16 + 8 * h + q) * ROWA + col * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * ROWA));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    s16x8 w8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fa[i] = __builtin_bit_cast(bf16x8, w8);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int col = wn * (BNW / 2) + j * 32 + 16 * (g & 1) + 4 * pp;
+                    const unsigned char* b0 = Bb + (ss * 16 + 8 * h + q) * ROWB + col * 2;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(b0));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(b0 + 4 * ROWB));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    s16x8 w8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fb[j] = __builtin_bit_cast(bf16x8, w8);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j],
+                                                                            0, 0, 0);
+            }
+        } else {
+            const int l31 = lane & 31, lk = lane >> 5;
+#pragma unroll 4
+            for (int ss = 0; ss < KP / 2; ++ss) {
+                float fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *(const float*)(Ab + (ss * 2 + lk) * ROWA +
+                                            (wm * (BMW / 2) + i * 32 + l31) * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *(const float*)(Bb + (ss * 2 + lk) * ROWB +
+                                            (wn * (BNW / 2) + j * 32 + l31) * 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0,
+                                                                         0, 0);
+            }
+        }
+        if (ks + 1 < ks1) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* slab = p.slab + (size_t)split * p.Cout * p.ntaps * p.Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = tile_co * BMW + wm * (BMW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int ci = tile_ci * BNW + wn * (BNW / 2) + j * 32 + l31;
+                slab[((size_t)co * p.ntaps + tap) * p.Cin + ci] = acc[i][j][r];
+            }
+}
+
+// dw[co][ci][t] (+)= sum_s slab[s*slab_stride + co*s_co + t*s_t + ci*s_ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                    int splits, size_t slab_stride, int Cout, int Cin, int ntaps,
+                                    size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci,
+                                    int accumulate) {
+    size_t total = (size_t)Cout * Cin * ntaps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int co, t, ci;
+        if (inner_is_ci) {            // slab order [co][t][ci]
+            ci = (int)(i % Cin);
+            size_t r = i / Cin;
+            t = (int)(r % ntaps);
+            co = (int)(r / ntaps);
+        } else {                      // slab order [t][ci][co]
+            co = (int)(i % Cout);
+            size_t r = i / Cout;
+            ci = (int)(r % Cin);
+            t = (int)(r / Cin);
+        }
+        const float* sp = slab + co * s_co + t * s_t + ci * s_ci;
+        float acc = 0.f;
+        for (int s = 0; s < splits; ++s) acc += sp[(size_t)s * slab_stride];
+        size_t o = ((size_t)co * Cin + ci) * ntaps + t;
+        dw[o] = accumulate ? dw[o] + acc : acc;
+    }
+}
+
+template <typename T, int BMW, int BNW> int launch_wgrad(const WgradParams& p, hipStream_t s) {
+    constexpr int KP = WgCfg<T>::KP;
+    size_t lds = 2 * KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + 2 * KP * (BNW * sizeof(T) + WgCfg<T>::PAD);
+    int grid = p.splits * p.tiles_co * p.ntaps * p.tiles_ci;
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW>), dim3(grid), dim3(256), lds, s, p);
+    CNK_CHECK_LAUNCH("wgrad_mfma");
+    return 0;
+}
+
+}  // namespace
+
+int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_stride, int Cout,
+                        int Cin, int ntaps, size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci,
+                        int accumulate, hipStream_t s) {
+    size_t total = (size_t)Cout * Cin * ntaps;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, dw, splits,
+                       slab_stride, Cout, Cin, ntaps, s_co, s_t, s_ci, inner_is_ci, accumulate);
+    CNK_CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}
+
+bool wgrad_mfma_supported(const cnk_conv_desc* d) { return d->Cin % 64 == 0 && d->Cout % 64 == 0; }
+
+// Tile shape and split count shared by the workspace query and the launch.
+static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, int* ksteps,
+                       int* per_split) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    int M = d->N * Ho * Wo;
+    int kp = d->dtype == CNK_BF16 ? 64 : 32;
+    *bmw = d->Cout % 128 == 0 ? 128 : 64;
+    *bnw = d->Cin % 128 == 0 ? 128 : 64;
+    int tiles = (d->Cout / *bmw) * (d->Cin / *bnw) * d->kh * d->kw;
+    *ksteps = ceil_div(M, kp);
+    int want = ceil_div(1024, tiles);
+    int max_by_k = *ksteps / 4 > 0 ? *ksteps / 4 : 1;       // at least 4 K steps per split
+    int sp = want < max_by_k ? want : max_by_k;
+    if (sp < 1) sp = 1;
+    *per_split = ceil_div(*ksteps, sp);
+    *splits = ceil_div(*ksteps, *per_split);
+}
+
+size_t wgrad_mfma_workspace(const cnk_conv_desc* d) {
+    int bmw, bnw, splits, ksteps, per;
+    wgrad_plan(d, &bmw, &bnw, &splits, &ksteps, &per);
+    return (size_t)splits * d->Cout * d->Cin * d->kh * d->kw * sizeof(float);
+}
+
+int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate,
+               void* ws, size_t ws_bytes, hipStream_t s) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    WgradParams p = {};
+    int bmw, bnw;
+    wgrad_plan(d, &bmw, &bnw, &p.splits, &p.ksteps, &p.ksteps_per_split);
+    size_t need = (size_t)p.splits * d->Cout * d->Cin * d->kh * d->kw * sizeof(float);
+    CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    p.dy = dy; p.x = x; p.slab = (float*)ws;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
+    p.KH = d->kh; p.KW = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+    p.M = d->N * Ho * Wo;
+    p.tiles_co = d->Cout / bmw; p.tiles_ci = d->Cin / bnw; p.ntaps = d->kh * d->kw;
+    p.fd_howo = make_fastdiv(Ho * Wo);
+    p.fd_wo = make_fastdiv(Wo);
+    int rc;
+    bool b = d->dtype == CNK_BF16;
+    if (bmw == 128 && bnw == 128) rc = b ? launch_wgrad<bf16, 128, 128>(p, s) : launch_wgrad<float, 128, 128>(p, s);
+    else if (bmw == 128) rc = b ? launch_wgrad<bf16, 128, 64>(p, s) : launch_wgrad<float, 128, 64>(p, s);
+    else if (bnw == 128) rc = b ? launch_wgrad<bf16, 64, 128>(p, s) : launch_wgrad<float, 64, 128>(p, s);
+    else rc = b ? launch_wgrad<bf16, 64, 64>(p, s) : launch_wgrad<float, 64, 64>(p, s);
+    if (rc) return rc;
+    size_t per = (size_t)d->Cout * p.ntaps * d->Cin;
+    return launch_wgrad_reduce(p.slab, dw, p.splits, per, d->Cout, d->Cin, p.ntaps,
+                               (size_t)p.ntaps * d->Cin, (size_t)d->Cin, 1, 1, accumulate, s);
+}

@@ -1,0 +1,324 @@
+// Streaming (HBM-bound) kernels of the path: max-pool, ReLU, add+ReLU, global average pool,
+// NCHW->NHWC hand-off at the model boundary, flat-arena Adam.  16-byte vector access along C.
+#include "common.h"
+
+namespace {
+
+template <typename T, int VEC> struct VL {
+    float f[VEC];
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (VEC == 1) {
+            f[0] = to_f32(p[0]);
+        } else {
+            Vec16<T> v;
+            v.v = *(const decltype(v.v)*)p;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = v.get(i);
+        }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if constexpr (VEC == 1) {
+            p[0] = from_f32<T>(f[0]);
+        } else {
+            Vec16<T> v;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v.set(i, f[i]);
+            *(decltype(v.v)*)p = v.v;
+        }
+    }
+};
+
+struct PoolParams {
+    int N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw;
+    FastDiv fd_cols, fd_wo, fd_ho, fd_w, fd_h;
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          PoolParams p, int64_t total) {
+    const int cols = p.C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t pix = fd_div((uint32_t)i, p.fd_cols), vc = (uint32_t)i - pix * cols;
+        uint32_t t = fd_div(pix, p.fd_wo), wo = pix - t * p.Wo;
+        uint32_t n = fd_div(t, p.fd_ho), ho = t - n * p.Ho;
+        float best[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) best[k] = -INFINITY;
+        for (int r = 0; r < p.kh; ++r) {
+            int h = (int)ho * p.sh - p.ph + r;
+            if ((unsigned)h >= (unsigned)p.H) continue;
+            for (int q = 0; q < p.kw; ++q) {
+                int w = (int)wo * p.sw - p.pw + q;
+                if ((unsigned)w >= (unsigned)p.W) continue;
+                VL<T, VEC> v;
+                v.load(x + ((size_t)(n * p.H + h) * p.W + w) * p.C + vc * VEC);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    if (v.f[k] > best[k] || v.f[k] != v.f[k]) best[k] = v.f[k];
+            }
+        }
+        VL<T, VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.f[k] = best[k];
+        o.store(y + (size_t)i * VEC);
+    }
+}
+
+// Gather form of the backward: every input element sums dy over the windows whose arg-max
+// (first maximum in row-major window order, torch's rule) it is.  No atomics, deterministic.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy,
+                                                          const T* __restrict__ x, T* __restrict__ dx,
+                                                          PoolParams p, int64_t total) {
+    const int cols = p.C / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t pix = fd_div((uint32_t)i, p.fd_cols), vc = (uint32_t)i - pix * cols;
+        uint32_t t = fd_div(pix, p.fd_w), w = pix - t * p.W;
+        uint32_t n = fd_div(t, p.fd_h), h = t - n * p.H;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        int ho_lo = ((int)h + p.ph - p.kh + p.sh) / p.sh;     // ceil((h+p-k+1)/s) for non-negative
+        if ((int)h + p.ph - p.kh + 1 <= 0) ho_lo = 0;
+        int ho_hi = ((int)h + p.ph) / p.sh;
+        if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
+        int wo_lo = ((int)w + p.pw - p.kw + p.sw) / p.sw;
+        if ((int)w + p.pw - p.kw + 1 <= 0) wo_lo = 0;
+        int wo_hi = ((int)w + p.pw) / p.sw;
+        if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                float best[VEC];
+                bool mine[VEC], any[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; mine[k] = false; any[k] = false; }
+                for (int r = 0; r < p.kh; ++r) {
+                    int hh = ho * p.sh - p.ph + r;
+                    if ((unsigned)hh >= (unsigned)p.H) continue;
+                    for (int q = 0; q < p.kw; ++q) {
+                        int ww = wo * p.sw - p.pw + q;
+                        if ((unsigned)ww >= (unsigned)p.W) continue;
+                        VL<T, VEC> v;
+                        v.load(x + ((size_t)(n * p.H + hh) * p.W + ww) * p.C + vc * VEC);
+                        bool me = hh == (int)h && ww == (int)w;
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k)
+                            if (!any[k] || v.f[k] > best[k] || v.f[k] != v.f[k]) {
+                                best[k] = v.f[k]; mine[k] = me; any[k] = true;
+                            }
+                    }
+                }
+                VL<T, VEC> g;
+                g.load(dy + ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.C + vc * VEC);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    if (mine[k]) acc[k] += g.f[k];
+            }
+        VL<T, VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.f[k] = acc[k];
+        o.store(dx + (size_t)i * VEC);
+    }
+}
+
+template <typename T, int VEC, int OP>   // OP 0: relu(a)  1: relu-bwd(dy=a, y=b)  2: relu(a+b)
+__global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                      T* __restrict__ o, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        VL<T, VEC> va, vb;
+        va.load(a + i * VEC);
+        if (OP != 0) vb.load(b + i * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (OP == 0) va.f[k] = va.f[k] > 0.f ? va.f[k] : 0.f;
+            if (OP == 1) va.f[k] = vb.f[k] > 0.f ? va.f[k] : 0.f;
+            if (OP == 2) { float s = va.f[k] + vb.f[k]; va.f[k] = s > 0.f ? s : 0.f; }
+        }
+        va.store(o + i * VEC);
+    }
+}
+
+template <typename T>
+__global__ void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    int n = i / C, c = i - n * C;
+    const T* p = x + (size_t)n * HW * C + c;
+    float acc = 0.f;
+    for (int k = 0; k < HW; ++k) acc += to_f32(p[(size_t)k * C]);
+    y[i] = acc / (float)HW;
+}
+template <typename T>
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, T* __restrict__ dx, int N, int HW, int C) {
+    size_t total = (size_t)N * HW * C;
+    float inv = 1.f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        int n = (int)(i / ((size_t)HW * C));
+        dx[i] = from_f32<T>(dy[(size_t)n * C + c] * inv);
+    }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C,
+                                    int H, int W) {
+    size_t total = (size_t)N * C * H * W, hw = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        size_t pix = i / C;
+        size_t n = pix / hw, s = pix - n * hw;
+        y[i] = from_f32<T>(x[(n * C + c) * hw + s]);
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n4, int64_t n, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2_sqrt) {
+    // step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps   (torch.optim.Adam)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t base = i * 4;
+        if (base + 4 <= n) {
+            f32x4 pp = *(f32x4*)(p + base), gg = *(const f32x4*)(g + base);
+            f32x4 mm = *(f32x4*)(m + base), vv = *(f32x4*)(v + base);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float gk = gg[k] + wd * pp[k];
+                mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+                vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+                float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+                pp[k] -= (lr / bc1) * (mm[k] / denom);
+            }
+            *(f32x4*)(p + base) = pp;
+            *(f32x4*)(m + base) = mm;
+            *(f32x4*)(v + base) = vv;
+        } else {
+            for (int64_t j = base; j < n; ++j) {
+                float gk = g[j] + wd * p[j];
+                m[j] = b1 * m[j] + (1.f - b1) * gk;
+                v[j] = b2 * v[j] + (1.f - b2) * gk * gk;
+                float denom = sqrtf(v[j]) / bc2_sqrt + eps;
+                p[j] -= (lr / bc1) * (m[j] / denom);
+            }
+        }
+    }
+}
+
+inline int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096);
+}
+
+PoolParams make_pool(int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                     int vec) {
+    PoolParams p;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+    p.Ho = (H + 2 * ph - kh) / sh + 1;
+    p.Wo = (W + 2 * pw - kw) / sw + 1;
+    p.fd_cols = make_fastdiv(C / vec);
+    p.fd_wo = make_fastdiv(p.Wo); p.fd_ho = make_fastdiv(p.Ho);
+    p.fd_w = make_fastdiv(W); p.fd_h = make_fastdiv(H);
+    return p;
+}
+
+}  // namespace
+
+template <typename T, int VEC>
+static int maxpool_t(bool bwd, const void* a, const void* b, void* o, int N, int H, int W, int C,
+                     int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t s) {
+    PoolParams p = make_pool(N, H, W, C, kh, kw, sh, sw, ph, pw, VEC);
+    if (!bwd) {
+        int64_t total = (int64_t)N * p.Ho * p.Wo * (C / VEC);
+        CNK_CHECK_ARG(total < (1ll << 31), "maxpool: tensor too large");
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, VEC>), dim3(grid_for(total)), dim3(256), 0, s,
+                           (const T*)a, (T*)o, p, total);
+    } else {
+        int64_t total = (int64_t)N * H * W * (C / VEC);
+        CNK_CHECK_ARG(total < (1ll << 31), "maxpool: tensor too large");
+        hipLaunchKernelGGL((maxpool_bwd_kernel<T, VEC>), dim3(grid_for(total)), dim3(256), 0, s,
+                           (const T*)a, (const T*)b, (T*)o, p, total);
+    }
+    CNK_CHECK_LAUNCH("maxpool");
+    return 0;
+}
+
+int maxpool_dispatch(bool bwd, const void* a, const void* b, void* o, int N, int H, int W, int C,
+                     int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s) {
+    if (dtype == CNK_BF16) {
+        if (C % 8 == 0) return maxpool_t<bf16, 8>(bwd, a, b, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+        return maxpool_t<bf16, 1>(bwd, a, b, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    }
+    if (C % 4 == 0) return maxpool_t<float, 4>(bwd, a, b, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    return maxpool_t<float, 1>(bwd, a, b, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+}
+
+template <int OP>
+int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s) {
+    if (n == 0) return 0;
+    if (dtype == CNK_BF16) {
+        if (n % 8 == 0)
+            hipLaunchKernelGGL((eltwise_kernel<bf16, 8, OP>), dim3(grid_for(n / 8)), dim3(256), 0, s,
+                               (const bf16*)a, (const bf16*)b, (bf16*)o, n / 8);
+        else
+            hipLaunchKernelGGL((eltwise_kernel<bf16, 1, OP>), dim3(grid_for(n)), dim3(256), 0, s,
+                               (const bf16*)a, (const bf16*)b, (bf16*)o, n);
+    } else {
+        if (n % 4 == 0)
+            hipLaunchKernelGGL((eltwise_kernel<float, 4, OP>), dim3(grid_for(n / 4)), dim3(256), 0, s,
+                               (const float*)a, (const float*)b, (float*)o, n / 4);
+        else
+            hipLaunchKernelGGL((eltwise_kernel<float, 1, OP>), dim3(grid_for(n)), dim3(256), 0, s,
+                               (const float*)a, (const float*)b, (float*)o, n);
+    }
+    CNK_CHECK_LAUNCH("eltwise");
+    return 0;
+}
+template int eltwise_dispatch<0>(const void*, const void*, void*, int64_t, int, hipStream_t);
+template int eltwise_dispatch<1>(const void*, const void*, void*, int64_t, int, hipStream_t);
+template int eltwise_dispatch<2>(const void*, const void*, void*, int64_t, int, hipStream_t);
+
+int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s) {
+    if (!bwd) {
+        int total = N * C;
+        if (dtype == CNK_BF16)
+            hipLaunchKernelGGL(gap_fwd_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const bf16*)a, (float*)o, N, HW, C);
+        else
+            hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)a, (float*)o, N, HW, C);
+    } else {
+        int64_t total = (int64_t)N * HW * C;
+        if (dtype == CNK_BF16)
+            hipLaunchKernelGGL(gap_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)a, (bf16*)o, N, HW, C);
+        else
+            hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)a, (float*)o, N, HW, C);
+    }
+    CNK_CHECK_LAUNCH("gap");
+    return 0;
+}
+
+int nchw_to_nhwc_dispatch(const float* x, void* y, int N, int C, int H, int W, int dtype,
+                          hipStream_t s) {
+    int64_t total = (int64_t)N * C * H * W;
+    if (dtype == CNK_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16*)y, N, C, H, W);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, N, C, H, W);
+    CNK_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+
+int adam_dispatch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                  float b2, float eps, float wd, int step, hipStream_t s) {
+    float bc1 = 1.f - powf(b1, (float)step);
+    float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+    int64_t n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4)), dim3(256), 0, s, p, g, m, v, n4, n, lr, b1, b2,
+                       eps, wd, bc1, bc2_sqrt);
+    CNK_CHECK_LAUNCH("adam");
+    return 0;
+}

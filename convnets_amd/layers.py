@@ -1,0 +1,128 @@
+"""Drop-in modules returned by the layer factory (convnets_amd/basemodel.py).
+
+They SUBCLASS the stock torch.nn modules the reference's factory returns
+(src/basemodel.py:966-1067), so everything the reference does with a layer keeps working:
+`.kernel_size/.stride/.padding/.dilation/.out_channels` for the shape tracker (:725-781),
+`isinstance(m, nn.Conv2d / nn.BatchNorm2d)` for init_params (:85-108), parameter/buffer names and
+shapes for state_dict interchange (:883,940), `.train()/.eval()`, `.to(device)`, deepcopy.
+Only `forward` is replaced: it dispatches to the HIP kernels through convnets_amd.ops.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d with the MI355X implicit-GEMM forward/dgrad/wgrad (groups=1, dilation=1, zeros
+    padding -- everything the hot path's models use; anything else is refused loudly)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.groups != 1 or _pair(self.dilation) != (1, 1) or self.padding_mode != 'zeros' \
+                or isinstance(self.padding, str):
+            raise NotImplementedError('convnets_amd.Conv2d: groups/dilation/padding_mode outside the '
+                                      'hot path (groups=1, dilation=1, zeros) are not implemented')
+        self._packed = ops.PackedWeights()
+
+    def __deepcopy__(self, memo):
+        # the packed-weight cache is derived state; rebuild it in the copy
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = ops.PackedWeights() if k == '_packed' else copy.deepcopy(v, memo)
+        return new
+
+    def forward(self, x):
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
+                                  self._packed)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d; `forward(x, residual=None, relu=False)` exposes the fused epilogue used by
+    ConvBlock and the residual blocks.  Called plainly it is exactly BatchNorm2d."""
+
+    def forward(self, x, residual=None, relu=False):
+        if not (self.affine and self.track_running_stats):
+            raise NotImplementedError('convnets_amd.BatchNorm2d: affine=True, '
+                                      'track_running_stats=True only (the factory default)')
+        if self.training:
+            if self.momentum is None:
+                raise NotImplementedError('convnets_amd.BatchNorm2d: cumulative momentum (None)')
+            y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
+                                         self.running_var, float(self.eps), float(self.momentum),
+                                         bool(relu))
+            self.num_batches_tracked += 1
+            return y
+        return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                   float(self.eps), residual, relu)
+
+
+class ReLU(nn.ReLU):
+    """nn.ReLU(inplace=True) of the factory (basemodel.py:1012).  The result is returned in a new
+    tensor: the reference's in-place flag is a memory optimisation with no observable effect on
+    the values a Sequential passes on."""
+
+    def forward(self, x):
+        return ops.ReLUFn.apply(x)
+
+
+class MaxPool2d(nn.MaxPool2d):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if _pair(self.dilation) != (1, 1) or self.ceil_mode or self.return_indices:
+            raise NotImplementedError('convnets_amd.MaxPool2d: dilation=1, ceil_mode=False only')
+
+    def forward(self, x):
+        k = _pair(self.kernel_size)
+        s = _pair(self.stride if self.stride is not None else self.kernel_size)
+        return ops.MaxPool2dFn.apply(x, k, s, _pair(self.padding))
+
+
+class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    def __init__(self, output_size):
+        super().__init__(output_size)
+        if _pair(self.output_size) != (1, 1):
+            raise NotImplementedError('convnets_amd.AdaptiveAvgPool2d: output_size=1 (global pool) only')
+
+    def forward(self, x):
+        return ops.GlobalAvgPoolFn.apply(x)
+
+
+class ConvBlock(nn.Sequential):
+    """conv -> [BN] -> [ReLU] as conv2d_block builds it (basemodel.py:999-1015): an nn.Sequential
+    with children '0','1','2' (same state_dict keys), whose forward runs BN + ReLU (+ the residual
+    add of the enclosing block) as ONE fused kernel pass instead of three."""
+
+    def forward(self, x, residual=None, relu_after_add=False):
+        mods = list(self)
+        conv = mods[0]
+        bn = mods[1] if len(mods) > 1 and isinstance(mods[1], BatchNorm2d) else None
+        act = isinstance(mods[-1], ReLU)
+        y = conv(x)
+        if bn is not None:
+            return bn(y, residual=residual, relu=act or relu_after_add)
+        if residual is not None:
+            if act:
+                y = ops.ReLUFn.apply(y)
+            return ops.AddReLUFn.apply(y, residual) if relu_after_add else y + residual
+        return ops.ReLUFn.apply(y) if act else y
+
+
+class Conv2dBlock(ConvBlock):
+    """The reference's named-children variant (basemodel.py:1045-1067): conv / bn / relu."""
+
+    def __init__(self, network, in_channels=None, num_filters=None, set_output=True, activation=True,
+                 **kwargs):
+        super().__init__()
+        self.add_module('conv', network.conv2d(in_channels, num_filters, set_output, **kwargs))
+        if network.setting.batch_norm:
+            self.add_module('bn', BatchNorm2d(num_features=num_filters))
+        if activation:
+            self.add_module('relu', ReLU(inplace=True))

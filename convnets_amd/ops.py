@@ -1,0 +1,333 @@
+"""torch.autograd.Function wrappers over the C ABI (include/cnk.h).
+
+Tensors are logical NCHW in torch.channels_last memory format (= physical NHWC), so the
+reference's semantics -- flatten order, state_dict shapes [Cout,Cin,kh,kw] -- are untouched
+(reference call sites: src/basemodel.py:974,1008,1012,1021,1039; src/resnet.py:151-154,191-194).
+PyTorch is used for device memory, streams and autograd bookkeeping only; every kernel that
+touches an activation is in libcnk.so.  Nothing here falls back to ATen/MIOpen.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CNK_BF16, CNK_F32, ConvDesc, PASS_DGRAD, PASS_FWD, PASS_WGRAD, check
+
+CL = torch.channels_last
+
+# bumped whenever parameters change behind autograd's back (flat-arena optimizer step,
+# load_state_dict): conv modules re-pack their weight images when it moves
+_weights_epoch = [0]
+
+
+def bump_weights_epoch():
+    _weights_epoch[0] += 1
+
+
+def weights_epoch():
+    return _weights_epoch[0]
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return CNK_F32
+    if t.dtype == torch.bfloat16:
+        return CNK_BF16
+    raise TypeError('convnets_amd: unsupported activation dtype %s (fp32 or bf16)' % t.dtype)
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('convnets_amd ops run on the MI355X HIP path only (got a %s tensor); '
+                           'there is no CPU fallback' % t.device)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _nhwc(t):
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """One grow-only scratch buffer per device; all kernels are stream-ordered on the caller's
+    stream, so successive ops can share it (the library itself never allocates)."""
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def make_desc(x_shape, weight_shape, stride, padding, dtype_code):
+    N, Cin, H, W = x_shape
+    Cout, Cin_w, kh, kw = weight_shape
+    if Cin != Cin_w:
+        raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_w))
+    return ConvDesc(N, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                    dtype_code)
+
+
+class PackedWeights:
+    """The two operand images of one conv weight (cnk_conv2d_pack_weights), re-made when the
+    master weight changes."""
+
+    def __init__(self):
+        self.key = None
+        self.w_fwd = None
+        self.w_dgrad = None
+
+    def get(self, weight, desc, need_dgrad):
+        lib = _lib.load()
+        key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad)
+        if self.key != key:
+            dev = weight.device
+            nf = lib.cnk_conv2d_packed_bytes(ctypes.byref(desc), PASS_FWD)
+            self.w_fwd = torch.empty(nf, dtype=torch.uint8, device=dev)
+            self.w_dgrad = None
+            if need_dgrad:
+                nd = lib.cnk_conv2d_packed_bytes(ctypes.byref(desc), PASS_DGRAD)
+                self.w_dgrad = torch.empty(nd, dtype=torch.uint8, device=dev)
+            with torch.no_grad():
+                check(lib.cnk_conv2d_pack_weights(ctypes.byref(desc), _p(weight), _p(self.w_fwd),
+                                                  _p(self.w_dgrad), _stream()))
+            self.key = key
+        return self.w_fwd, self.w_dgrad
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d forward / dgrad / wgrad (reference: basemodel.py:974)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, packed):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x))
+        need_dgrad = x.requires_grad
+        w_fwd, w_dgrad = packed.get(w, desc, need_dgrad)
+        Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
+        lib.cnk_conv2d_out_hw(ctypes.byref(desc), ctypes.byref(Ho), ctypes.byref(Wo))
+        y = torch.empty((desc.N, desc.Cout, Ho.value, Wo.value), dtype=x.dtype, device=x.device,
+                        memory_format=CL)
+        check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), None, 0,
+                                 _stream()))
+        ctx.save_for_backward(x, w)
+        ctx.desc, ctx.w_dgrad, ctx.has_bias = desc, w_dgrad, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        desc = ctx.desc
+        dy = _nhwc(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=CL)
+            check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(dx), None, 0,
+                                       _stream()))
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+            if ctx.has_bias:
+                db = torch.empty((desc.Cout,), dtype=torch.float32, device=w.device)
+            nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), PASS_WGRAD)
+            ws = workspace(nws, x.device)
+            check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw), _p(db), 0, _p(ws),
+                                       ws.numel(), _stream()))
+        return dx, dw, db, None, None, None
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """nn.BatchNorm2d (training mode) fused with the following ReLU and, in the residual blocks,
+    with `output += identity; F.relu(output)` (basemodel.py:1008-1012, resnet.py:191-194)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        if residual is not None:
+            residual = _nhwc(residual)
+            if residual.shape != x.shape or residual.dtype != x.dtype:
+                raise ValueError('batch_norm: residual must match the input shape and dtype')
+        N, C, H, W = x.shape
+        M = N * H * W
+        y = torch.empty_like(x, memory_format=CL)
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean),
+                                   _p(running_var), _p(save_mean), _p(save_invstd), M, C, eps,
+                                   momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(x, y if relu else None, gamma, save_mean, save_invstd)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        dy = _nhwc(dy)
+        N, C, H, W = x.shape
+        M = N * H * W
+        dx = torch.empty_like(x, memory_format=CL)
+        want_res = ctx.has_res and ctx.needs_input_grad[3]
+        if want_res and not ctx.relu:
+            dres = dy                       # identity branch of a plain add: gradient passes through
+            dres_out = None
+        else:
+            dres = torch.empty_like(x, memory_format=CL) if want_res else None
+            dres_out = dres
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(save_mean), _p(save_invstd), _p(dx),
+                             _p(dres_out), _p(dgamma), _p(dbeta), 0, M, C, int(ctx.relu),
+                             _dtype_code(x), _p(ws), ws.numel(), _stream()))
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
+
+
+def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):
+    """Eval-mode BN (valid_model, basemodel.py:311); inference only, no autograd graph."""
+    _require_gpu(x)
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
+        raise RuntimeError('convnets_amd: eval-mode batch norm is inference-only; wrap the call in '
+                           'torch.no_grad() as the reference does (basemodel.py:304)')
+    lib = _lib.load()
+    x = _nhwc(x)
+    if residual is not None:
+        residual = _nhwc(residual)
+    N, C, H, W = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    check(lib.cnk_bn_fwd_eval(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                              _p(residual), _p(y), N * H * W, C, eps, int(relu), _dtype_code(x),
+                              _stream()))
+    return y
+
+
+class MaxPool2dFn(torch.autograd.Function):
+    """nn.MaxPool2d (basemodel.py:1021)."""
+
+    @staticmethod
+    def forward(ctx, x, ksize, stride, padding):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        N, C, H, W = x.shape
+        Ho = (H + 2 * padding[0] - ksize[0]) // stride[0] + 1
+        Wo = (W + 2 * padding[1] - ksize[1]) // stride[1] + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=CL)
+        check(lib.cnk_maxpool2d_fwd(_p(x), _p(y), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
+                                    padding[0], padding[1], _dtype_code(x), _stream()))
+        ctx.save_for_backward(x)
+        ctx.geom = (ksize, stride, padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        ksize, stride, padding = ctx.geom
+        dy = _nhwc(dy)
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x, memory_format=CL)
+        check(lib.cnk_maxpool2d_bwd(_p(dy), _p(x), _p(dx), N, H, W, C, ksize[0], ksize[1], stride[0],
+                                    stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
+        return dx, None, None, None
+
+
+class ReLUFn(torch.autograd.Function):
+    """nn.ReLU / F.relu as a stand-alone op (basemodel.py:1012; resnet.py:154,194)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = x if (x.is_contiguous() or x.is_contiguous(memory_format=CL)) else x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.cnk_relu_fwd(_p(x), _p(y), x.numel(), _dtype_code(x), _stream()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        if dy.stride() != y.stride():
+            dy = dy.contiguous(memory_format=CL) if y.is_contiguous(memory_format=CL) and y.dim() == 4 \
+                else dy.contiguous()
+        dx = torch.empty_like(y)
+        check(lib.cnk_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _dtype_code(y), _stream()))
+        return dx
+
+
+class AddReLUFn(torch.autograd.Function):
+    """`output += identity; output = F.relu(output)` (resnet.py:151-154,191-194) for blocks whose
+    last conv has no BN to fuse into."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a)
+        lib = _lib.load()
+        a, b = _nhwc(a), _nhwc(b)
+        y = torch.empty_like(a, memory_format=CL)
+        check(lib.cnk_add_relu_fwd(_p(a), _p(b), _p(y), a.numel(), _dtype_code(a), _stream()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        dy = _nhwc(dy)
+        dx = torch.empty_like(y, memory_format=CL)
+        check(lib.cnk_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _dtype_code(y), _stream()))
+        return dx, dx
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) (basemodel.py:1039); returns fp32 [N,C,1,1] for the fp32 head."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, 1, 1), dtype=torch.float32, device=x.device)
+        check(lib.cnk_gap_fwd(_p(x), _p(y), N, H * W, C, _dtype_code(x), _stream()))
+        ctx.shape, ctx.dt = x.shape, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, C, H, W = ctx.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty(ctx.shape, dtype=ctx.dt, device=dy.device, memory_format=CL)
+        check(lib.cnk_gap_bwd(_p(dy), _p(dx), N, H * W, C, CNK_BF16 if ctx.dt == torch.bfloat16 else CNK_F32,
+                              _stream()))
+        return dx
+
+
+def nchw_to_nhwc(x, dtype):
+    """Model-boundary hand-off: the reference feeds NCHW fp32 batches (basemodel.py:185-188)."""
+    _require_gpu(x)
+    lib = _lib.load()
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H, W), dtype=dtype, device=x.device, memory_format=CL)
+    check(lib.cnk_nchw_to_nhwc(_p(x), _p(y), N, C, H, W, CNK_BF16 if dtype == torch.bfloat16 else CNK_F32,
+                               _stream()))
+    return y

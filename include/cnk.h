@@ -1,0 +1,155 @@
+/* cnk.h -- C ABI of the MI355X-native conv / batch-norm / pool / ReLU training path.
+ *
+ * The reference (milan-pavlovic-ai/ConvNets) has no FFI or plugin interface of its own: its
+ * narrowest seam is the layer factory of MultiClassBaseModel (src/basemodel.py:966-1042), whose
+ * returned torch.nn modules do all arithmetic inside third-party torch.  Each entry point below
+ * therefore replaces the torch operator that one reference call site reaches; the citation on
+ * every declaration names that call site (file:line in /root/reference/src).  The Python host
+ * side (convnets_amd/) binds these through ctypes and mirrors the reference factory on top.
+ *
+ * Conventions
+ *   - every function returns 0 on success, nonzero on error; cnk_last_error() gives the message
+ *     (thread-local).  The library never exits, aborts, allocates, frees, or synchronises.
+ *   - all tensor arguments are raw DEVICE pointers owned by the caller (inputs, outputs, saved
+ *     statistics, workspaces); nothing is retained across calls.
+ *   - activations are NHWC ("channels_last"): x[n][h][w][c], element type given by `dtype`
+ *     (CNK_F32 or CNK_BF16).  Master weights, weight/bias gradients, BN parameters and
+ *     statistics are always fp32.  Master conv weights keep the reference layout
+ *     [Cout][Cin][kh][kw] (nn.Conv2d.weight, basemodel.py:974).
+ *   - `stream` is a hipStream_t passed as void*; kernels are launched only on it.
+ *   - re-entrant: forward is called from the Python main thread, backward from the autograd
+ *     engine thread (loss.backward(), basemodel.py:278).
+ */
+#ifndef CNK_H
+#define CNK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CNK_F32 = 0, CNK_BF16 = 1 };
+enum { CNK_PASS_FWD = 0, CNK_PASS_DGRAD = 1, CNK_PASS_WGRAD = 2 };
+
+/* One nn.Conv2d as the reference factory builds it: groups=1, dilation=1, zero padding
+ * (basemodel.py:966-979; kwargs forwarded verbatim at :974). */
+typedef struct cnk_conv_desc {
+    int32_t N, H, W, Cin;      /* input  x[N][H][W][Cin]              */
+    int32_t Cout, kh, kw;      /* weight w[Cout][Cin][kh][kw] (fp32)  */
+    int32_t stride_h, stride_w;
+    int32_t pad_h, pad_w;
+    int32_t dtype;             /* element type of x, y, dy, dx        */
+} cnk_conv_desc;
+
+int cnk_version(void);
+const char* cnk_last_error(void);
+
+/* Output spatial size, floor((H + 2p - k)/s) + 1 -- the reference's shape tracker formula
+ * (basemodel.py:770-771). */
+int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo);
+
+/* Bytes of packed weights for `pass` (FWD or DGRAD) and of workspace for `pass`. */
+size_t cnk_conv2d_packed_bytes(const cnk_conv_desc* d, int pass);
+size_t cnk_conv2d_workspace_bytes(const cnk_conv_desc* d, int pass);
+
+/* Re-lays the fp32 master weight into the operand images the kernels stream:
+ *   w_fwd   [Cout][kh][kw][Cin]            in `dtype` (forward B operand, K contiguous)
+ *   w_dgrad [class][Cin][taps(class)][Cout] in `dtype` (dgrad B operand per stride-parity class)
+ * Either output may be NULL.  Replaces nothing in the reference (torch keeps its own packed
+ * copies inside oneDNN/cuDNN); called once per optimizer step. */
+int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
+                            void* stream);
+
+/* y = conv2d(x, w) (+ bias).  nn.Conv2d.forward reached from basemodel.py:974 via :1004.
+ * bias (fp32[Cout]) may be NULL: the reference has a bias only when batch_norm is off (:973). */
+int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                   void* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dx = conv2d_transpose(dy, w): autograd's input gradient of the call above
+ * (loss.backward(), basemodel.py:258/278). */
+int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* dw[Cout][Cin][kh][kw] (fp32) = sum over N,Ho,Wo of dy * x ; dbias[Cout] = sum dy (may be NULL).
+ * accumulate != 0 adds into dw/dbias (torch's .grad accumulation), else overwrites. */
+int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
+                     float* dbias, int accumulate, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* nn.BatchNorm2d in training mode (basemodel.py:1008,1061), optionally fused with the ReLU that
+ * follows it in conv2d_block (:1012) and with the residual add + F.relu of the ResNet blocks
+ * (resnet.py:151-154,191-194):   y = act( (x-mean)*invstd*gamma + beta [+ residual] ).
+ * x,y,residual: [M][C] NHWC-flattened, M = N*H*W.  Batch mean / biased variance are computed in
+ * fp32; running_mean/var (may be NULL) get momentum updates with the UNBIASED variance;
+ * save_mean/save_invstd (fp32[C]) are outputs kept for the backward.
+ * workspace: cnk_bn_workspace_bytes(M, C). */
+size_t cnk_bn_workspace_bytes(int64_t M, int32_t C);
+int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual,
+                     void* y, float* running_mean, float* running_var, float* save_mean,
+                     float* save_invstd, int64_t M, int32_t C, float eps, float momentum,
+                     int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Eval mode (valid_model, basemodel.py:311): running statistics, same fused epilogue. */
+int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* running_mean,
+                    const float* running_var, const void* residual, void* y, int64_t M, int32_t C,
+                    float eps, int relu, int dtype, void* stream);
+
+/* Backward of cnk_bn_fwd_train.  y is the forward OUTPUT (needed only when relu != 0: the mask is
+ * taken from the output like nn.ReLU's backward).  dresidual (may be NULL) receives the gradient
+ * of the residual operand (= masked dy).  dgamma/dbeta fp32[C]; accumulate as in wgrad. */
+int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma,
+               const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
+               float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu,
+               int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.MaxPool2d (basemodel.py:1017-1024): floor mode, implicit -inf padding, dilation 1.
+ * The backward re-derives the arg-max (first maximum in row-major window order, as torch)
+ * from x instead of storing indices. */
+int cnk_maxpool2d_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                      int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw,
+                      int dtype, void* stream);
+int cnk_maxpool2d_bwd(const void* dy, const void* x, void* dx, int32_t N, int32_t H, int32_t W,
+                      int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph,
+                      int32_t pw, int dtype, void* stream);
+
+/* nn.ReLU (basemodel.py:1012,1065) and the block-level  output += identity; F.relu(output)
+ * (resnet.py:151-154,191-194) as stand-alone ops for unfused use. */
+int cnk_relu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int cnk_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+int cnk_add_relu_fwd(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+
+/* nn.AdaptiveAvgPool2d(1) (basemodel.py:1035-1042): y[N][C] = mean over H*W; output fp32. */
+int cnk_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, int dtype, void* stream);
+int cnk_gap_bwd(const float* dy, void* dx, int32_t N, int32_t HW, int32_t C, int dtype,
+                void* stream);
+
+/* Layout/precision hand-off at the model boundary: the reference feeds NCHW fp32 batches
+ * (basemodel.py:185-188); the path computes in NHWC `dtype`. */
+int cnk_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int32_t N, int32_t C, int32_t H, int32_t W,
+                     int dtype, void* stream);
+
+/* optim.Adam with L2 weight decay as the reference configures it (basemodel.py:64-67; betas
+ * (0.9,0.999), eps 1e-8), over one flat fp32 arena holding every parameter:
+ *   g += wd*p; m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v/(1-b2^t))+eps)
+ * `step` is the 1-based step count t. */
+int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline
+ * leg).  cnk_prof_begin(tag_mask) arms recording for kernels whose class bit is set;
+ * cnk_prof_collect synchronises the recorded events (call after the timed region) and returns
+ * count / total milliseconds / total algorithmic flops for `cls`. */
+enum { CNK_CLS_CONV3X3_FWD = 1, CNK_CLS_CONV3X3_DGRAD = 2, CNK_CLS_CONV3X3_WGRAD = 4,
+       CNK_CLS_CONV1X1_FWD = 8, CNK_CLS_CONV1X1_DGRAD = 16, CNK_CLS_CONV1X1_WGRAD = 32,
+       CNK_CLS_BN_FWD = 64, CNK_CLS_BN_BWD = 128, CNK_CLS_OTHER = 256 };
+int cnk_prof_begin(int32_t class_mask);
+int cnk_prof_collect(int32_t cls, int64_t* count, double* total_ms, double* total_flops,
+                     double* total_bytes);
+int cnk_prof_end(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNK_H */

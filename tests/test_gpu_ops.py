@@ -1,0 +1,268 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every hot-path operator, called through
+the C ABI (convnets_amd.ops -> ctypes -> libcnk.so), against
+  (1) the golden vectors produced from the reference's own factory-built layers (tests/golden/ops.npz),
+  (2) the oracle (oracle/cpu_ops.c / torch-CPU) on seeded inputs covering edge tiles, ragged sizes,
+      strides and every kernel family (MFMA implicit-GEMM, MFMA wgrad, direct).
+Tolerances: fp32 path L2-rel <= 1e-5 (wgrad 2e-5: long fp32 reductions);
+bf16-operand path L2-rel <= 1e-2 against the fp32 oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+OPS = np.load(os.path.join(G, 'ops.npz'))
+CL = torch.channels_last
+TOL = {torch.float32: 1e-5, torch.bfloat16: 1e-2}
+TOLW = {torch.float32: 2e-5, torch.bfloat16: 1e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def dev(a, dtype=torch.float32):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dtype)
+    return t.contiguous(memory_format=CL) if t.dim() == 4 else t
+
+
+def host(t):
+    return t.detach().float().cpu().contiguous().numpy()
+
+
+def _cases(prefix):
+    return sorted({k.split('/')[1] for k in OPS.files if k.startswith(prefix + '/')})
+
+
+def run_conv(x, w, b, dy, stride, pad, dtype):
+    from convnets_amd import ops
+    xt = dev(x, dtype).requires_grad_(True)
+    wt = dev(w).contiguous().requires_grad_(True)
+    bt = dev(b).requires_grad_(True) if b is not None else None
+    y = ops.Conv2dFn.apply(xt, wt, bt, (stride, stride), (pad, pad), ops.PackedWeights())
+    y.backward(dev(dy, dtype))
+    torch.cuda.synchronize()
+    return host(y), host(xt.grad), host(wt.grad), (host(bt.grad) if bt is not None else None)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('name', _cases('conv'))
+def test_conv_golden(name, dtype):
+    g = lambda k: OPS[f'conv/{name}/{k}']
+    N, Ci, H, W, Co, k, st, p, has_b = g('cfg')
+    y, dx, dw, db = run_conv(g('x'), g('w'), g('b') if has_b else None, g('dy'), int(st), int(p), dtype)
+    assert rel_l2(y, g('y')) < TOL[dtype], 'fwd'
+    assert rel_l2(dx, g('dx')) < TOL[dtype], 'dgrad'
+    assert rel_l2(dw, g('dw')) < TOLW[dtype], 'wgrad'
+    if has_b:
+        assert rel_l2(db, g('db')) < TOLW[dtype], 'dbias'
+
+
+# (N, Cin, H, W, Cout, k, stride, pad): ragged M (not a tile multiple), multi-tile N, both strides,
+# 5x5, every (BMW,BNW) wgrad tile, direct-path shapes, 1-pixel images
+RANDOM_CONVS = [
+    (3, 64, 17, 19, 128, 3, 1, 1), (2, 128, 9, 9, 64, 1, 2, 0), (5, 64, 7, 7, 64, 3, 2, 1),
+    (2, 256, 14, 14, 256, 3, 1, 1), (2, 128, 28, 28, 512, 1, 1, 0), (1, 512, 7, 7, 2048, 1, 1, 0),
+    (2, 64, 13, 13, 192, 5, 1, 2), (4, 192, 6, 6, 384, 3, 1, 1), (1, 64, 1, 1, 64, 1, 1, 0),
+    (2, 64, 56, 56, 64, 3, 1, 1), (1, 1024, 14, 14, 2048, 1, 2, 0), (2, 3, 37, 41, 64, 7, 2, 3),
+    (3, 6, 10, 10, 16, 5, 1, 0), (2, 32, 9, 9, 64, 5, 2, 1), (2, 16, 8, 8, 24, 3, 1, 1),
+    (1, 128, 5, 5, 128, 3, 2, 1), (2, 64, 8, 8, 64, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', RANDOM_CONVS, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_vs_oracle(cfg, dtype):
+    N, Ci, H, W, Co, k, st, p = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % (2 ** 31))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * (2.0 / (Ci * k * k)) ** 0.5
+    if dtype == torch.bfloat16:      # compare on identical (bf16-representable) operands
+        x, w = x.bfloat16().float(), w
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr.double(), wr.double(), stride=st, padding=p)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy.double())
+    y, dx, dw, _ = run_conv(x.numpy(), w.numpy(), None, dy.numpy(), st, p, dtype)
+    assert rel_l2(y, yr.detach().numpy()) < TOL[dtype], 'fwd'
+    assert rel_l2(dx, xr.grad.numpy()) < TOL[dtype], 'dgrad'
+    assert rel_l2(dw, wr.grad.numpy()) < TOLW[dtype], 'wgrad'
+
+
+def test_conv_small_case_vs_c_oracle():
+    from oracle import cpu_ops as orc
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 64, 6, 5)).astype(np.float32)
+    w = (rng.standard_normal((64, 64, 3, 3)) * 0.05).astype(np.float32)
+    dy = rng.standard_normal((2, 64, 3, 3)).astype(np.float32)
+    y, dx, dw, _ = run_conv(x, w, None, dy, 2, 1, torch.float32)
+    assert rel_l2(y, orc.conv2d_fwd(x, w, None, 2, 1)) < 1e-5
+    assert rel_l2(dx, orc.conv2d_dgrad(dy, w, (6, 5), 2, 1)) < 1e-5
+    assert rel_l2(dw, orc.conv2d_wgrad(dy, x, 3, 2, 1)) < 2e-5
+
+
+def run_bn(x, gamma, beta, res, dy, relu, dtype, rm=None, rv=None):
+    from convnets_amd import ops
+    xt = dev(x, dtype).requires_grad_(True)
+    gt, bt = dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    rt = dev(res, dtype).requires_grad_(True) if res is not None else None
+    C = x.shape[1]
+    rm = torch.zeros(C, device='cuda') if rm is None else rm
+    rv = torch.ones(C, device='cuda') if rv is None else rv
+    y = ops.BatchNormActFn.apply(xt, gt, bt, rt, rm, rv, 1e-5, 0.1, relu)
+    y.backward(dev(dy, dtype))
+    torch.cuda.synchronize()
+    return (host(y), host(xt.grad), host(gt.grad), host(bt.grad),
+            host(rt.grad) if rt is not None else None, host(rm), host(rv))
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(4, 64, 10, 10), (2, 256, 7, 7), (3, 2048, 2, 2), (2, 192, 5, 5),
+                                   (2, 6, 9, 9), (1, 16, 1, 3), (8, 64, 33, 31), (2, 128, 40, 40)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('mode', ['plain', 'relu', 'add_relu'])
+def test_batchnorm_vs_oracle(shape, mode, dtype):
+    g = torch.Generator().manual_seed(sum(shape) + len(mode))
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    res = torch.randn(shape, generator=g) if mode == 'add_relu' else None
+    dy = torch.randn(shape, generator=g)
+    gamma, beta = torch.rand(shape[1], generator=g) + 0.5, torch.randn(shape[1], generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+        res = res.bfloat16().float() if res is not None else None
+    xr = x.clone().double().requires_grad_(True)
+    gr, br = gamma.clone().double().requires_grad_(True), beta.clone().double().requires_grad_(True)
+    rr = res.clone().double().requires_grad_(True) if res is not None else None
+    rm, rv = torch.zeros(shape[1], dtype=torch.float64), torch.ones(shape[1], dtype=torch.float64)
+    z = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    if rr is not None:
+        z = z + rr
+    yr = torch.relu(z) if mode != 'plain' else z
+    yr.backward(dy.double())
+    y, dx, dg, db, dres, rm2, rv2 = run_bn(x.numpy(), gamma.numpy(), beta.numpy(),
+                                           None if res is None else res.numpy(), dy.numpy(),
+                                           mode != 'plain', dtype)
+    t = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(y, yr.detach().numpy()) < t, 'y'
+    assert rel_l2(rm2, rm.numpy()) < 1e-5 and rel_l2(rv2, rv.numpy()) < 1e-5, 'running stats'
+    assert rel_l2(dx, xr.grad.numpy()) < (1e-4 if dtype == torch.float32 else 2e-2), 'dx'
+    assert rel_l2(dg, gr.grad.numpy()) < (5e-5 if dtype == torch.float32 else 2e-2), 'dgamma'
+    assert rel_l2(db, br.grad.numpy()) < (5e-5 if dtype == torch.float32 else 2e-2), 'dbeta'
+    if res is not None:
+        assert rel_l2(dres, rr.grad.numpy()) < t, 'dres'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('name', _cases('block'))
+def test_conv_block_golden(name, dtype):
+    """conv -> BN -> ReLU exactly as the reference's conv2d_block builds it, train and eval mode."""
+    import convnets_amd as ca
+    g = lambda k: OPS[f'block/{name}/{k}']
+    N, Ci, H, W, Co, k, st, p, act = [int(v) for v in g('cfg')]
+    s = ca.Settings(kind=0, input_size=(Ci, H, W), num_classes=10, mixed_precision=dtype == torch.bfloat16)
+    net = ca.MultiClassBaseModel(s)
+    blk = net.conv2d_block(num_filters=Co, kernel_size=k, stride=st, padding=p, activation=bool(act)).cuda()
+    assert (net.in_channels, net.height, net.width) == tuple(g('y').shape[1:])
+    with torch.no_grad():
+        blk[0].weight.copy_(dev(g('w')))
+        blk[1].weight.copy_(dev(g('gamma')))
+        blk[1].bias.copy_(dev(g('beta')))
+    blk.train()
+    x = dev(g('x'), dtype).requires_grad_(True)
+    y = blk(x)
+    y.backward(dev(g('dy'), dtype))
+    torch.cuda.synchronize()
+    t, tg = (2e-5, 1e-4) if dtype == torch.float32 else (1.5e-2, 3e-2)
+    assert rel_l2(host(y), g('y')) < t
+    assert rel_l2(host(blk[1].running_mean), g('running_mean')) < t
+    assert rel_l2(host(blk[1].running_var), g('running_var')) < t
+    assert int(blk[1].num_batches_tracked) == 1
+    assert rel_l2(host(blk[0].weight.grad), g('dw')) < tg
+    assert rel_l2(host(blk[1].weight.grad), g('dgamma')) < tg
+    assert rel_l2(host(blk[1].bias.grad), g('dbeta')) < tg
+    if name != 'blkstem':
+        assert rel_l2(host(x.grad), g('dx')) < tg
+    blk.eval()
+    with torch.no_grad():
+        ye = blk(dev(g('x'), dtype))
+    assert rel_l2(host(ye), g('y_eval')) < t
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('name', _cases('pool'))
+def test_maxpool_golden(name, dtype):
+    from convnets_amd import ops
+    g = lambda k: OPS[f'pool/{name}/{k}']
+    N, C, H, W, k, st, p = [int(v) for v in g('cfg')]
+    x = torch.from_numpy(g('x'))
+    dy = torch.from_numpy(g('dy'))
+    if dtype == torch.bfloat16:      # bf16 rounding changes which element is the max: re-derive
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, k, st, p)
+        yr.backward(dy)
+        y_ref, dx_ref = yr.detach().numpy(), xr.grad.numpy()
+    else:
+        y_ref, dx_ref = g('y'), g('dx')
+    xt = dev(x.numpy(), dtype).requires_grad_(True)
+    y = ops.MaxPool2dFn.apply(xt, (k, k), (st, st), (p, p))
+    y.backward(dev(dy.numpy(), dtype))
+    torch.cuda.synchronize()
+    assert np.array_equal(host(y), y_ref)
+    if dtype == torch.float32:
+        assert np.array_equal(host(xt.grad), dx_ref)
+    else:                            # overlapping windows sum two bf16 grads: one rounding
+        assert rel_l2(host(xt.grad), dx_ref) < 5e-3
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_gap_relu_add_nchw(dtype):
+    from convnets_amd import ops
+    x = dev(OPS['gap/x'], dtype).requires_grad_(True)
+    y = ops.GlobalAvgPoolFn.apply(x)
+    y.backward(dev(OPS['gap/dy']).contiguous())
+    torch.cuda.synchronize()
+    t = 1e-6 if dtype == torch.float32 else 1e-2
+    assert y.dtype == torch.float32 and rel_l2(host(y), OPS['gap/y']) < t
+    assert rel_l2(host(x.grad), OPS['gap/dx']) < t
+    g = torch.Generator().manual_seed(3)
+    for shape in [(2, 64, 5, 7), (3, 7, 3, 3), (1, 1, 1, 1)]:
+        a, b, dy = (torch.randn(shape, generator=g) for _ in range(3))
+        if dtype == torch.bfloat16:
+            a, b, dy = a.bfloat16().float(), b.bfloat16().float(), dy.bfloat16().float()
+        at, bt = dev(a.numpy(), dtype).requires_grad_(True), dev(b.numpy(), dtype).requires_grad_(True)
+        r = ops.ReLUFn.apply(at)
+        r.backward(dev(dy.numpy(), dtype))
+        assert np.array_equal(host(r), torch.relu(a).numpy())
+        assert np.array_equal(host(at.grad), (dy * (a > 0)).numpy())
+        at.grad = None
+        s = ops.AddReLUFn.apply(at, bt)
+        s.backward(dev(dy.numpy(), dtype))
+        ref = torch.relu(a + b)
+        assert rel_l2(host(s), ref.numpy()) < t
+        assert np.array_equal(host(at.grad), (dy * (host(s) > 0)).numpy())
+        xin = torch.randn(shape, generator=g)
+        out = ops.nchw_to_nhwc(xin.cuda(), dtype)
+        assert out.is_contiguous(memory_format=CL)
+        assert rel_l2(host(out), xin.numpy()) < t
+
+
+def test_errors_are_loud():
+    from convnets_amd import ops
+    from convnets_amd._lib import CnkError
+    x = torch.randn(2, 64, 8, 8, device='cuda').contiguous(memory_format=CL)
+    with pytest.raises(RuntimeError):
+        ops.ReLUFn.apply(torch.randn(4))                                   # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        ops.Conv2dFn.apply(x, torch.randn(64, 32, 3, 3, device='cuda'), None, (1, 1), (1, 1), ops.PackedWeights())
+    with pytest.raises(CnkError):                                          # kernel larger than padded input
+        ops.Conv2dFn.apply(x, torch.randn(64, 64, 11, 11, device='cuda'), None, (1, 1), (0, 0), ops.PackedWeights())
+    with pytest.raises(TypeError):
+        ops.ReLUFn.apply(x.half())
