@@ -1,0 +1,178 @@
+"""Headline benchmark: images/sec of one full training step (zero_grad + forward + CE(sum) loss +
+backward [+ gradient all-reduce] + Adam step -- the reference's loop body, src/basemodel.py:245-288)
+for ResNet-50 224x224, bs=256 per GPU, bf16 operands / fp32 accumulate, synthetic data.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events
+recorded on the launch stream around the dominant conv kernel class (cnk_prof_*), `cpu_baseline`
+is the oracle's torch-CPU restatement of the same step timed on this box's host cores (rank 0,
+N=1 only, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
+CONV_CLASSES = ['conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'conv1x1_fwd', 'conv1x1_dgrad',
+                'conv1x1_wgrad']
+MODEL_CFG = {
+    'resnet50': ('resnet', 50, (3, 224, 224), 1000, 256),
+    'resnet152': ('resnet', 152, (3, 224, 224), 1000, 128),
+    'vgg16': ('vgg', 16, (3, 224, 224), 1000, 64),
+    'alexnet': ('alexnet', 0, (3, 224, 224), 1000, 128),
+    'resnet26s': ('resnet', 26, (3, 32, 32), 10, 64),         # quick plumbing check
+}
+
+
+def prof_collect(lib, cls_bit):
+    n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    rc = lib.cnk_prof_collect(cls_bit, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+    assert rc == 0
+    return n.value, ms.value, fl.value, by.value
+
+
+def cpu_baseline(model_key, dtype_note):
+    """The oracle ('port' of the reference's torch-CPU step) timed on the host cores."""
+    from oracle import torch_ref as tr
+    family, kind, in_size, classes, _ = MODEL_CFG[model_key]
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    bs = 16
+    torch.manual_seed(21)
+    m = tr.MODELS[family](tr.RefSettings(kind, in_size, classes, batch_size=bs, dropout_rate=0.5))
+    m.init_optimizer()
+    x, y = tr.synthetic_batch(bs, in_size, classes, seed=21)
+    tr.ref_training_step(m, x, y)                      # warm-up
+    times = []
+    t_end = time.perf_counter() + 25.0
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 6):
+        t0 = time.perf_counter()
+        tr.ref_training_step(m, x, y)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(bs / med, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d fp32 training steps of %s at bs=%d on torch-CPU (oracle/torch_ref.py), median'
+                      % (len(times), model_key, bs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--model', default='resnet50', choices=sorted(MODEL_CFG))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: BASELINE config)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print the per-class kernel time table to stderr')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    import convnets_amd as ca
+    from convnets_amd import _lib, dp
+    lib = _lib.load()
+
+    family, kind, in_size, classes, def_bs = MODEL_CFG[args.model]
+    bs = args.batch or def_bs
+    torch.manual_seed(21)                                    # identical replicas
+    setting = ca.Settings(kind=kind, input_size=in_size, num_classes=classes, batch_size=bs,
+                          mixed_precision=args.dtype == 'bf16', device=dev)
+    model = ca.MODELS[family](setting).to(dev)
+    model.init_optimizer()
+    if world > 1:
+        dp.attach(model)
+    model.train()
+    g = torch.Generator(device=dev).manual_seed(21 + rank)  # each rank its own shard of synthetic data
+    x = torch.randn(bs, *in_size, generator=g, device=dev)
+    y = torch.randint(0, classes, (bs,), generator=g, device=dev)
+    batch = (x, y)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the last warm-up step doubles as the per-class breakdown that picks the dominant
+    # conv kernel class for the roofline object
+    for i in range(max(args.warmup, 1)):
+        last = i == max(args.warmup, 1) - 1
+        if last:
+            lib.cnk_prof_begin(0x1FF)
+        loss, _ = model.train_batch(batch)
+        if last:
+            torch.cuda.synchronize()
+            table = {name: prof_collect(lib, _lib.CLS[name]) for name in _lib.CLS}
+            lib.cnk_prof_end()
+    dom = max(CONV_CLASSES, key=lambda k: table[k][1])
+    if args.breakdown and rank == 0:
+        for name, (n, ms, fl, by) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+            print('  %-14s n=%4d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)' %
+                  (name, n, ms, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0), file=sys.stderr)
+
+    lib.cnk_prof_begin(_lib.CLS[dom])
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = model.train_batch(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    n_l, ms_l, fl_l, by_l = prof_collect(lib, _lib.CLS[dom])
+    lib.cnk_prof_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss)
+    assert loss_val == loss_val, 'loss is NaN'
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * bs * args.steps / elapsed
+        achieved = fl_l / ms_l / 1e9 if ms_l > 0 else 0.0          # TFLOP/s over the class's launches
+        peak = PEAK_TFLOPS[args.dtype]
+        out = {
+            'metric': 'images/sec training step, ResNet-50 224x224 bs=256/GPU' if args.model == 'resnet50'
+                      else 'images/sec training step, %s bs=%d/GPU' % (args.model, bs),
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d training step (fwd+CE(sum)+bwd+Adam), bs=%d/GPU, random-init'
+                                   % (args.model, in_size[1], in_size[2], bs),
+                       'global_batch': world * bs, 'parallelism': 'dp%d' % world,
+                       'final_loss': round(loss_val, 4)},
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None,
+                         'launches': n_l, 'avg_launch_ms': round(ms_l / n_l, 4) if n_l else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.model, args.dtype)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,220 @@
+"""GPU parity (-m gpu): residual blocks and whole models for one full training step on the HIP path
+vs (1) the reference's golden traces (tests/golden/resblocks.npz, models.npz) and (2) the oracle's
+torch-CPU restatement for the nets the reference does not have (LeNet-5, AlexNet)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+BLK = np.load(os.path.join(G, 'resblocks.npz'))
+MODELS = np.load(os.path.join(G, 'models.npz'))
+CL = torch.channels_last
+
+
+def host(t):
+    return t.detach().float().cpu().contiguous().numpy()
+
+
+@pytest.mark.parametrize('mixed', [False, True], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('name', ['bott_proj_s2', 'bott_id', 'bott_proj_s1', 'basic_proj_s2', 'basic_id'])
+def test_residual_block_golden(name, mixed):
+    import convnets_amd as ca
+    g = lambda k: BLK[f'{name}/{k}']
+    N, Ci, H, nf, exp, stride, bott = [int(v) for v in g('cfg')]
+    s = ca.Settings(kind=50, input_size=(Ci, H, H), num_classes=10, mixed_precision=mixed, dropout_rate=0)
+    net = ca.ResNet.__new__(ca.ResNet)
+    ca.MultiClassBaseModel.__init__(net, s)
+    blk = net.residual_block(ca.ResBottleneck if bott else ca.ResBlock, nf, exp, stride).cuda()
+    sd = {k[len(name) + 4:]: torch.from_numpy(BLK[k]) for k in BLK.files if k.startswith(name + '/sd/')}
+    assert list(sd.keys()) == list(blk.state_dict().keys())
+    init = {k: v for k, v in sd.items()}
+    for k in init:                      # fixtures hold running stats AFTER the step: reset to fresh
+        if k.endswith('running_mean'):
+            init[k] = torch.zeros_like(init[k])
+        elif k.endswith('running_var'):
+            init[k] = torch.ones_like(init[k])
+        elif k.endswith('num_batches_tracked'):
+            init[k] = torch.zeros_like(init[k])
+    blk.load_state_dict(init)
+    blk.train()
+    dt = s.compute_dtype
+    x = torch.from_numpy(g('x')).cuda().to(dt).contiguous(memory_format=CL).requires_grad_(True)
+    y = blk(x)
+    y.backward(torch.from_numpy(g('dy')).cuda().to(dt).contiguous(memory_format=CL))
+    torch.cuda.synchronize()
+    t, tg = (3e-5, 2e-4) if not mixed else (2e-2, 2e-1)
+    assert rel_l2(host(y), g('y')) < t
+    assert rel_l2(host(x.grad), g('dx')) < tg
+    for k, p in blk.named_parameters():
+        ref = BLK[f'{name}/grad/{k}']
+        assert rel_l2(host(p.grad), ref) < tg, k
+    for k, b in blk.named_buffers():
+        if 'running' in k:
+            assert rel_l2(host(b), sd[k].numpy()) < (1e-5 if not mixed else 1e-2), k
+
+
+MODEL_CASES = [('resnet26', 'resnet', 26, (3, 32, 32), True), ('resnet18', 'resnet', 18, (3, 32, 32), True),
+               ('vgg11', 'vgg', 11, (3, 32, 32), True), ('convnet', 'convnet', 0, (1, 28, 28), False)]
+
+
+@pytest.mark.parametrize('mixed', [False, True], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('name,family,kind,in_size,bn', MODEL_CASES)
+def test_model_one_step_golden(name, family, kind, in_size, bn, mixed):
+    """zero_grad -> forward -> CE(sum) -> backward -> Adam step on the HIP path reproduces the
+    reference's trace: logits, loss, correct count, gradient norms/samples, post-step weights,
+    BN running statistics, and the loss of the NEXT step (which pins the optimizer update)."""
+    import convnets_amd as ca
+    g = lambda k: MODELS[f'{name}/{k}']
+    bs = len(g('targets'))
+    s = ca.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs, batch_norm=bn,
+                    dropout_rate=0, mixed_precision=mixed)
+    torch.manual_seed(21)                       # same registration order => the reference's weights
+    model = ca.MODELS[family](s)
+    assert list(model.state_dict().keys()) == list(g('sd_keys'))
+    norms = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+    np.testing.assert_allclose(norms, g('init_norms'), rtol=1e-6)
+    model = model.cuda()
+    model.init_optimizer()
+    model.train()
+    x, y = torch.from_numpy(g('x')), torch.from_numpy(g('targets'))
+    with torch.no_grad():
+        model.eval()                            # eval forward must not touch running stats
+        model(x.cuda())
+        model.train()
+    out = model(x.cuda())
+    t_out = 2e-4 if not mixed else 2.5e-1   # bf16 vs fp32 is loose by nature; see the emulation test
+    assert rel_l2(host(out), g('logits')) < t_out
+    for b in model.buffers():                   # undo the extra forward's running-stat update
+        pass
+    # fresh model for the actual one-step trace (the forward above advanced the BN running stats)
+    torch.manual_seed(21)
+    model = ca.MODELS[family](s).cuda()
+    model.init_optimizer()
+    model.train()
+    loss, correct = model.train_batch((x, y))
+    torch.cuda.synchronize()
+    t_loss, t_g, t_w = (1e-4, 2e-3, 1e-4) if not mixed else (3e-2, 2.5e-1, 3e-2)
+    assert abs(float(loss) - float(g('loss'))) <= t_loss * abs(float(g('loss')))
+    if not mixed:
+        assert int(correct) == int(g('correct'))
+    gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    assert rel_l2(gn, g('grad_norms')) < t_g
+    pn = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+    assert rel_l2(pn, g('post_norms')) < t_w
+    bufs = [b for k, b in model.named_buffers() if 'running' in k]
+    if bufs:
+        bn_norms = np.array([float(b.double().norm()) for b in bufs])
+        assert rel_l2(bn_norms, g('buf_norms')) < (1e-5 if not mixed else 1e-2)
+    with torch.no_grad():
+        loss2 = model.cost_function(model(x.cuda()), y.cuda())
+    # Adam's first update is lr*g/(|g|+eps) ~ lr*sign(g): weights whose gradient is ~0 move by +-lr on
+    # rounding noise, so the next-step loss is pinned only loosely (the Adam kernel itself is checked
+    # bit-tightly against torch.optim.Adam in test_gpu_ops.py::test_flat_adam_matches_torch)
+    assert abs(float(loss2) - float(g('loss2'))) <= (5e-2 if not mixed else 2.5e-1) * abs(float(g('loss2')))
+
+
+@pytest.mark.parametrize('family,kind,in_size,bs', [('lenet5', 0, (1, 28, 28), 64), ('alexnet', 0, (3, 67, 67), 4),
+                                                     ('convnet', 0, (1, 28, 28), 64)])
+def test_small_nets_vs_oracle_fp32(family, kind, in_size, bs):
+    """BASELINE configs 1-2 (LeNet-5 plumbing, AlexNet's 11x11/5x5/3x3 stack) at fp32 vs the oracle."""
+    import convnets_amd as ca
+    from oracle import torch_ref as tr
+    bn = family != 'convnet'
+    torch.manual_seed(21)
+    ref = tr.MODELS[family](tr.RefSettings(kind, in_size, 10, batch_size=bs, batch_norm=bn, dropout_rate=0))
+    ref.init_optimizer()
+    torch.manual_seed(21)
+    s = ca.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs, batch_norm=bn,
+                    dropout_rate=0, mixed_precision=False)
+    model = ca.MODELS[family](s).cuda()
+    assert list(model.state_dict().keys()) == list(ref.state_dict().keys())
+    model.init_optimizer()
+    x, y = tr.synthetic_batch(bs, in_size, 10, seed=21)
+    for step in range(2):
+        loss, correct = model.train_batch((x, y))
+        loss_ref, correct_ref = tr.ref_training_step(ref, x, y)
+        assert abs(float(loss) - loss_ref) <= (2e-5 if step == 0 else 5e-2) * abs(loss_ref)
+        if step == 0:
+            assert int(correct) == correct_ref
+            for (k, p), q in zip(model.named_parameters(), ref.parameters()):
+                assert rel_l2(host(p.grad), q.grad.numpy()) < 5e-4, k
+
+
+def test_train_model_epoch_outputs_match_reference_loop():
+    """train_model/valid_model return (sum loss / |D|, sum correct / |D|) like basemodel.py:299-300."""
+    import convnets_amd as ca
+    from oracle import torch_ref as tr
+    torch.manual_seed(21)
+    s = ca.Settings(kind=0, input_size=(1, 28, 28), num_classes=10, batch_size=16, batch_norm=False,
+                    dropout_rate=0, mixed_precision=False)
+    model = ca.ConvNet(s).cuda()
+    torch.manual_seed(21)
+    ref = tr.RefConvNet(tr.RefSettings(0, (1, 28, 28), 10, batch_size=16, batch_norm=False, dropout_rate=0))
+    ref.init_optimizer()
+    xs, ys = tr.synthetic_batch(48, (1, 28, 28), 10, seed=3)
+
+    class Loader(list):
+        dataset = range(48)
+    loader = Loader([(xs[i:i + 16], ys[i:i + 16]) for i in range(0, 48, 16)])
+    l, a = model.train_model(loader)
+    tl = tc = 0
+    for xb, yb in loader:
+        li, ci = tr.ref_training_step(ref, xb, yb)
+        tl += li
+        tc += ci
+    assert abs(l - tl / 48) < 1e-4 * abs(tl / 48) and abs(a - tc / 48) < 1e-9
+    lv, av = model.valid_model(loader)
+    ref.eval()
+    with torch.no_grad():
+        tl = sum(float(ref.cost_function(ref(xb), yb)) for xb, yb in loader)
+    assert abs(lv - tl / 48) < 1e-4 * abs(tl / 48)
+
+
+@pytest.mark.parametrize('name,family,kind,in_size,bn', MODEL_CASES[:3])
+def test_model_bf16_vs_bf16_emulated_oracle(name, family, kind, in_size, bn):
+    """The bf16 HIP path against the oracle instrumented to round to bf16 at the same points
+    (oracle/bf16_emu.py): this is the tight whole-network check of the bf16 kernels; the fp32
+    golden comparison above can only be loose for bf16."""
+    import convnets_amd as ca
+    from oracle import torch_ref as tr
+    from oracle.bf16_emu import emulate_bf16
+    g = lambda k: MODELS[f'{name}/{k}']
+    bs = len(g('targets'))
+    torch.manual_seed(21)
+    ref = emulate_bf16(tr.MODELS[family](tr.RefSettings(kind, in_size, 10, batch_size=bs, dropout_rate=0)))
+    torch.manual_seed(21)
+    s = ca.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs, dropout_rate=0, mixed_precision=True)
+    model = ca.MODELS[family](s).cuda()
+    model.init_optimizer()
+    model.train()
+    ref.train()
+    x, y = torch.from_numpy(g('x')), torch.from_numpy(g('targets'))
+    out_ref = ref(x)
+    loss_ref = ref.cost_function(out_ref, y)
+    loss_ref.backward()
+    model.optimizer.zero_grad()
+    out = model(x.cuda())
+    loss = model.cost_function(out, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    e_logits = rel_l2(host(out), out_ref.detach().numpy())
+    num = den = 0.0
+    worst = (0.0, '')
+    for (k, p), q in zip(model.named_parameters(), ref.parameters()):
+        d = float((p.grad.detach().cpu().double() - q.grad.double()).pow(2).sum())
+        n = float(q.grad.double().pow(2).sum())
+        num += d
+        den += n
+        if n > 0 and (d / n) ** 0.5 > worst[0]:
+            worst = ((d / n) ** 0.5, k)
+    e_grad = (num / den) ** 0.5
+    print('bf16 vs emulation %s: logits %.3e loss %.3e grads %.3e worst %s' %
+          (name, e_logits, abs(float(loss) - float(loss_ref)) / abs(float(loss_ref)), e_grad, worst))
+    assert e_logits < 2e-2
+    assert abs(float(loss) - float(loss_ref)) < 1e-2 * abs(float(loss_ref))
+    assert e_grad < 6e-2
