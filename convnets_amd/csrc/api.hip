@@ -24,11 +24,17 @@ size_t colsum_workspace(int64_t M, int C);
 int colsum(const void* a, float* out, int64_t M, int C, int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int pack_direct(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
 int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, const signed char* kh, const signed char* kw, int transpose, hipStream_t s);
+bool smallc_supported(const cnk_conv_desc* d);
+size_t smallc_packed_bytes(const cnk_conv_desc* d);
+int smallc_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
+int smallc_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, hipStream_t s);
+size_t smallc_wgrad_workspace(const cnk_conv_desc* d);
+int smallc_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t bn_workspace_bytes(int64_t M, int C);
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* rm, float* rv, float* sm, float* si, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
 int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
-int maxpool_dispatch(bool bwd, const void* a, const void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
+int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
 int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
 int nchw_to_nhwc_dispatch(const float* x, void* y, int N, int C, int H, int W, int dtype, hipStream_t s);
@@ -126,14 +132,17 @@ int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo) {
 size_t cnk_conv2d_packed_bytes(const cnk_conv_desc* d, int pass) {
     size_t n = (size_t)d->Cout * d->Cin * d->kh * d->kw;
     if (pass != CNK_PASS_FWD && pass != CNK_PASS_DGRAD) return 0;
-    return igemm_supported(d, pass) ? n * esize(d->dtype) : n * sizeof(float);
+    if (igemm_supported(d, pass)) return n * esize(d->dtype);
+    if (pass == CNK_PASS_FWD && smallc_supported(d)) return smallc_packed_bytes(d);
+    return n * sizeof(float);
 }
 
 size_t cnk_conv2d_workspace_bytes(const cnk_conv_desc* d, int pass) {
     if (pass != CNK_PASS_WGRAD) return 0;
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
-    size_t a = wgrad_mfma_supported(d) ? wgrad_mfma_workspace(d) : direct_wgrad_workspace(d);
+    size_t a = wgrad_mfma_supported(d) ? wgrad_mfma_workspace(d)
+               : smallc_supported(d) ? smallc_wgrad_workspace(d) : direct_wgrad_workspace(d);
     a = (a + 255) & ~(size_t)255;
     return a + colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout);
 }
@@ -147,6 +156,8 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
             signed char kh[32], kw[32];
             for (int t = 0; t < d->kh * d->kw; ++t) { kh[t] = (signed char)(t / d->kw); kw[t] = (signed char)(t % d->kw); }
             if (int rc = pack_taps(d, w, w_fwd, d->kh * d->kw, kh, kw, 0, S(stream))) return rc;
+        } else if (smallc_supported(d)) {
+            if (int rc = smallc_pack(d, w, w_fwd, S(stream))) return rc;
         } else {
             if (int rc = pack_direct(d, w, w_fwd, S(stream))) return rc;
             direct_done = true;
@@ -178,6 +189,7 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
     if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd(d, x, w_fwd, bias, y, S(stream));
+    if (smallc_supported(d)) return smallc_fwd(d, x, w_fwd, bias, y, S(stream));
     return direct_fwd(d, x, w_fwd, bias, y, S(stream));
 }
 
@@ -205,6 +217,9 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
     if (wgrad_mfma_supported(d)) {
         a = wgrad_mfma_workspace(d);
         rc = wgrad_mfma(d, dy, x, dw, accumulate, workspace, a, S(stream));
+    } else if (smallc_supported(d)) {
+        a = smallc_wgrad_workspace(d);
+        rc = smallc_wgrad(d, dy, x, dw, accumulate, workspace, a, S(stream));
     } else {
         a = direct_wgrad_workspace(d);
         rc = direct_wgrad(d, dy, x, dw, accumulate, workspace, a, S(stream));
@@ -245,15 +260,16 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma,
     return bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, M, C, relu, dtype, (float*)workspace, S(stream));
 }
 
-int cnk_maxpool2d_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+int cnk_maxpool2d_fwd(const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
     CNK_CHECK_ARG(x && y, "cnk_maxpool2d_fwd: null pointer");
     CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && H + 2 * ph >= kh && W + 2 * pw >= kw, "cnk_maxpool2d_fwd: bad geometry");
-    return maxpool_dispatch(false, x, nullptr, y, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+    CNK_CHECK_ARG(kh * kw <= 255, "cnk_maxpool2d_fwd: window too large for uint8 positions");
+    return maxpool_dispatch(false, x, argmax, y, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
 }
-int cnk_maxpool2d_bwd(const void* dy, const void* x, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
-    CNK_CHECK_ARG(dy && x && dx, "cnk_maxpool2d_bwd: null pointer");
+int cnk_maxpool2d_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+    CNK_CHECK_ARG(dy && argmax && dx, "cnk_maxpool2d_bwd: null pointer");
     CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && H + 2 * ph >= kh && W + 2 * pw >= kw, "cnk_maxpool2d_bwd: bad geometry");
-    return maxpool_dispatch(true, dy, x, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+    return maxpool_dispatch(true, dy, (void*)argmax, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
 }
 
 int cnk_relu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {

@@ -53,7 +53,7 @@ SliceGeom make_geom(int64_t M, int C, int vec) {
     g.rpb = 256 / g.cpb;
     g.colgroups = ceil_div(g.cols, g.cpb);
     int64_t sr = (int64_t)g.rpb * 32;
-    if (ceil_div64(M, sr) > 2048) sr = ceil_div64(ceil_div64(M, 2048), g.rpb) * g.rpb;
+    if (ceil_div64(M, sr) > 1024) sr = ceil_div64(ceil_div64(M, 1024), g.rpb) * g.rpb;
     g.slice_rows = (int)sr;
     g.slices = (int)ceil_div64(M, sr);
     return g;
@@ -99,45 +99,64 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x,
         sh[2][tid * VEC + i] = m2 > 0.f ? m2 : 0.f;
     }
     __syncthreads();
+    int span = 1;
+    while (span < g.rpb) span <<= 1;
+    for (int st = span >> 1; st >= 1; st >>= 1) {
+        if (trow < st && trow + st < g.rpb && vcol < g.cols) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                int a = tid * VEC + i, b = (tid + st * g.cpb) * VEC + i;
+                float na = sh[0][a], ma = sh[1][a], qa = sh[2][a];
+                float nb = sh[0][b], mb = sh[1][b], qb = sh[2][b];
+                if (nb > 0.f) {
+                    float nt = na + nb, d = mb - ma, f = nb / nt;
+                    ma += d * f;
+                    qa += qb + d * d * (na * f);
+                    na = nt;
+                }
+                sh[0][a] = na; sh[1][a] = ma; sh[2][a] = qa;
+            }
+        }
+        __syncthreads();
+    }
     if (trow == 0 && vcol < g.cols) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            float na = sh[0][tid * VEC + i], ma = sh[1][tid * VEC + i], qa = sh[2][tid * VEC + i];
-            for (int r = 1; r < g.rpb; ++r) {
-                int o = (r * g.cpb + tcol) * VEC + i;
-                float nb = sh[0][o], mb = sh[1][o], qb = sh[2][o];
-                if (nb > 0.f) {
-                    float nt = na + nb, d = mb - ma;
-                    ma += d * (nb / nt);
-                    qa += qb + d * d * (na * nb / nt);
-                    na = nt;
-                }
-            }
             int c = vcol * VEC + i;
             float* o = partial + ((size_t)blockIdx.x * C + c) * 3;
-            o[0] = na; o[1] = ma; o[2] = qa;
+            o[0] = sh[0][tid * VEC + i]; o[1] = sh[1][tid * VEC + i]; o[2] = sh[2][tid * VEC + i];
         }
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int slices, int C, int64_t M,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, float* save_mean,
-                                   float* save_invstd, float* scale, float* shift, float eps,
-                                   float momentum) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// Chan merge of (n, mean, M2) pairs
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    if (nb > 0.f) {
+        float nt = na + nb, d = mb - ma, f = nb / nt;
+        ma += d * f;
+        qa += qb + d * d * (na * f);
+        na = nt;
+    }
+}
+
+// One wave per channel: lanes stride over the slices, then a 6-step butterfly merge.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, int slices, int C, int64_t M, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float* save_mean,
+    float* save_invstd, float* scale, float* shift, float eps, float momentum) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     float na = 0.f, ma = 0.f, qa = 0.f;
-    for (int s = 0; s < slices; ++s) {
+    for (int s = lane; s < slices; s += 64) {
         const float* o = partial + ((size_t)s * C + c) * 3;
-        float nb = o[0], mb = o[1], qb = o[2];
-        if (nb > 0.f) {
-            float nt = na + nb, d = mb - ma;
-            ma += d * (nb / nt);
-            qa += qb + d * d * (na * nb / nt);
-            na = nt;
-        }
+        chan_merge(na, ma, qa, o[0], o[1], o[2]);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float nb = __shfl_xor(na, o, 64), mb = __shfl_xor(ma, o, 64), qb = __shfl_xor(qa, o, 64);
+        chan_merge(na, ma, qa, nb, mb, qb);
+    }
+    if (lane != 0) return;
     float var = qa / (float)M;
     float invstd = rsqrtf(var + eps);
     // one Newton step: rsqrtf is ~1 ulp, this keeps fp32 parity tight
@@ -163,27 +182,39 @@ __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const
     shift[c] = beta[c] - rmean[c] * sc;
 }
 
+// y = act(x*scale + shift [+ res]).  Same (column-thread, row-thread) geometry as the statistics
+// pass: a thread owns VEC channels for all its rows, so the per-channel coefficients live in
+// registers and the only memory instructions in the loop are the 16-byte payload loads/stores.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
                                                        const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift,
-                                                       int64_t nvec, int C, int relu) {
-    const int cols = C / VEC;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int c0 = (int)(i % cols) * VEC;
+                                                       const float* __restrict__ shift, int64_t M,
+                                                       int C, int relu, SliceGeom g) {
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    if (trow >= g.rpb || vcol >= g.cols) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        sc[k] = scale[vcol * VEC + k];
+        sh[k] = shift[vcol * VEC + k];
+    }
+    const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
+    for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
+        const int64_t off = m * C + (int64_t)vcol * VEC;
         VLoad<T, VEC> v, r;
-        v.load(x + i * VEC);
-        if (res) r.load(res + i * VEC);
+        v.load(x + off);
+        if (res) r.load(res + off);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float o = v.f[k] * scale[c0 + k] + shift[c0 + k];
+            float o = v.f[k] * sc[k] + sh[k];
             if (res) o += r.f[k];
             if (relu) o = o > 0.f ? o : 0.f;
             v.f[k] = o;
         }
-        v.store(y + i * VEC);
+        v.store(y + off);
     }
 }
 
@@ -256,34 +287,44 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         sh[1][tid * VEC + i] = s2[i];
     }
     __syncthreads();
+    int span = 1;
+    while (span < g.rpb) span <<= 1;
+    for (int st = span >> 1; st >= 1; st >>= 1) {
+        if (trow < st && trow + st < g.rpb && vcol < g.cols) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                int a = tid * VEC + i, b = (tid + st * g.cpb) * VEC + i;
+                sh[0][a] += sh[0][b];
+                sh[1][a] += sh[1][b];
+            }
+        }
+        __syncthreads();
+    }
     if (trow == 0 && vcol < g.cols) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            float a = sh[0][tid * VEC + i], b = sh[1][tid * VEC + i];
-            for (int r = 1; r < g.rpb; ++r) {
-                int o = (r * g.cpb + tcol) * VEC + i;
-                a += sh[0][o];
-                b += sh[1][o];
-            }
             int c = vcol * VEC + i;
             float* o = partial + ((size_t)blockIdx.x * C + c) * 2;
-            o[0] = a; o[1] = b;
+            o[0] = sh[0][tid * VEC + i]; o[1] = sh[1][tid * VEC + i];
         }
     }
 }
 
-__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int slices, int C, int64_t M,
-                                    const float* __restrict__ gamma,
-                                    const float* __restrict__ invstd, float* dgamma, float* dbeta,
-                                    float* coefA, float* coefB1, float* coefB2, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(
+    const float* __restrict__ partial, int slices, int C, int64_t M, const float* __restrict__ gamma,
+    const float* __restrict__ invstd, float* dgamma, float* dbeta, float* coefA, float* coefB1,
+    float* coefB2, int accumulate) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     float a = 0.f, b = 0.f;
-    for (int s = 0; s < slices; ++s) {
+    for (int s = lane; s < slices; s += 64) {
         const float* o = partial + ((size_t)s * C + c) * 2;
         a += o[0];
         b += o[1];
     }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane != 0) return;
     dbeta[c] = accumulate ? dbeta[c] + a : a;
     dgamma[c] = accumulate ? dgamma[c] + b : b;
     coefA[c] = gamma[c] * invstd[c];
@@ -296,26 +337,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ dx,
     T* __restrict__ dres, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ coefA, const float* __restrict__ coefB1,
-    const float* __restrict__ coefB2, int64_t nvec, int C, int relu) {
-    const int cols = C / VEC;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int c0 = (int)(i % cols) * VEC;
+    const float* __restrict__ coefB2, int64_t M, int C, int relu, SliceGeom g) {
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    if (trow >= g.rpb || vcol >= g.cols) return;
+    // dx = a*(d - b1 - (x-mu)*(is*b2)); the centred form keeps fp32 accuracy when |mu| >> sigma
+    float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        int c = vcol * VEC + k;
+        ka[k] = coefA[c];
+        kb1[k] = coefB1[c];
+        kmu[k] = mean[c];
+        kis[k] = invstd[c] * coefB2[c];
+    }
+    const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
+    for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
+        const int64_t off = m * C + (int64_t)vcol * VEC;
         VLoad<T, VEC> vd, vx, vy, vo;
-        vd.load(dy + i * VEC);
-        vx.load(x + i * VEC);
-        if (relu) vy.load(y + i * VEC);
+        vd.load(dy + off);
+        vx.load(x + off);
+        if (relu) vy.load(y + off);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            int c = c0 + k;
             float d = vd.f[k];
             if (relu && !(vy.f[k] > 0.f)) d = 0.f;
             vd.f[k] = d;
-            float xh = (vx.f[k] - mean[c]) * invstd[c];
-            vo.f[k] = coefA[c] * (d - coefB1[c] - xh * coefB2[c]);
+            vo.f[k] = ka[k] * (d - kb1[k] - (vx.f[k] - kmu[k]) * kis[k]);
         }
-        vo.store(dx + i * VEC);
-        if (dres) vd.store(dres + i * VEC);
+        vo.store(dx + off);
+        if (dres) vd.store(dres + off);
     }
 }
 
@@ -351,12 +403,11 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
                        (const T*)x, partial, M, C, g);
     CNK_CHECK_LAUNCH("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, g.slices, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, g.slices, C,
                        M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
     CNK_CHECK_LAUNCH("bn_finalize");
-    int64_t nvec = M * C / VEC;
-    hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), dim3(grid_for(nvec)), dim3(256), 0, s, (const T*)x,
-                       (const T*)res, (T*)y, scale, shift, nvec, C, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
+                       (const T*)x, (const T*)res, (T*)y, scale, shift, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_apply");
     return 0;
 }
@@ -407,13 +458,12 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* g
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
                        (const T*)dy, (const T*)x, (const T*)y, sm, si, partial, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, partial, g.slices,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, g.slices,
                        C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
     CNK_CHECK_LAUNCH("bn_bwd_final");
-    int64_t nvec = M * C / VEC;
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC>), dim3(grid_for(nvec)), dim3(256), 0, s,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
                        (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, sm, si, coefA, coefB1,
-                       coefB2, nvec, C, relu);
+                       coefB2, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }

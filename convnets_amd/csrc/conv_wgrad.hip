@@ -204,30 +204,45 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
 }
 
 // dw[co][ci][t] (+)= sum_s slab[s*slab_stride + co*s_co + t*s_t + ci*s_ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                    int splits, size_t slab_stride, int Cout, int Cin, int ntaps,
-                                    size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci,
-                                    int accumulate) {
+// Four lanes per output element, lane q summing slabs q, q+4, ... (independent loads in flight),
+// combined with two xor-shuffles: fixed summation order => bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(
+    const float* __restrict__ slab, float* __restrict__ dw, int splits, size_t slab_stride, int Cout,
+    int Cin, int ntaps, size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci, int accumulate) {
     size_t total = (size_t)Cout * Cin * ntaps;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
+    const int q = threadIdx.x & 3;
+    const size_t total_r = (total + 63) / 64 * 64;        // whole waves stay converged for the shuffles
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < total_r;
+         i += ((size_t)gridDim.x * blockDim.x) >> 2) {
+        const bool live = i < total;
+        size_t ii = live ? i : 0;
         int co, t, ci;
         if (inner_is_ci) {            // slab order [co][t][ci]
-            ci = (int)(i % Cin);
-            size_t r = i / Cin;
+            ci = (int)(ii % Cin);
+            size_t r = ii / Cin;
             t = (int)(r % ntaps);
             co = (int)(r / ntaps);
         } else {                      // slab order [t][ci][co]
-            co = (int)(i % Cout);
-            size_t r = i / Cout;
+            co = (int)(ii % Cout);
+            size_t r = ii / Cout;
             ci = (int)(r % Cin);
             t = (int)(r / Cin);
         }
         const float* sp = slab + co * s_co + t * s_t + ci * s_ci;
-        float acc = 0.f;
-        for (int s = 0; s < splits; ++s) acc += sp[(size_t)s * slab_stride];
-        size_t o = ((size_t)co * Cin + ci) * ntaps + t;
-        dw[o] = accumulate ? dw[o] + acc : acc;
+        float a0 = 0.f, a1 = 0.f;
+        int s = q;
+        for (; s + 4 < splits; s += 8) {
+            a0 += sp[(size_t)s * slab_stride];
+            a1 += sp[(size_t)(s + 4) * slab_stride];
+        }
+        if (s < splits) a0 += sp[(size_t)s * slab_stride];
+        float acc = a0 + a1;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (q == 0 && live) {
+            size_t o = ((size_t)co * Cin + ci) * ntaps + t;
+            dw[o] = accumulate ? dw[o] + acc : acc;
+        }
     }
 }
 
@@ -246,8 +261,8 @@ int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_st
                         int Cin, int ntaps, size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci,
                         int accumulate, hipStream_t s) {
     size_t total = (size_t)Cout * Cin * ntaps;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
+    int grid = (int)((total * 4 + 255) / 256);
+    if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, dw, splits,
                        slab_stride, Cout, Cin, ntaps, s_co, s_t, s_ci, inner_is_ci, accumulate);
     CNK_CHECK_LAUNCH("wgrad_reduce");

@@ -35,6 +35,7 @@ struct PoolParams {
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          unsigned char* __restrict__ idx,
                                                           PoolParams p, int64_t total) {
     const int cols = p.C / VEC;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -43,8 +44,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         uint32_t t = fd_div(pix, p.fd_wo), wo = pix - t * p.Wo;
         uint32_t n = fd_div(t, p.fd_ho), ho = t - n * p.Ho;
         float best[VEC];
+        unsigned char bi[VEC];
+        bool any = false;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) best[k] = -INFINITY;
+        for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = 0; }
         for (int r = 0; r < p.kh; ++r) {
             int h = (int)ho * p.sh - p.ph + r;
             if ((unsigned)h >= (unsigned)p.H) continue;
@@ -53,24 +56,32 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 if ((unsigned)w >= (unsigned)p.W) continue;
                 VL<T, VEC> v;
                 v.load(x + ((size_t)(n * p.H + h) * p.W + w) * p.C + vc * VEC);
+                unsigned char pos = (unsigned char)(r * p.kw + q);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    if (v.f[k] > best[k] || v.f[k] != v.f[k]) best[k] = v.f[k];
+                    if (!any || v.f[k] > best[k] || v.f[k] != v.f[k]) { best[k] = v.f[k]; bi[k] = pos; }
+                any = true;
             }
         }
         VL<T, VEC> o;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o.f[k] = best[k];
         o.store(y + (size_t)i * VEC);
+        if (idx) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) idx[(size_t)i * VEC + k] = bi[k];
+        }
     }
 }
 
-// Gather form of the backward: every input element sums dy over the windows whose arg-max
-// (first maximum in row-major window order, torch's rule) it is.  No atomics, deterministic.
+// Gather form of the backward from the saved window positions (first maximum in row-major window
+// order, torch's rule): every input element sums dy over the <= ceil(k/s)^2 windows that cover it
+// and whose saved arg-max is this element.  No atomics, deterministic.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy,
-                                                          const T* __restrict__ x, T* __restrict__ dx,
-                                                          PoolParams p, int64_t total) {
+                                                          const unsigned char* __restrict__ idx,
+                                                          T* __restrict__ dx, PoolParams p,
+                                                          int64_t total) {
     const int cols = p.C / VEC;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -90,31 +101,23 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
         for (int ho = ho_lo; ho <= ho_hi; ++ho)
             for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                float best[VEC];
-                bool mine[VEC], any[VEC];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; mine[k] = false; any[k] = false; }
-                for (int r = 0; r < p.kh; ++r) {
-                    int hh = ho * p.sh - p.ph + r;
-                    if ((unsigned)hh >= (unsigned)p.H) continue;
-                    for (int q = 0; q < p.kw; ++q) {
-                        int ww = wo * p.sw - p.pw + q;
-                        if ((unsigned)ww >= (unsigned)p.W) continue;
-                        VL<T, VEC> v;
-                        v.load(x + ((size_t)(n * p.H + hh) * p.W + ww) * p.C + vc * VEC);
-                        bool me = hh == (int)h && ww == (int)w;
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k)
-                            if (!any[k] || v.f[k] > best[k] || v.f[k] != v.f[k]) {
-                                best[k] = v.f[k]; mine[k] = me; any[k] = true;
-                            }
-                    }
-                }
+                const int pos = ((int)h - (ho * p.sh - p.ph)) * p.kw + ((int)w - (wo * p.sw - p.pw));
+                const size_t o = ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.C + vc * VEC;
                 VL<T, VEC> g;
-                g.load(dy + ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.C + vc * VEC);
+                g.load(dy + o);
+                unsigned char b[VEC];
+                if constexpr (VEC == 8) {
+                    u32x2 raw = *(const u32x2*)(idx + o);
+                    __builtin_memcpy(b, &raw, 8);
+                } else if constexpr (VEC == 4) {
+                    unsigned int raw = *(const unsigned int*)(idx + o);
+                    __builtin_memcpy(b, &raw, 4);
+                } else {
+                    b[0] = idx[o];
+                }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    if (mine[k]) acc[k] += g.f[k];
+                    if ((int)b[k] == pos) acc[k] += g.f[k];
             }
         VL<T, VEC> o;
 #pragma unroll
@@ -230,25 +233,25 @@ PoolParams make_pool(int N, int H, int W, int C, int kh, int kw, int sh, int sw,
 }  // namespace
 
 template <typename T, int VEC>
-static int maxpool_t(bool bwd, const void* a, const void* b, void* o, int N, int H, int W, int C,
+static int maxpool_t(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C,
                      int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t s) {
     PoolParams p = make_pool(N, H, W, C, kh, kw, sh, sw, ph, pw, VEC);
     if (!bwd) {
         int64_t total = (int64_t)N * p.Ho * p.Wo * (C / VEC);
         CNK_CHECK_ARG(total < (1ll << 31), "maxpool: tensor too large");
         hipLaunchKernelGGL((maxpool_fwd_kernel<T, VEC>), dim3(grid_for(total)), dim3(256), 0, s,
-                           (const T*)a, (T*)o, p, total);
+                           (const T*)a, (T*)o, (unsigned char*)b, p, total);
     } else {
         int64_t total = (int64_t)N * H * W * (C / VEC);
         CNK_CHECK_ARG(total < (1ll << 31), "maxpool: tensor too large");
         hipLaunchKernelGGL((maxpool_bwd_kernel<T, VEC>), dim3(grid_for(total)), dim3(256), 0, s,
-                           (const T*)a, (const T*)b, (T*)o, p, total);
+                           (const T*)a, (const unsigned char*)b, (T*)o, p, total);
     }
     CNK_CHECK_LAUNCH("maxpool");
     return 0;
 }
 
-int maxpool_dispatch(bool bwd, const void* a, const void* b, void* o, int N, int H, int W, int C,
+int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C,
                      int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s) {
     if (dtype == CNK_BF16) {
         if (C % 8 == 0) return maxpool_t<bf16, 8>(bwd, a, b, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);

@@ -227,22 +227,23 @@ class MaxPool2dFn(torch.autograd.Function):
         Ho = (H + 2 * padding[0] - ksize[0]) // stride[0] + 1
         Wo = (W + 2 * padding[1] - ksize[1]) // stride[1] + 1
         y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=CL)
-        check(lib.cnk_maxpool2d_fwd(_p(x), _p(y), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
-                                    padding[0], padding[1], _dtype_code(x), _stream()))
-        ctx.save_for_backward(x)
-        ctx.geom = (ksize, stride, padding)
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device) if x.requires_grad else None
+        check(lib.cnk_maxpool2d_fwd(_p(x), _p(y), _p(idx), N, H, W, C, ksize[0], ksize[1], stride[0],
+                                    stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
+        ctx.save_for_backward(idx)
+        ctx.geom = (ksize, stride, padding, tuple(x.shape), x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        (x,) = ctx.saved_tensors
-        ksize, stride, padding = ctx.geom
+        (idx,) = ctx.saved_tensors
+        ksize, stride, padding, shape, dt = ctx.geom
         dy = _nhwc(dy)
-        N, C, H, W = x.shape
-        dx = torch.empty_like(x, memory_format=CL)
-        check(lib.cnk_maxpool2d_bwd(_p(dy), _p(x), _p(dx), N, H, W, C, ksize[0], ksize[1], stride[0],
-                                    stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
+        N, C, H, W = shape
+        dx = torch.empty(shape, dtype=dt, device=dy.device, memory_format=CL)
+        check(lib.cnk_maxpool2d_bwd(_p(dy), _p(idx), _p(dx), N, H, W, C, ksize[0], ksize[1], stride[0],
+                                    stride[1], padding[0], padding[1], _dtype_code(dy), _stream()))
         return dx, None, None, None
 
 

@@ -105,14 +105,15 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma,
                int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.MaxPool2d (basemodel.py:1017-1024): floor mode, implicit -inf padding, dilation 1.
- * The backward re-derives the arg-max (first maximum in row-major window order, as torch)
- * from x instead of storing indices. */
-int cnk_maxpool2d_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
-                      int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw,
-                      int dtype, void* stream);
-int cnk_maxpool2d_bwd(const void* dy, const void* x, void* dx, int32_t N, int32_t H, int32_t W,
+ * The forward optionally saves, per output element, the window-relative position r*kw+q (uint8)
+ * of the arg-max -- the first maximum in row-major window order, as torch -- and the backward
+ * routes the gradient from it (argmax[N][Ho][Wo][C]; kh*kw <= 255). */
+int cnk_maxpool2d_fwd(const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W,
                       int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph,
                       int32_t pw, int dtype, void* stream);
+int cnk_maxpool2d_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N, int32_t H,
+                      int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                      int32_t ph, int32_t pw, int dtype, void* stream);
 
 /* nn.ReLU (basemodel.py:1012,1065) and the block-level  output += identity; F.relu(output)
  * (resnet.py:151-154,191-194) as stand-alone ops for unfused use. */

@@ -196,7 +196,7 @@ def test_conv_block_golden(name, dtype):
         r = lambda v: v.bfloat16().float()
         tn = lambda k_: torch.from_numpy(g(k_))
         xe = r(tn('x'))
-        we = r(tn('w')) if Ci % 64 == 0 else tn('w')      # the direct path keeps fp32 weights
+        we = r(tn('w'))          # implicit-GEMM and small-C paths both take bf16 weight operands
         c = r(F.conv2d(xe, we, stride=st, padding=p)).requires_grad_(True)
         ge, be = tn('gamma').clone().requires_grad_(True), tn('beta').clone().requires_grad_(True)
         z = F.batch_norm(c, None, None, ge, be, True, 0.1, 1e-5)
@@ -204,7 +204,7 @@ def test_conv_block_golden(name, dtype):
         ye.backward(r(tn('dy')))        # mask from the rounded output, like the kernel
         dc = r(c.grad)
         dwe = torch.nn.grad.conv2d_weight(xe, we.shape, dc, stride=st, padding=p)
-        assert rel_l2(host(y), ye.detach().numpy()) < 4e-3   # direct path keeps fp32 weights
+        assert rel_l2(host(y), ye.detach().numpy()) < 4e-3
         assert rel_l2(host(blk[0].weight.grad), dwe.numpy()) < 4e-3
         assert rel_l2(host(blk[1].weight.grad), ge.grad.numpy()) < 4e-3
         if name != 'blkstem':
