@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     constexpr int NJ = BN / 64;                      // 32-wide MFMA blocks per wave along n
     constexpr int B_LOADS = BN / 32;                 // 16-B chunks per thread for the B tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                        // [2][128][128 B]
-    unsigned char* Bs = smem + 2 * BM * 128;         // [2][BN][128 B]
-    int* row_dst = (int*)(smem + 2 * BM * 128 + 2 * BN * 128);   // dst pixel per tile row (-1: none)
+    int* row_dst = (int*)smem;                       // [128] dst pixel per tile row (-1: none)
+    unsigned char* As = smem + BM * sizeof(int);     // [2][128][128 B]
+    unsigned char* Bs = As + 2 * BM * 128;           // [2][BN][128 B]
 
     // XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
     // run of tiles so neighbours (same A rows, other n tile; adjacent pixels) share L2 lines.
@@ -187,31 +187,60 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) Mma32<T>::run(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < NJ; ++j) Mma32<T>::run(acc[i][j], fb[j], fa[i]);   // C^T block
         }
         if (ks + 1 < nk) store_step(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: acc block (i,j), reg r -> row (r&3) + 8*(r>>2) + 4*lh, col l31
-    T* dst = (T*)p.dst;
+    // Epilogue.  The MFMA computed the TRANSPOSED block (weights as the row operand), so lane
+    // (l31, lh) holds pixel row l31 and, in registers 4g..4g+3, the four consecutive output
+    // channels 8g + 4*lh + {0..3}: one 8-byte (bf16) / 16-byte (fp32) LDS store per group.  The
+    // tile is then written to HBM as whole rows, 16 bytes per lane, coalesced.
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CS = BN * ES + 16;                 // staged row stride
+    unsigned char* Cs = smem + BM * sizeof(int);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        int col = tile_n * BN + wn * (BN / 2) + j * 32 + l31;
-        float bv = p.bias ? p.bias[col] : 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                int pix = row_dst[row];
-                if (pix >= 0) dst[(size_t)pix * p.Nout + col] = from_f32<T>(acc[i][j][r] + bv);
+            for (int gq = 0; gq < 4; ++gq) {
+                const int row = wm * 64 + i * 32 + l31;
+                const int col = wn * (BN / 2) + j * 32 + 8 * gq + 4 * lh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.bias[tile_n * BN + col + e];
+                }
+                if constexpr (ES == 2) {
+                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *(bf16x4*)(Cs + row * CS + col * 2) = o;
+                } else {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(Cs + row * CS + col * 4) = o;
+                }
             }
+    __syncthreads();
+    constexpr int CPR = BN * ES / 16;                // 16-B chunks per row
+    constexpr int RPP = 256 / CPR;                   // rows per pass
+    unsigned char* dst = (unsigned char*)p.dst;
+    const int crow = tid / CPR, cc = tid - crow * CPR;
+#pragma unroll
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+        const int row = ps * RPP + crow;
+        const int pix = row_dst[row];
+        if (pix >= 0)
+            *(u32x4*)(dst + ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16) =
+                *(const u32x4*)(Cs + row * CS + cc * 16);
     }
 }
 
 template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
-    size_t lds = 2 * BM * 128 + 2 * BN * 128 + BM * sizeof(int);
+    size_t pipe = 2 * BM * 128 + 2 * BN * 128, epi = (size_t)BM * (BN * sizeof(T) + 16);
+    size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
     hipLaunchKernelGGL((igemm_gather_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;

@@ -1,0 +1,137 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/cnk.h declares (no compute
+calls without a GPU), host-side planning entry points are consistent, and the Python mirror of the
+reference's factory behaves like the reference's (names, kwargs, shape tracker, state_dict keys,
+error behaviour).  The product path must fail LOUDLY without a GPU -- never fall back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODELS = np.load(os.path.join(ROOT, 'tests', 'golden', 'models.npz'))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'cnk.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(cnk_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from convnets_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), 'libcnk.so does not export %s' % s
+    assert sorted(_lib.SIGNATURES) == syms, 'ctypes table and header disagree'
+    assert lib.cnk_version() >= 100
+
+
+def test_host_side_planning_queries_run_without_gpu():
+    from convnets_amd import _lib
+    lib = _lib.load()
+    D = _lib.ConvDesc
+    # (N,H,W,Cin,Cout,kh,kw,sh,sw,ph,pw,dtype)
+    d = D(256, 56, 56, 64, 64, 3, 3, 1, 1, 1, 1, _lib.CNK_BF16)
+    Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
+    assert lib.cnk_conv2d_out_hw(ctypes.byref(d), ctypes.byref(Ho), ctypes.byref(Wo)) == 0
+    assert (Ho.value, Wo.value) == (56, 56)
+    n = 64 * 64 * 9
+    assert lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_FWD) == n * 2      # bf16 image
+    assert lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_DGRAD) == n * 2
+    ws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), _lib.PASS_WGRAD)
+    assert ws >= n * 4 and ws % 4 == 0                                              # >= one fp32 slab
+    stem = D(256, 224, 224, 3, 64, 7, 7, 2, 2, 3, 3, _lib.CNK_BF16)
+    assert lib.cnk_conv2d_out_hw(ctypes.byref(stem), ctypes.byref(Ho), ctypes.byref(Wo)) == 0
+    assert (Ho.value, Wo.value) == (112, 112)
+    assert lib.cnk_conv2d_packed_bytes(ctypes.byref(stem), _lib.PASS_FWD) == 64 * 160 * 2   # K 147 -> 160
+    assert lib.cnk_bn_workspace_bytes(256 * 56 * 56, 64) > 0
+    # argument errors come back as codes + text, never exit/abort
+    bad = D(1, 4, 4, 8, 8, 9, 9, 1, 1, 0, 0, _lib.CNK_F32)
+    rc = lib.cnk_conv2d_fwd(ctypes.byref(bad), ctypes.c_void_p(16), ctypes.c_void_p(16), None,
+                            ctypes.c_void_p(16), None, 0, None)
+    assert rc != 0 and b'kernel larger' in lib.cnk_last_error()
+    with pytest.raises(_lib.CnkError):
+        _lib.check(rc)
+
+
+def test_ops_refuse_cpu_tensors_no_fallback():
+    from convnets_amd import ops
+    import convnets_amd as ca
+    x = torch.randn(2, 64, 8, 8)
+    for fn in (lambda: ops.ReLUFn.apply(x), lambda: ops.GlobalAvgPoolFn.apply(x),
+               lambda: ops.MaxPool2dFn.apply(x, (2, 2), (2, 2), (0, 0)),
+               lambda: ops.nchw_to_nhwc(x, torch.bfloat16),
+               lambda: ops.Conv2dFn.apply(x, torch.randn(64, 64, 3, 3), None, (1, 1), (1, 1), ops.PackedWeights())):
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            fn()
+    m = ca.ConvNet(ca.Settings(kind=0, input_size=(1, 28, 28), num_classes=10, batch_norm=False, device='cpu'))
+    with pytest.raises(RuntimeError):
+        m(torch.randn(2, 1, 28, 28))
+    with pytest.raises(RuntimeError, match='HIP path only'):
+        m.init_optimizer()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'convnets_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            assert 'oracle' not in re.sub(r'""".*?"""', '', open(os.path.join(pkg, f)).read(), flags=re.S), f
+
+
+def test_factory_returns_stock_subclasses_and_tracks_shapes():
+    import convnets_amd as ca
+    s = ca.Settings(kind=0, input_size=(3, 224, 224), num_classes=10, device='cpu')
+    net = ca.MultiClassBaseModel(s)
+    blk = net.conv2d_block(num_filters=64, kernel_size=7, stride=2, padding=3)
+    assert isinstance(blk, nn.Sequential) and [type(m).__name__ for m in blk] == ['Conv2d', 'BatchNorm2d', 'ReLU']
+    assert isinstance(blk[0], nn.Conv2d) and isinstance(blk[1], nn.BatchNorm2d) and isinstance(blk[2], nn.ReLU)
+    assert blk[0].bias is None                                   # bias iff not batch_norm (basemodel.py:973)
+    assert (net.in_channels, net.height, net.width) == (64, 112, 112)
+    mp = net.maxpool2d(kernel_size=3, stride=2, padding=1)
+    assert isinstance(mp, nn.MaxPool2d) and (net.height, net.width) == (56, 56)
+    ds = net.conv2d_block(64, 256, set_output=False, activation=False, kernel_size=1, stride=2)
+    assert len(ds) == 2 and (net.in_channels, net.height) == (64, 56)   # set_output=False leaves the tracker alone
+    gap = net.adapt_avgpool2d(output_size=1)
+    assert isinstance(gap, nn.AdaptiveAvgPool2d) and net.num_flat_features() == 64
+    nobn = ca.MultiClassBaseModel(ca.Settings(kind=0, input_size=(1, 28, 28), num_classes=10, batch_norm=False, device='cpu'))
+    c = nobn.conv2d(num_filters=32, kernel_size=3)
+    assert c.bias is not None and (nobn.height, nobn.width) == (26, 26)
+    with pytest.raises(NotImplementedError):
+        net.conv2d_depthwise(num_filters=8, kernel_size=3)
+    with pytest.raises(NotImplementedError):
+        net.conv2d(num_filters=8, kernel_size=3, groups=2)
+    with pytest.raises(TypeError):
+        ca.Settings(kind=0, input_size=(1, 2, 2), num_classes=2, no_such_field=1)
+
+
+@pytest.mark.parametrize('name,family,kind', [('resnet50', 'resnet', 50), ('resnet152', 'resnet', 152), ('vgg16', 'vgg', 16)])
+def test_state_dict_interchange_with_reference(name, family, kind):
+    """Same keys and shapes as the reference's classes (golden facts), so checkpoints interchange."""
+    import convnets_amd as ca
+    s = ca.Settings(kind=kind, input_size=(3, 224, 224), num_classes=1000, init_params=False, device='cpu')
+    m = ca.MODELS[family](s)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(MODELS[f'{name}/sd_keys'])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(MODELS[f'{name}/sd_shapes'])
+    assert sum(p.numel() for p in m.parameters()) == int(MODELS[f'{name}/n_params'])
+
+
+def test_init_params_reproduces_reference_weights_and_deepcopy():
+    import copy
+    import convnets_amd as ca
+    torch.manual_seed(21)
+    m = ca.ResNet(ca.Settings(kind=26, input_size=(3, 32, 32), num_classes=10, device='cpu'))
+    norms = np.array([float(p.detach().double().norm()) for p in m.parameters()])
+    np.testing.assert_allclose(norms, MODELS['resnet26/init_norms'], rtol=1e-6)
+    m2 = copy.deepcopy(m)                                         # basemodel.py:413 deep-copies state
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert m2.features[0][0]._packed is not m.features[0][0]._packed
+    s = ca.Settings(kind=26, input_size=(3, 32, 32), num_classes=10, device='cpu')
+    assert (s.batch_size, s.learning_rate, s.weight_decay, s.dropout_rate, s.seed) == (256, 0.01, 1e-4, 0.5, 21)
+    assert s.compute_dtype == torch.bfloat16 and ca.Settings(kind=0, input_size=(1, 1, 1), num_classes=2, mixed_precision=False, device='cpu').compute_dtype == torch.float32
