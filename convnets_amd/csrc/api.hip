@@ -10,7 +10,8 @@
 
 // ---- kernel families (other translation units) ---------------------------------------------------
 bool igemm_supported(const cnk_conv_desc* d, int pass);
-int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, hipStream_t s);
+int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, hipStream_t s);
+int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, hipStream_t s);
 int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
 bool wgrad_mfma_supported(const cnk_conv_desc* d);
@@ -24,6 +25,12 @@ size_t colsum_workspace(int64_t M, int C);
 int colsum(const void* a, float* out, int64_t M, int C, int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int pack_direct(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
 int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, const signed char* kh, const signed char* kw, int transpose, hipStream_t s);
+bool rowpatch_supported(const cnk_conv_desc* d);
+size_t rowpatch_packed_bytes(const cnk_conv_desc* d);
+int rowpatch_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
+int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, hipStream_t s);
+size_t rowpatch_wgrad_workspace(const cnk_conv_desc* d);
+int rowpatch_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 bool smallc_supported(const cnk_conv_desc* d);
 size_t smallc_packed_bytes(const cnk_conv_desc* d);
 int smallc_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
@@ -31,9 +38,9 @@ int smallc_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const flo
 size_t smallc_wgrad_workspace(const cnk_conv_desc* d);
 int smallc_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t bn_workspace_bytes(int64_t M, int C);
-int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* rm, float* rv, float* sm, float* si, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
+int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
-int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
+int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
 int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
 int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
@@ -133,6 +140,7 @@ size_t cnk_conv2d_packed_bytes(const cnk_conv_desc* d, int pass) {
     size_t n = (size_t)d->Cout * d->Cin * d->kh * d->kw;
     if (pass != CNK_PASS_FWD && pass != CNK_PASS_DGRAD) return 0;
     if (igemm_supported(d, pass)) return n * esize(d->dtype);
+    if (pass == CNK_PASS_FWD && rowpatch_supported(d)) return rowpatch_packed_bytes(d);
     if (pass == CNK_PASS_FWD && smallc_supported(d)) return smallc_packed_bytes(d);
     return n * sizeof(float);
 }
@@ -142,6 +150,7 @@ size_t cnk_conv2d_workspace_bytes(const cnk_conv_desc* d, int pass) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     size_t a = wgrad_mfma_supported(d) ? wgrad_mfma_workspace(d)
+               : rowpatch_supported(d) ? rowpatch_wgrad_workspace(d)
                : smallc_supported(d) ? smallc_wgrad_workspace(d) : direct_wgrad_workspace(d);
     a = (a + 255) & ~(size_t)255;
     return a + colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout);
@@ -156,6 +165,8 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
             signed char kh[32], kw[32];
             for (int t = 0; t < d->kh * d->kw; ++t) { kh[t] = (signed char)(t / d->kw); kw[t] = (signed char)(t % d->kw); }
             if (int rc = pack_taps(d, w, w_fwd, d->kh * d->kw, kh, kw, 0, S(stream))) return rc;
+        } else if (rowpatch_supported(d)) {
+            if (int rc = rowpatch_pack(d, w, w_fwd, S(stream))) return rc;
         } else if (smallc_supported(d)) {
             if (int rc = smallc_pack(d, w, w_fwd, S(stream))) return rc;
         } else {
@@ -181,14 +192,20 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
     return 0;
 }
 
-int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, void* workspace, size_t workspace_bytes, void* stream) {
+int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d) {
+    return igemm_supported(d, CNK_PASS_FWD) ? igemm_fwd_stat_slices(d) : 0;
+}
+
+int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (int rc = check_desc(d, "cnk_conv2d_fwd")) return rc;
     CNK_CHECK_ARG(x && w_fwd && y, "cnk_conv2d_fwd: null pointer");
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
-    if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd(d, x, w_fwd, bias, y, S(stream));
+    if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd(d, x, w_fwd, bias, y, bn_partial, S(stream));
+    CNK_CHECK_ARG(!bn_partial, "cnk_conv2d_fwd: this conv shape cannot emit BN partials (cnk_conv2d_fwd_bn_partial_slices == 0)");
+    if (rowpatch_supported(d)) return rowpatch_fwd(d, x, w_fwd, bias, y, S(stream));
     if (smallc_supported(d)) return smallc_fwd(d, x, w_fwd, bias, y, S(stream));
     return direct_fwd(d, x, w_fwd, bias, y, S(stream));
 }
@@ -217,6 +234,9 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
     if (wgrad_mfma_supported(d)) {
         a = wgrad_mfma_workspace(d);
         rc = wgrad_mfma(d, dy, x, dw, accumulate, workspace, a, S(stream));
+    } else if (rowpatch_supported(d)) {
+        a = rowpatch_wgrad_workspace(d);
+        rc = rowpatch_wgrad(d, dy, x, dw, accumulate, workspace, a, S(stream));
     } else if (smallc_supported(d)) {
         a = smallc_wgrad_workspace(d);
         rc = smallc_wgrad(d, dy, x, dw, accumulate, workspace, a, S(stream));
@@ -236,13 +256,14 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
 
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(M, C); }
 
-int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* running_mean, float* running_var, float* save_mean, float* save_invstd, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* partial, int64_t partial_slices, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd, "cnk_bn_fwd_train: null pointer");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_train: empty tensor");
     CNK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cnk_bn_fwd_train: running stats must both be given or both NULL");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_fwd_train: workspace too small");
-    ProfScope ps(CNK_CLS_BN_FWD, S(stream), 0.0, 3.0 * (double)M * C * esize(dtype));
-    return bn_fwd_train(x, gamma, beta, residual, y, running_mean, running_var, save_mean, save_invstd, M, C, eps, momentum, relu, dtype, (float*)workspace, S(stream));
+    CNK_CHECK_ARG((partial == nullptr) == (partial_slices == 0) && partial_slices >= 0, "cnk_bn_fwd_train: partial and partial_slices must come together");
+    ProfScope ps(CNK_CLS_BN_FWD, S(stream), 0.0, (partial ? 2.0 : 3.0) * (double)M * C * esize(dtype));
+    return bn_fwd_train(x, gamma, beta, residual, y, running_mean, running_var, save_mean, save_invstd, partial, partial_slices, M, C, eps, momentum, relu, dtype, (float*)workspace, S(stream));
 }
 
 int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var, const void* residual, void* y, int64_t M, int32_t C, float eps, int relu, int dtype, void* stream) {
@@ -251,13 +272,13 @@ int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const 
     return bn_fwd_eval(x, gamma, beta, running_mean, running_var, residual, y, M, C, eps, relu, dtype, S(stream));
 }
 
-int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "cnk_bn_bwd: null pointer");
-    CNK_CHECK_ARG(!relu || y, "cnk_bn_bwd: relu backward needs the forward output");
+    CNK_CHECK_ARG(!relu || y || (beta && !dresidual), "cnk_bn_bwd: relu backward needs the forward output, or beta and no residual");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd: empty tensor");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd: workspace too small");
     ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, 5.0 * (double)M * C * esize(dtype));
-    return bn_bwd(dy, x, y, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, M, C, relu, dtype, (float*)workspace, S(stream));
+    return bn_bwd(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, M, C, relu, dtype, (float*)workspace, S(stream));
 }
 
 int cnk_maxpool2d_fwd(const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {

@@ -53,7 +53,7 @@ SliceGeom make_geom(int64_t M, int C, int vec) {
     g.rpb = 256 / g.cpb;
     g.colgroups = ceil_div(g.cols, g.cpb);
     int64_t sr = (int64_t)g.rpb * 32;
-    if (ceil_div64(M, sr) > 1024) sr = ceil_div64(ceil_div64(M, 1024), g.rpb) * g.rpb;
+    if (ceil_div64(M, sr) > 2048) sr = ceil_div64(ceil_div64(M, 2048), g.rpb) * g.rpb;
     g.slice_rows = (int)sr;
     g.slices = (int)ceil_div64(M, sr);
     return g;
@@ -139,15 +139,16 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, floa
     }
 }
 
-// One wave per channel: lanes stride over the slices, then a 6-step butterfly merge.
+// One 256-thread block per channel: threads stride over the slices (a conv-fused layer has one
+// slice per 128-row tile, thousands of them), butterfly merge per wave, then across the 4 waves.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ partial, int slices, int C, int64_t M, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float* save_mean,
     float* save_invstd, float* scale, float* shift, float eps, float momentum) {
-    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ float sh[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
     float na = 0.f, ma = 0.f, qa = 0.f;
-    for (int s = lane; s < slices; s += 64) {
+    for (int s = tid; s < slices; s += 256) {
         const float* o = partial + ((size_t)s * C + c) * 3;
         chan_merge(na, ma, qa, o[0], o[1], o[2]);
     }
@@ -156,7 +157,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         float nb = __shfl_xor(na, o, 64), mb = __shfl_xor(ma, o, 64), qb = __shfl_xor(qa, o, 64);
         chan_merge(na, ma, qa, nb, mb, qb);
     }
-    if (lane != 0) return;
+    if (lane == 0) { sh[0][wave] = na; sh[1][wave] = ma; sh[2][wave] = qa; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < 4; ++w) chan_merge(na, ma, qa, sh[0][w], sh[1][w], sh[2][w]);
     float var = qa / (float)M;
     float invstd = rsqrtf(var + eps);
     // one Newton step: rsqrtf is ~1 ulp, this keeps fp32 parity tight
@@ -202,7 +206,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
     }
     const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
     const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
-    for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
+    // two rows per iteration: twice the bytes in flight per wave (these kernels are bound by
+    // outstanding-request depth, not by arithmetic)
+    int64_t m = m0 + trow;
+    for (; m + g.rpb < m1; m += 2 * g.rpb) {
+        const int64_t off0 = m * C + (int64_t)vcol * VEC, off1 = off0 + (int64_t)g.rpb * C;
+        VLoad<T, VEC> v0, v1, r0, r1;
+        v0.load(x + off0);
+        v1.load(x + off1);
+        if (res) { r0.load(res + off0); r1.load(res + off1); }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float a = v0.f[k] * sc[k] + sh[k], b = v1.f[k] * sc[k] + sh[k];
+            if (res) { a += r0.f[k]; b += r1.f[k]; }
+            if (relu) { a = a > 0.f ? a : 0.f; b = b > 0.f ? b : 0.f; }
+            v0.f[k] = a; v1.f[k] = b;
+        }
+        v0.store(y + off0);
+        v1.store(y + off1);
+    }
+    if (m < m1) {
         const int64_t off = m * C + (int64_t)vcol * VEC;
         VLoad<T, VEC> v, r;
         v.load(x + off);
@@ -250,34 +273,50 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const T* __restrict__ x,
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
     int64_t M, int C, int relu, SliceGeom g) {
     __shared__ float sh[2][256 * (VEC > 1 ? VEC : 1)];
+    const bool remask = relu && y == nullptr;      // mask from x*scale+shift (same fp32 ops as forward)
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     const bool active = trow < g.rpb && vcol < g.cols;
     const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
     const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
-    float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+    float s1[VEC], s2[VEC], mu[VEC], is[VEC], sc[VEC], sf[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         s1[i] = s2[i] = 0.f;
         mu[i] = active ? mean[vcol * VEC + i] : 0.f;
         is[i] = active ? invstd[vcol * VEC + i] : 0.f;
+        sc[i] = (active && remask) ? gamma[vcol * VEC + i] * is[i] : 0.f;
+        sf[i] = (active && remask) ? beta[vcol * VEC + i] - mu[i] * sc[i] : 0.f;
     }
     if (active) {
-        for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
-            int64_t off = m * C + (int64_t)vcol * VEC;
-            VLoad<T, VEC> vd, vx, vy;
-            vd.load(dy + off);
-            vx.load(x + off);
-            if (relu) vy.load(y + off);
+        for (int64_t m = m0 + trow; m < m1; m += 2 * g.rpb) {
+            const bool two = m + g.rpb < m1;
+            int64_t off[2] = {m * C + (int64_t)vcol * VEC, (m + g.rpb) * C + (int64_t)vcol * VEC};
+            VLoad<T, VEC> vd[2], vx[2], vy[2];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                float d = vd.f[i];
-                if (relu && !(vy.f[i] > 0.f)) d = 0.f;
-                s1[i] += d;
-                s2[i] += d * (vx.f[i] - mu[i]) * is[i];
+            for (int u = 0; u < 2; ++u) {
+                if (u == 0 || two) {
+                    vd[u].load(dy + off[u]);
+                    vx[u].load(x + off[u]);
+                    if (relu && !remask) vy[u].load(y + off[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 0 || two) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        float d = vd[u].f[i];
+                        if (remask) vy[u].f[i] = vx[u].f[i] * sc[i] + sf[i];
+                        if (relu && !(vy[u].f[i] > 0.f)) d = 0.f;
+                        s1[i] += d;
+                        s2[i] += d * (vx[u].f[i] - mu[i]) * is[i];
+                    }
+                }
             }
         }
     }
@@ -335,39 +374,54 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ dx,
-    T* __restrict__ dres, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ coefA, const float* __restrict__ coefB1,
-    const float* __restrict__ coefB2, int64_t M, int C, int relu, SliceGeom g) {
+    T* __restrict__ dres, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ coefA,
+    const float* __restrict__ coefB1, const float* __restrict__ coefB2, int64_t M, int C, int relu,
+    SliceGeom g) {
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     if (trow >= g.rpb || vcol >= g.cols) return;
+    const bool remask = relu && y == nullptr;
     // dx = a*(d - b1 - (x-mu)*(is*b2)); the centred form keeps fp32 accuracy when |mu| >> sigma
-    float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC];
+    float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC], ksf[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         int c = vcol * VEC + k;
-        ka[k] = coefA[c];
+        ka[k] = coefA[c];                       // gamma*invstd == the forward's scale
         kb1[k] = coefB1[c];
         kmu[k] = mean[c];
         kis[k] = invstd[c] * coefB2[c];
+        ksf[k] = remask ? beta[c] - kmu[k] * ka[k] : 0.f;
     }
     const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
     const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
-    for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
-        const int64_t off = m * C + (int64_t)vcol * VEC;
-        VLoad<T, VEC> vd, vx, vy, vo;
-        vd.load(dy + off);
-        vx.load(x + off);
-        if (relu) vy.load(y + off);
+    for (int64_t m = m0 + trow; m < m1; m += 2 * g.rpb) {
+        const bool two = m + g.rpb < m1;
+        int64_t off[2] = {m * C + (int64_t)vcol * VEC, (m + g.rpb) * C + (int64_t)vcol * VEC};
+        VLoad<T, VEC> vd[2], vx[2], vy[2], vo[2];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            float d = vd.f[k];
-            if (relu && !(vy.f[k] > 0.f)) d = 0.f;
-            vd.f[k] = d;
-            vo.f[k] = ka[k] * (d - kb1[k] - (vx.f[k] - kmu[k]) * kis[k]);
+        for (int u = 0; u < 2; ++u) {
+            if (u == 0 || two) {
+                vd[u].load(dy + off[u]);
+                vx[u].load(x + off[u]);
+                if (relu && !remask) vy[u].load(y + off[u]);
+            }
         }
-        vo.store(dx + off);
-        if (dres) vd.store(dres + off);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 0 || two) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float d = vd[u].f[k];
+                    if (remask) vy[u].f[k] = vx[u].f[k] * ka[k] + ksf[k];
+                    if (relu && !(vy[u].f[k] > 0.f)) d = 0.f;
+                    vd[u].f[k] = d;
+                    vo[u].f[k] = ka[k] * (d - kb1[k] - (vx[u].f[k] - kmu[k]) * kis[k]);
+                }
+                vo[u].store(dx + off[u]);
+                if (dres) vd[u].store(dres + off[u]);
+            }
+        }
     }
 }
 
@@ -394,16 +448,23 @@ size_t bn_workspace_bytes(int64_t M, int C) {
 
 template <typename T, int VEC>
 static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* res,
-                          void* y, float* rm, float* rv, float* sm, float* si, int64_t M, int C,
-                          float eps, float mom, int relu, float* ws, hipStream_t s) {
+                          void* y, float* rm, float* rv, float* sm, float* si, const float* ext_partial,
+                          int64_t ext_slices, int64_t M, int C, float eps, float mom, int relu,
+                          float* ws, hipStream_t s) {
     SliceGeom g = make_geom(M, C, VEC);
     float* scale = ws;
     float* shift = ws + C;
-    float* partial = ws + ws_partials_off(C);
-    hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)x, partial, M, C, g);
-    CNK_CHECK_LAUNCH("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, g.slices, C,
+    const float* partial = ext_partial;
+    int slices = (int)ext_slices;
+    if (!ext_partial) {                  // statistics not supplied by the producing conv: own pass
+        float* own = ws + ws_partials_off(C);
+        hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
+                           (const T*)x, own, M, C, g);
+        CNK_CHECK_LAUNCH("bn_stats");
+        partial = own;
+        slices = g.slices;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, slices, C,
                        M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
     CNK_CHECK_LAUNCH("bn_finalize");
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
@@ -413,14 +474,14 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
 }
 
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y,
-                 float* rm, float* rv, float* sm, float* si, int64_t M, int C, float eps, float mom,
-                 int relu, int dtype, float* ws, hipStream_t s) {
+                 float* rm, float* rv, float* sm, float* si, const float* ep, int64_t es, int64_t M, int C,
+                 float eps, float mom, int relu, int dtype, float* ws, hipStream_t s) {
     if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_fwd_train_t<bf16, 8>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
-        return bn_fwd_train_t<bf16, 1>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
+        if (C % 8 == 0) return bn_fwd_train_t<bf16, 8>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+        return bn_fwd_train_t<bf16, 1>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
     }
-    if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
-    return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, rm, rv, sm, si, M, C, eps, mom, relu, ws, s);
+    if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+    return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
 }
 
 template <typename T, int VEC>
@@ -447,7 +508,7 @@ int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const floa
 
 template <typename T, int VEC>
 static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* gamma,
-                    const float* sm, const float* si, void* dx, void* dres, float* dgamma,
+                    const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma,
                     float* dbeta, int accumulate, int64_t M, int C, int relu, float* ws,
                     hipStream_t s) {
     SliceGeom g = make_geom(M, C, VEC);
@@ -456,25 +517,25 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* g
     float* coefB2 = ws + 3 * C;
     float* partial = ws + ws_partials_off(C);
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)dy, (const T*)x, (const T*)y, sm, si, partial, M, C, relu, g);
+                       (const T*)dy, (const T*)x, (const T*)y, gamma, beta, sm, si, partial, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, g.slices,
                        C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
     CNK_CHECK_LAUNCH("bn_bwd_final");
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, sm, si, coefA, coefB1,
+                       (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, beta, sm, si, coefA, coefB1,
                        coefB2, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }
 
-int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* sm,
+int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* sm,
            const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
            int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s) {
     if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_bwd_t<bf16, 8>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
-        return bn_bwd_t<bf16, 1>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+        if (C % 8 == 0) return bn_bwd_t<bf16, 8>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+        return bn_bwd_t<bf16, 1>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
     }
-    if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
-    return bn_bwd_t<float, 1>(dy, x, y, gamma, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+    if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+    return bn_bwd_t<float, 1>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
 }

@@ -12,6 +12,8 @@
 // (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for exact fp32).  Global -> registers ->
 // LDS staging, double-buffered LDS, one barrier per K step; LDS rows are 128 B with the 16-byte
 // chunk index XORed by (row>>1)&7 so every ds_read_b128 lane group hits 16 distinct bank slots.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -24,6 +26,7 @@ struct GatherParams {
     const void* wpk;
     void* dst;
     const float* bias;
+    float* stats;            // optional [tiles_m][Nout][3] BN partials (n, mean, M2) of the OUTPUT
     int N, IH, IW, C;
     int OH, OW;
     int FH, FW, Nout;
@@ -56,7 +59,7 @@ template <> struct Mma32<float> {
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
 
 template <typename T, int BN>
-__global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
     constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
     constexpr int NJ = BN / 64;                      // 32-wide MFMA blocks per wave along n
@@ -115,9 +118,13 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     const int nk = p.ntaps * csteps;
     const size_t wrow = (size_t)p.ntaps * p.C;
 
-    u32x4 ra[4], rb[B_LOADS];
+    // Two register staging sets: tile t is loaded into set t&1 two K steps before it is consumed
+    // and written to LDS buffer t&1 one step before, so a global load has two MFMA phases (plus the
+    // co-resident workgroup) to land instead of one.
+    u32x4 ra[2][4], rb[2][B_LOADS];
     int ld_t = 0, ld_cs = 0;                         // (tap, channel step) of the next load_step
-    auto load_step = [&]() {
+    auto load_step = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
         const int t = ld_t, c0 = ld_cs * KSTEP + chunk * PER16;
         if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
         int dh = p.dh[t], dw = p.dw[t];
@@ -130,25 +137,26 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
                 size_t off = ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + c0;
                 v = *(const u32x4*)(src + off);
             }
-            ra[i] = v;
+            ra[S][i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             int n = tile_n * BN + lrow + 32 * i;
             size_t off = (size_t)n * wrow + (size_t)t * p.C + c0;
-            rb[i] = *(const u32x4*)(wpk + off);
+            rb[S][i] = *(const u32x4*)(wpk + off);
         }
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = lrow + 32 * i;
-            *(u32x4*)(As + buf * (BM * 128) + r * 128 + swz(r, chunk)) = ra[i];
+            *(u32x4*)(As + S * (BM * 128) + r * 128 + swz(r, chunk)) = ra[S][i];
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             int r = lrow + 32 * i;
-            *(u32x4*)(Bs + buf * (BN * 128) + r * 128 + swz(r, chunk)) = rb[i];
+            *(u32x4*)(Bs + S * (BN * 128) + r * 128 + swz(r, chunk)) = rb[S][i];
         }
     };
 
@@ -161,16 +169,12 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    if (nk > 0) {
-        load_step();
-        store_step(0);
-    }
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) load_step();
-        const unsigned char* Ab = As + buf * (BM * 128);
-        const unsigned char* Bb = Bs + buf * (BN * 128);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto compute = [&](auto BUF) {
+        constexpr int S = decltype(BUF)::value;
+        const unsigned char* Ab = As + S * (BM * 128);
+        const unsigned char* Bb = Bs + S * (BN * 128);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 fa[2], fb[NJ];
@@ -189,7 +193,24 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) Mma32<T>::run(acc[i][j], fb[j], fa[i]);   // C^T block
         }
-        if (ks + 1 < nk) store_step(buf ^ 1);
+    };
+    if (nk > 0) {
+        load_step(I0{});
+        store_step(I0{});
+        if (nk > 1) load_step(I1{});
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+        // even step: consume buffer 0, prefetch tile ks+2 into set 0, publish tile ks+1 (set 1)
+        if (ks + 2 < nk) load_step(I0{});
+        compute(I0{});
+        if (ks + 1 < nk) store_step(I1{});
+        __syncthreads();
+        if (ks + 1 >= nk) break;
+        // odd step
+        if (ks + 3 < nk) load_step(I1{});
+        compute(I1{});
+        if (ks + 2 < nk) store_step(I0{});
         __syncthreads();
     }
 
@@ -228,28 +249,74 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     constexpr int RPP = 256 / CPR;                   // rows per pass
     unsigned char* dst = (unsigned char*)p.dst;
     const int crow = tid / CPR, cc = tid - crow * CPR;
+    float s8[PER16], q8[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) s8[e] = q8[e] = 0.f;
 #pragma unroll
     for (int ps = 0; ps < BM / RPP; ++ps) {
         const int row = ps * RPP + crow;
         const int pix = row_dst[row];
-        if (pix >= 0)
-            *(u32x4*)(dst + ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16) =
-                *(const u32x4*)(Cs + row * CS + cc * 16);
+        if (pix >= 0) {
+            Vec16<T> v;
+            v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
+            *(decltype(v.v)*)(dst + ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16) = v.v;
+            if (p.stats) {
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) {
+                    float f = v.get(e);
+                    s8[e] += f;
+                    q8[e] += f * f;
+                }
+            }
+        }
+    }
+    // Fused BN statistics of the values just stored (i.e. of the ROUNDED output, exactly what the
+    // BN kernels would read back): per-channel sum / sum-of-squares over this tile's <=128 rows ->
+    // (n, mean, M2) partial, merged across tiles by bn_finalize (Chan).  Saves one full read pass.
+    if (p.stats) {
+        float* red = (float*)(Cs + BM * CS);          // [2][RPP][BN]
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) {
+            red[crow * BN + cc * PER16 + e] = s8[e];
+            red[(RPP + crow) * BN + cc * PER16 + e] = q8[e];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < RPP; ++r) {
+                S += red[r * BN + tid];
+                Q += red[(RPP + r) * BN + tid];
+            }
+            const int nvalid = min(BM, p.M - tile_m * BM);
+            const float mean = S / (float)nvalid;
+            float m2 = Q - S * mean;
+            float* o = p.stats + ((size_t)tile_m * p.Nout + tile_n * BN + tid) * 3;
+            o[0] = (float)nvalid;
+            o[1] = mean;
+            o[2] = m2 > 0.f ? m2 : 0.f;
+        }
     }
 }
 
 template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
-    size_t pipe = 2 * BM * 128 + 2 * BN * 128, epi = (size_t)BM * (BN * sizeof(T) + 16);
+    size_t pipe = 2 * BM * 128 + 2 * BN * 128;
+    size_t epi = (size_t)BM * (BN * sizeof(T) + 16) + (p.stats ? 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float) : 0);
     size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
     hipLaunchKernelGGL((igemm_gather_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
 }
 
-template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
+static bool pick_bn128(int M, int Nout) {
     // BN = 128 when it divides Nout and the grid still fills the chip, else 64
+    int tiles_m = ceil_div(M, BM);
+    return (Nout % 128 == 0) && ((int64_t)tiles_m * (Nout / 128) >= 512);
+}
+
+template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     int tiles_m = ceil_div(p.M, BM);
-    bool use128 = (p.Nout % 128 == 0) && ((int64_t)tiles_m * (p.Nout / 128) >= 512);
+    bool use128 = pick_bn128(p.M, p.Nout);
     int bn = use128 ? 128 : 64;
     p.tiles_n = p.Nout / bn;
     p.tiles_total = tiles_m * p.tiles_n;
@@ -269,12 +336,18 @@ bool igemm_supported(const cnk_conv_desc* d, int pass) {
     return true;
 }
 
+int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    return ceil_div(d->N * Ho * Wo, BM);
+}
+
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
-              hipStream_t s) {
+              float* stats, hipStream_t s) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     GatherParams p = {};
-    p.src = x; p.wpk = w_fwd; p.dst = y; p.bias = bias;
+    p.src = x; p.wpk = w_fwd; p.dst = y; p.bias = bias; p.stats = stats;
     p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cin;
     p.OH = Ho; p.OW = Wo; p.FH = Ho; p.FW = Wo; p.Nout = d->Cout;
     p.sm_h = d->stride_h; p.sm_w = d->stride_w;

@@ -1,0 +1,482 @@
+// "Row-patch" MFMA convolution for the first layer of a network (Cin = 1..4, Cout <= 64): ResNet's
+// 7x7/2 stem, AlexNet's 11x11/4, VGG's first 3x3.  Supersedes the element-gather kernels of
+// conv_smallc.hip whenever the input row fits the patch (they remain the fallback).
+//
+// In NHWC the kw*Cin values a window needs from one input row are CONTIGUOUS: for output pixel ow
+// and window row kh they are patch[kh][(ow*s - p)*Cin ... + kw*Cin).  So a workgroup stages the
+// KH input rows of one output row in LDS with coalesced 16-byte loads (zero rows/columns for the
+// padding) and the MFMA fragments are read straight out of that patch -- no im2col, no gather:
+//   K' = kh*Rp + j,  j in [0,Rp),  Rp = kw*Cin (+lead) rounded up to the 16-byte chunk;
+//   the weight image [64 co][K'pad] has zeros at the padded j, so whatever finite patch values
+//   the over-read touches are multiplied by zero.
+// `lead` (0/1) shifts the run start one element left when that makes every run start 4-byte
+// aligned (bf16, even s*Cin): the fragment is then four ds_read_b32; otherwise eight ds_read_u16.
+//   forward : acc^T[co][px]  += W[co][k'] * patch(px,k')      (px on the MFMA lane)
+//   wgrad   : dW[co][k']     += dy^T[co][px] * patch(px,k')   (reduction over px; dy through the
+//             transposing LDS read, patch column fragments by strided element reads); every
+//             workgroup owns a run of output rows and writes one fp32 slab, summed by
+//             rowpatch_reduce in fixed order.
+#include "common.h"
+
+namespace {
+
+struct RowPatchParams {
+    const void* x;
+    const void* wpk;       // [64][Kp] weights (T)
+    void* y;
+    const void* dy;
+    float* slab;           // wgrad: [grid][64][Kp]
+    const float* bias;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, s, p;
+    int R, Rp, lead, Kp;   // run length, padded run, lead shift, padded K'
+    int A0;                // element offset of iw = -p inside a patch row is (A0 - p*Cin)
+    int PWE;               // patch row length in elements (incl. zero tail)
+    int rows_total;        // N*Ho
+    int rows_per_wg;
+};
+
+constexpr int PATCH_A0 = 16;     // data of an input row starts 16 elements into the patch row (16-B aligned)
+
+template <typename T> struct RpCfg;
+template <> struct RpCfg<bf16> { static constexpr int CH = 8; };   // elements per 16-B chunk
+template <> struct RpCfg<float> { static constexpr int CH = 4; };
+
+// Stage input rows ih0 .. ih0+nrows-1 of image n (zero outside) into patch[r][...]
+template <typename T>
+__device__ __forceinline__ void load_patch(const RowPatchParams& p, const T* x, T* patch, int n,
+                                           int ih0, int nrows) {
+    constexpr int CH = RpCfg<T>::CH;
+    const int row_elems = p.W * p.Cin;                 // multiple of CH checked on the host
+    const int cpr = p.PWE / CH;                        // chunks per patch row
+    const int data0 = PATCH_A0 / CH, data1 = data0 + row_elems / CH;
+    for (int i = threadIdx.x; i < nrows * cpr; i += blockDim.x) {
+        int r = i / cpr, c = i - r * cpr;
+        int ih = ih0 + r;
+        u32x4 v = {0, 0, 0, 0};
+        if ((unsigned)ih < (unsigned)p.H && c >= data0 && c < data1)
+            v = *(const u32x4*)(x + ((size_t)(n * p.H + ih) * p.W) * p.Cin + (size_t)(c - data0) * CH);
+        *(u32x4*)(patch + (size_t)r * p.PWE + c * CH) = v;
+    }
+}
+
+// 16 bytes (one MFMA k-chunk) starting at element e of a patch row
+template <typename T, bool ALIGN4>
+__device__ __forceinline__ u32x4 read_chunk(const T* row, int e) {
+    if constexpr (sizeof(T) == 4) {
+        const float* q = (const float*)row + e;
+        f32x4 v = {q[0], q[1], q[2], q[3]};
+        return __builtin_bit_cast(u32x4, v);
+    } else if constexpr (ALIGN4) {
+        const unsigned int* q = (const unsigned int*)((const unsigned short*)row + e);
+        u32x4 v = {q[0], q[1], q[2], q[3]};
+        return v;
+    } else {
+        const unsigned short* q = (const unsigned short*)row + e;
+        u32x4 v = {(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16),
+                   (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
+        return v;
+    }
+}
+
+template <typename T> struct RpMma;
+template <> struct RpMma<bf16> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct RpMma<float> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+        f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// forward: one workgroup = rows_per_wg consecutive output rows (n, oh); wave w takes pixel chunks
+// w, w+4, ... of 32 pixels.  LDS: weights [64][Kp+pad] | patch [(KH+1)][PWE] | per-wave out stage.
+template <typename T, bool ALIGN4>
+__global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams p) {
+    constexpr int CH = RpCfg<T>::CH, ES = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int WS = p.Kp * ES + 16;                               // weight row stride (odd # of 16-B slots)
+    unsigned char* Wl = smem;                                    // [64][WS]
+    T* patch = (T*)(Wl + 64 * WS);                               // [KH+1][PWE]
+    unsigned char* stage = (unsigned char*)(patch + (size_t)(p.KH + 1) * p.PWE);   // [4 waves][32][64*ES+16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const T* x = (const T*)p.x;
+    const T* wpk = (const T*)p.wpk;
+    // weights -> LDS (once per workgroup)
+    {
+        const int cpr = p.Kp / CH;
+        for (int i = tid; i < 64 * cpr; i += 256) {
+            int r = i / cpr, c = i - r * cpr;
+            *(u32x4*)(Wl + r * WS + c * 16) = *(const u32x4*)(wpk + (size_t)r * p.Kp + c * CH);
+        }
+        for (int i = tid; i < p.PWE; i += 256) patch[(size_t)p.KH * p.PWE + i] = from_f32<T>(0.f);   // guard row
+    }
+    const int nsteps = p.Kp / (2 * CH);                          // MFMA k-steps (two chunks each)
+    const int cps = p.Rp / CH;                                   // chunks per kh run
+    const int SS = 64 * ES + 16;
+    unsigned char* st = stage + wave * 32 * SS;
+    const int row0 = blockIdx.x * p.rows_per_wg;
+    for (int rr = 0; rr < p.rows_per_wg; ++rr) {
+        const int row = row0 + rr;
+        if (row >= p.rows_total) break;
+        const int n = row / p.Ho, oh = row - n * p.Ho;
+        __syncthreads();                                         // previous row's patch reads done
+        load_patch<T>(p, x, patch, n, oh * p.s - p.p, p.KH);
+        __syncthreads();
+        for (int c0 = wave * 32; c0 < p.Wo; c0 += 128) {
+            const int ow = c0 + l31;
+            const int owc = ow < p.Wo ? ow : p.Wo - 1;           // clamp: reads stay inside the patch
+            const int e0 = PATCH_A0 - p.p * p.Cin - p.lead + owc * p.s * p.Cin;
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int sidx = 0; sidx < nsteps; ++sidx) {
+                const int q = 2 * sidx + lh;                     // this lane's k-chunk
+                int kh = q / cps;
+                const int j0 = (q - kh * cps) * CH;
+                kh = kh < p.KH ? kh : p.KH;                      // K' padding -> zero guard row
+                u32x4 fa = read_chunk<T, ALIGN4>(patch + (size_t)kh * p.PWE, e0 + j0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u32x4 fb = *(const u32x4*)(Wl + (j * 32 + l31) * WS + q * 16);
+                    RpMma<T>::run(acc[j], fb, fa);               // transposed: rows = co, cols = pixels
+                }
+            }
+            // lane (pixel l31, lh) holds channels j*32 + 8g + 4lh + {0..3} in regs 4g..4g+3
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int col = j * 32 + 8 * gq + 4 * lh;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * gq + e] + (p.bias ? p.bias[min(col + e, p.Cout - 1)] : 0.f);
+                    if constexpr (ES == 2) {
+                        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *(bf16x4*)(st + l31 * SS + col * 2) = o;
+                    } else {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(st + l31 * SS + col * 4) = o;
+                    }
+                }
+            // wave-private staging: no workgroup barrier needed, only this wave's own LDS ordering
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+            T* y = (T*)p.y + ((size_t)row * p.Wo + c0) * p.Cout;
+            if (p.Cout == 64) {
+                constexpr int CPRO = 64 * ES / 16;               // 16-B chunks per output pixel
+                for (int i = lane; i < 32 * CPRO; i += 64) {
+                    int pr = i / CPRO, c = i - pr * CPRO;
+                    if (c0 + pr < p.Wo)
+                        *(u32x4*)((unsigned char*)y + (size_t)pr * 64 * ES + c * 16) = *(const u32x4*)(st + pr * SS + c * 16);
+                }
+            } else {
+                for (int i = lane; i < 32 * p.Cout; i += 64) {
+                    int pr = i / p.Cout, c = i - pr * p.Cout;
+                    if (c0 + pr < p.Wo) y[(size_t)pr * p.Cout + c] = *(const T*)(st + pr * SS + c * ES);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: dW[co][k'] += sum_px dy[px][co] * patch(px, k').  32x32 output blocks (2 co-blocks x
+// Kp/32 k'-blocks) are dealt round-robin to the 4 waves; each wave sweeps every 32-pixel chunk.
+template <typename T, int NBLK>
+__global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParams p) {
+    constexpr int CH = RpCfg<T>::CH, ES = (int)sizeof(T);
+    constexpr int DS = 64 * ES + (ES == 2 ? 64 : 0);              // dy image row stride (tr-read friendly)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* patch = (T*)smem;                                          // [KH+1][PWE]
+    unsigned char* Dl = (unsigned char*)(patch + (size_t)(p.KH + 1) * p.PWE);   // [WoPad][DS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* x = (const T*)p.x;
+    const T* dy = (const T*)p.dy;
+    const int WoPad = (p.Wo + 31) / 32 * 32;
+    const int nblk = 2 * (p.Kp / 32);                            // 32x32 blocks of dW
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    for (int i = tid; i < p.PWE; i += 256) patch[(size_t)p.KH * p.PWE + i] = from_f32<T>(0.f);
+    const int row0 = blockIdx.x * p.rows_per_wg;
+    for (int rr = 0; rr < p.rows_per_wg; ++rr) {
+        const int row = row0 + rr;
+        if (row >= p.rows_total) break;
+        const int n = row / p.Ho, oh = row - n * p.Ho;
+        __syncthreads();
+        load_patch<T>(p, x, patch, n, oh * p.s - p.p, p.KH);
+        // dy row -> LDS [px][64 co], zero beyond Wo / Cout
+        if (p.Cout == 64) {
+            constexpr int CPR = 64 * ES / 16;
+            for (int i = tid; i < WoPad * CPR; i += 256) {
+                int pr = i / CPR, c = i - pr * CPR;
+                u32x4 v = {0, 0, 0, 0};
+                if (pr < p.Wo) v = *(const u32x4*)(dy + ((size_t)row * p.Wo + pr) * 64 + c * CH);
+                *(u32x4*)(Dl + pr * DS + c * 16) = v;
+            }
+        } else {
+            for (int i = tid; i < WoPad * 64; i += 256) {
+                int pr = i >> 6, c = i & 63;
+                T v = from_f32<T>(0.f);
+                if (pr < p.Wo && c < p.Cout) v = dy[((size_t)row * p.Wo + pr) * p.Cout + c];
+                *(T*)(Dl + pr * DS + c * ES) = v;
+            }
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < WoPad; c0 += 32) {
+            if constexpr (ES == 2) {
+                const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
+                const int l31 = lane & 31;
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {                  // two 16-pixel reduction steps
+                    const int prow = c0 + ss * 16 + 8 * h;       // first of this lane half's 8 pixels
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        const int blk = wave + 4 * b;
+                        if (blk < nblk) {
+                            const int mi = blk & 1, nj = blk >> 1;
+                            // A: dy^T fragment (rows co) through the transposing read
+                            const unsigned char* a0 = Dl + (prow + q) * DS + (mi * 32 + 16 * (g & 1) + 4 * pp) * 2;
+                            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * DS));
+                            typedef __attribute__((ext_vector_type(8))) short s16x8;
+                            s16x8 w8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            bf16x8 fa = __builtin_bit_cast(bf16x8, w8);
+                            // B: column k' = nj*32 + l31 of the virtual im2col, pixels prow..prow+7
+                            const int kp = nj * 32 + l31;
+                            int kh = kp / p.Rp;
+                            const int jj = kp - kh * p.Rp;
+                            kh = kh < p.KH ? kh : p.KH;
+                            const unsigned short* prw = (const unsigned short*)(patch + (size_t)kh * p.PWE) +
+                                                        (PATCH_A0 - p.p * p.Cin - p.lead + jj);
+                            const int stp = p.s * p.Cin;
+                            unsigned short e[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                int px = prow + u;
+                                px = px < p.Wo ? px : p.Wo - 1;   // dy is zero there; keep the read in range
+                                e[u] = prw[px * stp];
+                            }
+                            u32x4 fbv = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                         (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, fbv), acc[b], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                const int l31 = lane & 31, lk = lane >> 5;
+                for (int ss = 0; ss < 16; ++ss) {                 // 32 pixels, two per 32x32x2 step
+                    int px = c0 + ss * 2 + lk;
+                    const int pxc = px < p.Wo ? px : p.Wo - 1;
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        const int blk = wave + 4 * b;
+                        if (blk < nblk) {
+                            const int mi = blk & 1, nj = blk >> 1;
+                            float fa = *(const float*)(Dl + px * DS + (mi * 32 + l31) * 4);
+                            const int kp = nj * 32 + l31;
+                            int kh = kp / p.Rp;
+                            const int jj = kp - kh * p.Rp;
+                            kh = kh < p.KH ? kh : p.KH;
+                            float fb = ((const float*)(patch + (size_t)kh * p.PWE))[PATCH_A0 - p.p * p.Cin - p.lead + jj + pxc * p.s * p.Cin];
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* slab = p.slab + (size_t)blockIdx.x * 64 * p.Kp;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int blk = wave + 4 * b;
+        if (blk < nblk) {
+            const int mi = blk & 1, nj = blk >> 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(size_t)co * p.Kp + nj * 32 + l31] = acc[b][r];
+            }
+        }
+    }
+}
+
+// dw[co][ci][kh][kw] (+)= sum_wg slab[wg][co][kh*Rp + lead + kw*Cin + ci]; 4 lanes per element
+__global__ __launch_bounds__(256) void rowpatch_reduce_kernel(const float* __restrict__ slab,
+                                                              float* __restrict__ dw, int nslabs,
+                                                              int Cout, int Cin, int KH, int KW, int Rp,
+                                                              int lead, int Kp, int accumulate) {
+    const int total = Cout * Cin * KH * KW, q = threadIdx.x & 3;
+    const int total_r = (total + 63) / 64 * 64;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < total_r; i += (gridDim.x * blockDim.x) >> 2) {
+        const bool live = i < total;
+        int ii = live ? i : 0;
+        int kw = ii % KW, r1 = ii / KW;
+        int kh = r1 % KH, r2 = r1 / KH;
+        int ci = r2 % Cin, co = r2 / Cin;
+        const float* sp = slab + (size_t)co * Kp + kh * Rp + lead + kw * Cin + ci;
+        float a = 0.f;
+        for (int s = q; s < nslabs; s += 4) a += sp[(size_t)s * 64 * Kp];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (q == 0 && live) dw[ii] = accumulate ? dw[ii] + a : a;
+    }
+}
+
+// weights: wpk[co][kh*Rp + lead + kw*Cin + ci] = w[co][ci][kh][kw], zero elsewhere ([64][Kp])
+template <typename T>
+__global__ void rowpatch_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout,
+                                     int Cin, int KH, int KW, int Rp, int lead, int Kp) {
+    const int total = 64 * Kp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int co = i / Kp, k = i - co * Kp;
+        int kh = k / Rp, j = k - kh * Rp - lead;
+        float v = 0.f;
+        if (co < Cout && kh < KH && j >= 0 && j < KW * Cin) {
+            int kw = j / Cin, ci = j - kw * Cin;
+            v = w[(((size_t)co * Cin + ci) * KH + kh) * KW + kw];
+        }
+        out[i] = from_f32<T>(v);
+    }
+}
+
+bool make_rp(const cnk_conv_desc* d, RowPatchParams* out) {
+    RowPatchParams p = {};
+    const int es = d->dtype == CNK_BF16 ? 2 : 4, ch = 16 / es;
+    if (d->Cout > 64 || d->stride_h != d->stride_w || d->pad_h != d->pad_w) return false;
+    if ((d->W * d->Cin) % ch) return false;                       // 16-byte row loads
+    if (d->pad_h * d->Cin + 1 > PATCH_A0) return false;
+    if ((int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31)) return false;
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
+    p.KH = d->kh; p.KW = d->kw; p.s = d->stride_h; p.p = d->pad_h;
+    p.R = d->kw * d->Cin;
+    p.A0 = PATCH_A0;
+    // lead: make (A0 - p*Cin - lead) even when every run start then is 4-byte aligned (bf16, even s*Cin)
+    p.lead = (es == 2 && ((p.s * p.Cin) % 2 == 0) && ((PATCH_A0 - p.p * p.Cin) & 1)) ? 1 : 0;
+    p.Rp = (p.R + p.lead + ch - 1) / ch * ch;
+    int kraw = p.KH * p.Rp;
+    p.Kp = (kraw + 31) / 32 * 32;
+    // patch row: A0 lead-in, (W+p)*Cin data+right pad, then the largest over-read (Rp) and chunk rounding
+    int need = PATCH_A0 + (p.W + p.p) * p.Cin + p.Rp + 2 * ch;
+    p.PWE = (need + ch - 1) / ch * ch;
+    p.rows_total = d->N * Ho;
+    size_t lds_f = (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + 1) * p.PWE * es + (size_t)4 * 32 * (64 * es + 16);
+    size_t lds_w = (size_t)(p.KH + 1) * p.PWE * es + (size_t)((Wo + 31) / 32 * 32) * (64 * es + (es == 2 ? 64 : 0));
+    if (lds_f > 150 * 1024 || lds_w > 150 * 1024) return false;
+    if (2 * (p.Kp / 32) > 4 * 6) return false;                   // wgrad accumulator budget (NBLK <= 6)
+    *out = p;
+    return true;
+}
+
+bool rp_align4(const cnk_conv_desc* d, const RowPatchParams& p) {
+    return d->dtype == CNK_BF16 && ((p.s * p.Cin) % 2 == 0) && (((PATCH_A0 - p.p * p.Cin - p.lead) & 1) == 0);
+}
+
+int rp_rows_per_wg(const RowPatchParams& p, int target_wgs) {
+    int r = ceil_div(p.rows_total, target_wgs);
+    return r < 1 ? 1 : r;
+}
+
+}  // namespace
+
+bool rowpatch_supported(const cnk_conv_desc* d) {
+    RowPatchParams p;
+    int kstep = d->dtype == CNK_BF16 ? 64 : 32;
+    if (d->Cin % kstep == 0 && d->Cout % 64 == 0) return false;   // implicit-GEMM tiles fit
+    if (d->Cin > 4) return false;
+    return make_rp(d, &p);
+}
+
+size_t rowpatch_packed_bytes(const cnk_conv_desc* d) {
+    RowPatchParams p;
+    make_rp(d, &p);
+    return (size_t)64 * p.Kp * (d->dtype == CNK_BF16 ? 2 : 4);
+}
+
+int rowpatch_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s) {
+    RowPatchParams p;
+    make_rp(d, &p);
+    int grid = ceil_div(64 * p.Kp, 256);
+    if (d->dtype == CNK_BF16)
+        hipLaunchKernelGGL(rowpatch_pack_kernel<bf16>, dim3(grid), dim3(256), 0, s, w, (bf16*)out, d->Cout, d->Cin, d->kh, d->kw, p.Rp, p.lead, p.Kp);
+    else
+        hipLaunchKernelGGL(rowpatch_pack_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, d->Cout, d->Cin, d->kh, d->kw, p.Rp, p.lead, p.Kp);
+    CNK_CHECK_LAUNCH("rowpatch_pack");
+    return 0;
+}
+
+int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y,
+                 hipStream_t s) {
+    RowPatchParams p;
+    make_rp(d, &p);
+    p.x = x; p.wpk = wpk; p.y = y; p.bias = bias;
+    p.rows_per_wg = rp_rows_per_wg(p, 4096);
+    int grid = ceil_div(p.rows_total, p.rows_per_wg);
+    const int es = d->dtype == CNK_BF16 ? 2 : 4;
+    size_t lds = (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + 1) * p.PWE * es + (size_t)4 * 32 * (64 * es + 16);
+    if (d->dtype == CNK_BF16) {
+        if (rp_align4(d, p)) hipLaunchKernelGGL((rowpatch_fwd_kernel<bf16, true>), dim3(grid), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((rowpatch_fwd_kernel<bf16, false>), dim3(grid), dim3(256), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((rowpatch_fwd_kernel<float, true>), dim3(grid), dim3(256), lds, s, p);
+    }
+    CNK_CHECK_LAUNCH("rowpatch_fwd");
+    return 0;
+}
+
+static int rp_wgrad_grid(const RowPatchParams& p, int* rows_per_wg) {
+    *rows_per_wg = rp_rows_per_wg(p, 1024);
+    return ceil_div(p.rows_total, *rows_per_wg);
+}
+
+size_t rowpatch_wgrad_workspace(const cnk_conv_desc* d) {
+    RowPatchParams p;
+    make_rp(d, &p);
+    int rpw;
+    int grid = rp_wgrad_grid(p, &rpw);
+    return (size_t)grid * 64 * p.Kp * sizeof(float);
+}
+
+int rowpatch_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate,
+                   void* ws, size_t ws_bytes, hipStream_t s) {
+    RowPatchParams p;
+    make_rp(d, &p);
+    int grid = rp_wgrad_grid(p, &p.rows_per_wg);
+    size_t need = (size_t)grid * 64 * p.Kp * sizeof(float);
+    CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad(rowpatch): workspace too small (%zu < %zu)", ws_bytes, need);
+    p.x = x; p.dy = dy; p.slab = (float*)ws;
+    const int es = d->dtype == CNK_BF16 ? 2 : 4;
+    size_t lds = (size_t)(p.KH + 1) * p.PWE * es + (size_t)((p.Wo + 31) / 32 * 32) * (64 * es + (es == 2 ? 64 : 0));
+    int nblk = 2 * (p.Kp / 32), per_wave = ceil_div(nblk, 4);
+#define RP_LAUNCH(TT, NB) hipLaunchKernelGGL((rowpatch_wgrad_kernel<TT, NB>), dim3(grid), dim3(256), lds, s, p)
+    if (d->dtype == CNK_BF16) {
+        if (per_wave <= 1) RP_LAUNCH(bf16, 1); else if (per_wave <= 2) RP_LAUNCH(bf16, 2);
+        else if (per_wave <= 3) RP_LAUNCH(bf16, 3); else if (per_wave <= 4) RP_LAUNCH(bf16, 4);
+        else RP_LAUNCH(bf16, 6);
+    } else {
+        if (per_wave <= 1) RP_LAUNCH(float, 1); else if (per_wave <= 2) RP_LAUNCH(float, 2);
+        else if (per_wave <= 3) RP_LAUNCH(float, 3); else if (per_wave <= 4) RP_LAUNCH(float, 4);
+        else RP_LAUNCH(float, 6);
+    }
+#undef RP_LAUNCH
+    CNK_CHECK_LAUNCH("rowpatch_wgrad");
+    int total = d->Cout * d->Cin * d->kh * d->kw;
+    int rgrid = ceil_div(total * 4, 256);
+    hipLaunchKernelGGL(rowpatch_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)ws, dw, grid, d->Cout,
+                       d->Cin, d->kh, d->kw, p.Rp, p.lead, p.Kp, accumulate);
+    CNK_CHECK_LAUNCH("rowpatch_reduce");
+    return 0;
+}

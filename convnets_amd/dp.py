@@ -46,19 +46,25 @@ class GradReducer:
                 self.bucket_of[i] = b
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                        for i, p in enumerate(self.params) if p.requires_grad]
+        # kernels that accumulate straight into the arena (convnets_amd.ops) report here instead
+        from . import ops
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._listener = lambda p: self._param_ready(self._index.get(id(p)))
+        ops._grad_ready_listeners.append(self._listener)
         self._pending, self._launched, self._works = None, None, None
         if flat_param is not None and self.world > 1:
             dist.broadcast(flat_param, src=0, group=process_group)      # identical replicas
 
+    def _param_ready(self, i):
+        if self._pending is None or i is None:
+            return
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
     def _make_hook(self, i):
-        def hook(_param):
-            if self._pending is None:
-                return
-            b = self.bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
-        return hook
+        return lambda _param: self._param_ready(i)
 
     def begin_step(self):
         self._pending = [sum(1 for i in ids if self.params[i].requires_grad) for _, _, ids in self.buckets]
@@ -96,8 +102,11 @@ class GradReducer:
         self._pending = None
 
     def remove(self):
+        from . import ops
         for h in self._hooks:
             h.remove()
+        if self._listener in ops._grad_ready_listeners:
+            ops._grad_ready_listeners.remove(self._listener)
 
 
 def attach(model, bucket_bytes=32 << 20, process_group=None):

@@ -28,6 +28,25 @@ def weights_epoch():
     return _weights_epoch[0]
 
 
+# Called with a parameter whose .grad was written in place by a kernel (no autograd accumulation,
+# hence no post-accumulate hook): the data-parallel reducer subscribes here.
+_grad_ready_listeners = []
+
+
+def _grad_written(param):
+    for cb in _grad_ready_listeners:
+        cb(param)
+
+
+def _arena_grad(param):
+    """The parameter's .grad if a kernel may accumulate into it directly (fp32, dense, same shape)."""
+    g = param.grad
+    if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape \
+            and g.device == param.device:
+        return g
+    return None
+
+
 def _dtype_code(t):
     if t.dtype == torch.float32:
         return CNK_F32
@@ -107,7 +126,9 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d forward / dgrad / wgrad (reference: basemodel.py:974)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, packed):
+    def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False):
+        """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
+        of y emitted by the conv epilogue (None when this conv shape cannot produce them)."""
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
@@ -119,14 +140,25 @@ class Conv2dFn(torch.autograd.Function):
         lib.cnk_conv2d_out_hw(ctypes.byref(desc), ctypes.byref(Ho), ctypes.byref(Wo))
         y = torch.empty((desc.N, desc.Cout, Ho.value, Wo.value), dtype=x.dtype, device=x.device,
                         memory_format=CL)
-        check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), None, 0,
-                                 _stream()))
+        partial = None
+        if want_bn_partial:
+            slices = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+            if slices > 0:
+                partial = torch.empty((slices, desc.Cout, 3), dtype=torch.float32, device=x.device)
+        check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial),
+                                 None, 0, _stream()))
         ctx.save_for_backward(x, w)
         ctx.desc, ctx.w_dgrad, ctx.has_bias = desc, w_dgrad, bias is not None
+        ctx.params = (weight, bias)
+        if want_bn_partial:
+            if partial is None:
+                partial = torch.empty(0, device=x.device)         # placeholder: "not available"
+            ctx.mark_non_differentiable(partial)
+            return y, partial
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
         x, w = ctx.saved_tensors
         desc = ctx.desc
@@ -137,14 +169,27 @@ class Conv2dFn(torch.autograd.Function):
             check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(dx), None, 0,
                                        _stream()))
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
-            if ctx.has_bias:
-                db = torch.empty((desc.Cout,), dtype=torch.float32, device=w.device)
+            weight, bias = ctx.params
+            # accumulate straight into .grad when it is a dense fp32 buffer (the flat arena): same
+            # result as autograd's `grad += dw`, without the extra kernel and tensor per parameter
+            gw = _arena_grad(weight) if weight.is_contiguous() else None
+            gb = _arena_grad(bias) if ctx.has_bias else None
+            direct = gw is not None and (not ctx.has_bias or gb is not None)
+            if direct:
+                dw_buf, db_buf = gw, gb
+            else:
+                dw_buf = dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+                db_buf = db = torch.empty((desc.Cout,), dtype=torch.float32, device=w.device) \
+                    if ctx.has_bias else None
             nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), PASS_WGRAD)
             ws = workspace(nws, x.device)
-            check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw), _p(db), 0, _p(ws),
-                                       ws.numel(), _stream()))
-        return dx, dw, db, None, None, None
+            check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
+                                       int(direct), _p(ws), ws.numel(), _stream()))
+            if direct:
+                _grad_written(weight)
+                if ctx.has_bias:
+                    _grad_written(bias)
+        return dx, dw, db, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -152,7 +197,8 @@ class BatchNormActFn(torch.autograd.Function):
     with `output += identity; F.relu(output)` (basemodel.py:1008-1012, resnet.py:191-194)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu,
+                partial=None):
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
@@ -166,17 +212,24 @@ class BatchNormActFn(torch.autograd.Function):
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        if partial is not None and partial.numel() == 0:
+            partial = None
+        nsl = 0 if partial is None else partial.shape[0]
         check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean),
-                                   _p(running_var), _p(save_mean), _p(save_invstd), M, C, eps,
-                                   momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
-        ctx.save_for_backward(x, y if relu else None, gamma, save_mean, save_invstd)
+                                   _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
+                                   M, C, eps, momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(),
+                                   _stream()))
+        # the ReLU mask needs y only with a residual operand; otherwise the backward re-derives it
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta,
+                              save_mean, save_invstd)
         ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        x, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
         dy = _nhwc(dy)
         N, C, H, W = x.shape
         M = N * H * W
@@ -188,13 +241,22 @@ class BatchNormActFn(torch.autograd.Function):
         else:
             dres = torch.empty_like(x, memory_format=CL) if want_res else None
             dres_out = dres
-        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        pg, pb = ctx.params
+        gg, gb = _arena_grad(pg), _arena_grad(pb)
+        direct = gg is not None and gb is not None
+        if direct:
+            dg_buf, db_buf, dgamma, dbeta = gg, gb, None, None
+        else:
+            dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+            db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
-        check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(save_mean), _p(save_invstd), _p(dx),
-                             _p(dres_out), _p(dgamma), _p(dbeta), 0, M, C, int(ctx.relu),
-                             _dtype_code(x), _p(ws), ws.numel(), _stream()))
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+        check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                             _p(dx), _p(dres_out), _p(dg_buf), _p(db_buf), int(direct), M, C,
+                             int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
+        if direct:
+            _grad_written(pg)
+            _grad_written(pb)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):

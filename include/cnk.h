@@ -63,9 +63,15 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
                             void* stream);
 
 /* y = conv2d(x, w) (+ bias).  nn.Conv2d.forward reached from basemodel.py:974 via :1004.
- * bias (fp32[Cout]) may be NULL: the reference has a bias only when batch_norm is off (:973). */
+ * bias (fp32[Cout]) may be NULL: the reference has a bias only when batch_norm is off (:973).
+ * Optional fusion with the BatchNorm2d that follows the conv in conv2d_block (:1008): when
+ * bn_partial is non-NULL the epilogue also emits, per 128-row output tile and channel, the
+ * (count, mean, M2) of the stored (rounded) outputs: bn_partial[slices][Cout][3] fp32 with
+ * slices = cnk_conv2d_fwd_bn_partial_slices(d) (0 when this conv shape cannot emit them);
+ * cnk_bn_fwd_train then skips its own statistics pass. */
+int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d);
 int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
-                   void* y, void* workspace, size_t workspace_bytes, void* stream);
+                   void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dx = conv2d_transpose(dy, w): autograd's input gradient of the call above
  * (loss.backward(), basemodel.py:258/278). */
@@ -83,23 +89,27 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
  * (resnet.py:151-154,191-194):   y = act( (x-mean)*invstd*gamma + beta [+ residual] ).
  * x,y,residual: [M][C] NHWC-flattened, M = N*H*W.  Batch mean / biased variance are computed in
  * fp32; running_mean/var (may be NULL) get momentum updates with the UNBIASED variance;
- * save_mean/save_invstd (fp32[C]) are outputs kept for the backward.
+ * save_mean/save_invstd (fp32[C]) are outputs kept for the backward.  partial/partial_slices:
+ * optional statistics partials from cnk_conv2d_fwd (NULL/0: computed here).
  * workspace: cnk_bn_workspace_bytes(M, C). */
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C);
 int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual,
                      void* y, float* running_mean, float* running_var, float* save_mean,
-                     float* save_invstd, int64_t M, int32_t C, float eps, float momentum,
-                     int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+                     float* save_invstd, const float* partial, int64_t partial_slices, int64_t M,
+                     int32_t C, float eps, float momentum, int relu, int dtype, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* Eval mode (valid_model, basemodel.py:311): running statistics, same fused epilogue. */
 int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* running_mean,
                     const float* running_var, const void* residual, void* y, int64_t M, int32_t C,
                     float eps, int relu, int dtype, void* stream);
 
-/* Backward of cnk_bn_fwd_train.  y is the forward OUTPUT (needed only when relu != 0: the mask is
- * taken from the output like nn.ReLU's backward).  dresidual (may be NULL) receives the gradient
- * of the residual operand (= masked dy).  dgamma/dbeta fp32[C]; accumulate as in wgrad. */
-int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma,
+/* Backward of cnk_bn_fwd_train.  The ReLU mask is taken from the forward OUTPUT like nn.ReLU's
+ * backward: from y when given; when y is NULL (allowed only without a residual operand) it is
+ * re-derived as x*scale+shift > 0 with the same fp32 arithmetic as the forward, which saves two
+ * full reads of y.  dresidual (may be NULL) receives the gradient of the residual operand
+ * (= masked dy).  dgamma/dbeta fp32[C]; accumulate as in wgrad. */
+int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
                float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu,
                int dtype, void* workspace, size_t workspace_bytes, void* stream);

@@ -71,6 +71,9 @@ RANDOM_CONVS = [
     (2, 64, 56, 56, 64, 3, 1, 1), (1, 1024, 14, 14, 2048, 1, 2, 0), (2, 3, 37, 41, 64, 7, 2, 3),
     (3, 6, 10, 10, 16, 5, 1, 0), (2, 32, 9, 9, 64, 5, 2, 1), (2, 16, 8, 8, 24, 3, 1, 1),
     (1, 128, 5, 5, 128, 3, 2, 1), (2, 64, 8, 8, 64, 3, 1, 0),
+    # row-patch first-layer kernels: ResNet stem (real width), VGG/AlexNet/LeNet-style first layers
+    (2, 3, 224, 224, 64, 7, 2, 3), (2, 3, 40, 40, 64, 7, 2, 3), (3, 3, 24, 32, 64, 3, 1, 1),
+    (1, 3, 64, 64, 64, 11, 4, 2), (2, 1, 32, 32, 16, 5, 1, 2), (2, 4, 18, 16, 48, 3, 2, 1),
 ]
 
 

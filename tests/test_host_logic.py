@@ -49,12 +49,14 @@ def test_host_side_planning_queries_run_without_gpu():
     stem = D(256, 224, 224, 3, 64, 7, 7, 2, 2, 3, 3, _lib.CNK_BF16)
     assert lib.cnk_conv2d_out_hw(ctypes.byref(stem), ctypes.byref(Ho), ctypes.byref(Wo)) == 0
     assert (Ho.value, Wo.value) == (112, 112)
-    assert lib.cnk_conv2d_packed_bytes(ctypes.byref(stem), _lib.PASS_FWD) == 64 * 160 * 2   # K 147 -> 160
+    assert lib.cnk_conv2d_packed_bytes(ctypes.byref(stem), _lib.PASS_FWD) == 64 * 192 * 2   # 7 runs of 24 -> K' 192
     assert lib.cnk_bn_workspace_bytes(256 * 56 * 56, 64) > 0
+    assert lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d)) == 256 * 56 * 56 // 128   # one per M tile
+    assert lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(stem)) == 0                  # small-C path: none
     # argument errors come back as codes + text, never exit/abort
     bad = D(1, 4, 4, 8, 8, 9, 9, 1, 1, 0, 0, _lib.CNK_F32)
     rc = lib.cnk_conv2d_fwd(ctypes.byref(bad), ctypes.c_void_p(16), ctypes.c_void_p(16), None,
-                            ctypes.c_void_p(16), None, 0, None)
+                            ctypes.c_void_p(16), None, None, 0, None)
     assert rc != 0 and b'kernel larger' in lib.cnk_last_error()
     with pytest.raises(_lib.CnkError):
         _lib.check(rc)
