@@ -12,13 +12,13 @@
 bool igemm_supported(const cnk_conv_desc* d, int pass);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
-int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, hipStream_t s);
+int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, hipStream_t s);
 int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
 bool wgrad_mfma_supported(const cnk_conv_desc* d);
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
 int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int direct_fwd(const cnk_conv_desc* d, const void* x, const void* w_t, const float* bias, void* y, hipStream_t s);
-int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s);
+int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend, hipStream_t s);
 size_t direct_wgrad_workspace(const cnk_conv_desc* d);
 int direct_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t colsum_workspace(int64_t M, int C);
@@ -210,15 +210,15 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
     return direct_fwd(d, x, w_fwd, bias, y, S(stream));
 }
 
-int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* workspace, size_t workspace_bytes, void* stream) {
+int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (int rc = check_desc(d, "cnk_conv2d_dgrad")) return rc;
     CNK_CHECK_ARG(dy && w_dgrad && dx, "cnk_conv2d_dgrad: null pointer");
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
-    if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, S(stream));
-    return direct_dgrad(d, dy, w_dgrad, dx, S(stream));
+    if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, addend, S(stream));
+    return direct_dgrad(d, dy, w_dgrad, dx, addend, S(stream));
 }
 
 int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {

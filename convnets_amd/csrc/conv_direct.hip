@@ -12,6 +12,7 @@ struct DirectParams {
     const void* b;      // fwd: w_t    dgrad: w_t    wgrad: x
     void* out;          // fwd: y      dgrad: dx     wgrad: slab
     const float* bias;
+    const void* addend; // dgrad: optional tensor added to dx
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw;
     int M;              // fwd/wgrad: N*Ho*Wo   dgrad: N*H*W
     int chunk;          // wgrad: pixels per grid.y slice
@@ -67,7 +68,9 @@ template <typename T> __global__ void direct_dgrad_kernel(const DirectParams p) 
             for (int co = 0; co < p.Cout; ++co) acc += to_f32(dp[co]) * wp[co];
         }
     }
-    ((T*)p.out)[(size_t)m * p.Cin + ci] = from_f32<T>(acc);
+    T o = from_f32<T>(acc);
+    if (p.addend) o = from_f32<T>(to_f32(o) + to_f32(((const T*)p.addend)[(size_t)m * p.Cin + ci]));
+    ((T*)p.out)[(size_t)m * p.Cin + ci] = o;
 }
 
 // slab[slice][t][ci][co] = sum over the slice's pixels of dy[m][co] * x[src(m,t)][ci]
@@ -175,9 +178,10 @@ int direct_fwd(const cnk_conv_desc* d, const void* x, const void* w_t, const flo
     return 0;
 }
 
-int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s) {
+int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
+                 hipStream_t s) {
     DirectParams p = make_params(d);
-    p.a = dy; p.b = w_t; p.out = dx;
+    p.a = dy; p.b = w_t; p.out = dx; p.addend = addend;
     p.M = d->N * d->H * d->W;
     p.fd_a = make_fastdiv(d->H * d->W); p.fd_b = make_fastdiv(d->W);
     dim3 block(64, 4), grid(ceil_div(p.M, 4), ceil_div(d->Cin, 64));

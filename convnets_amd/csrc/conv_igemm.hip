@@ -12,7 +12,7 @@
 // (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for exact fp32).  Global -> registers ->
 // LDS staging, double-buffered LDS, one barrier per K step; LDS rows are 128 B with the 16-byte
 // chunk index XORed by (row>>1)&7 so every ds_read_b128 lane group hits 16 distinct bank slots.
-#include <type_traits>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -26,6 +26,7 @@ struct GatherParams {
     const void* wpk;
     void* dst;
     const float* bias;
+    const void* addend;      // optional tensor shaped like dst: dst = conv + addend (fused grad sum)
     float* stats;            // optional [tiles_m][Nout][3] BN partials (n, mean, M2) of the OUTPUT
     int N, IH, IW, C;
     int OH, OW;
@@ -58,8 +59,8 @@ template <> struct Mma32<float> {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
 
-template <typename T, int BN>
-__global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams p) {
+template <typename T, int BN, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void igemm_gather_kernel(const GatherParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
     constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
     constexpr int NJ = BN / 64;                      // 32-wide MFMA blocks per wave along n
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* row_dst = (int*)smem;                       // [128] dst pixel per tile row (-1: none)
     unsigned char* As = smem + BM * sizeof(int);     // [2][128][128 B]
-    unsigned char* Bs = As + 2 * BM * 128;           // [2][BN][128 B]
+    unsigned char* Bs = As + NBUF * BM * 128;        // [NBUF][BN][128 B]
 
     // XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
     // run of tiles so neighbours (same A rows, other n tile; adjacent pixels) share L2 lines.
@@ -118,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams
     const int nk = p.ntaps * csteps;
     const size_t wrow = (size_t)p.ntaps * p.C;
 
-    // Two register staging sets: tile t is loaded into set t&1 two K steps before it is consumed
-    // and written to LDS buffer t&1 one step before, so a global load has two MFMA phases (plus the
-    // co-resident workgroup) to land instead of one.
-    u32x4 ra[2][4], rb[2][B_LOADS];
+    // Register-staged pipeline, prefetch distance 1: the global loads of tile ks+1 are issued before
+    // the MFMA phase of tile ks and written to LDS after it.  NBUF = 2: double-buffered LDS, one
+    // barrier per K step (64 KiB -> 2 workgroups/CU).  NBUF = 1: one LDS buffer, two barriers per
+    // step, half the LDS -> 3 workgroups/CU (register-limited), i.e. more loads in flight per CU.
+    u32x4 ra[4], rb[B_LOADS];
     int ld_t = 0, ld_cs = 0;                         // (tap, channel step) of the next load_step
-    auto load_step = [&](auto SET) {
-        constexpr int S = decltype(SET)::value;
+    auto load_step = [&]() {
         const int t = ld_t, c0 = ld_cs * KSTEP + chunk * PER16;
         if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
         int dh = p.dh[t], dw = p.dw[t];
@@ -137,26 +138,25 @@ __global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams
                 size_t off = ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + c0;
                 v = *(const u32x4*)(src + off);
             }
-            ra[S][i] = v;
+            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             int n = tile_n * BN + lrow + 32 * i;
             size_t off = (size_t)n * wrow + (size_t)t * p.C + c0;
-            rb[S][i] = *(const u32x4*)(wpk + off);
+            rb[i] = *(const u32x4*)(wpk + off);
         }
     };
-    auto store_step = [&](auto SET) {
-        constexpr int S = decltype(SET)::value;
+    auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = lrow + 32 * i;
-            *(u32x4*)(As + S * (BM * 128) + r * 128 + swz(r, chunk)) = ra[S][i];
+            *(u32x4*)(As + buf * (BM * 128) + r * 128 + swz(r, chunk)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             int r = lrow + 32 * i;
-            *(u32x4*)(Bs + S * (BN * 128) + r * 128 + swz(r, chunk)) = rb[S][i];
+            *(u32x4*)(Bs + buf * (BN * 128) + r * 128 + swz(r, chunk)) = rb[i];
         }
     };
 
@@ -169,12 +169,16 @@ __global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    auto compute = [&](auto BUF) {
-        constexpr int S = decltype(BUF)::value;
-        const unsigned char* Ab = As + S * (BM * 128);
-        const unsigned char* Bb = Bs + S * (BN * 128);
+    if (nk > 0) {
+        load_step();
+        store_step(0);
+    }
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = NBUF == 2 ? (ks & 1) : 0;
+        if (ks + 1 < nk) load_step();
+        const unsigned char* Ab = As + buf * (BM * 128);
+        const unsigned char* Bb = Bs + buf * (BN * 128);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 fa[2], fb[NJ];
@@ -193,24 +197,8 @@ __global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) Mma32<T>::run(acc[i][j], fb[j], fa[i]);   // C^T block
         }
-    };
-    if (nk > 0) {
-        load_step(I0{});
-        store_step(I0{});
-        if (nk > 1) load_step(I1{});
-    }
-    __syncthreads();
-    for (int ks = 0; ks < nk; ks += 2) {
-        // even step: consume buffer 0, prefetch tile ks+2 into set 0, publish tile ks+1 (set 1)
-        if (ks + 2 < nk) load_step(I0{});
-        compute(I0{});
-        if (ks + 1 < nk) store_step(I1{});
-        __syncthreads();
-        if (ks + 1 >= nk) break;
-        // odd step
-        if (ks + 3 < nk) load_step(I1{});
-        compute(I1{});
-        if (ks + 2 < nk) store_step(I0{});
+        if (NBUF == 1) __syncthreads();              // every wave is done reading the only buffer
+        if (ks + 1 < nk) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -259,7 +247,14 @@ __global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams
         if (pix >= 0) {
             Vec16<T> v;
             v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
-            *(decltype(v.v)*)(dst + ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16) = v.v;
+            const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
+            if (p.addend) {              // same rounding as a separate add kernel: round(round(conv) + addend)
+                Vec16<T> a;
+                a.v = *(const decltype(a.v)*)((const unsigned char*)p.addend + goff);
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + a.get(e));
+            }
+            *(decltype(v.v)*)(dst + goff) = v.v;
             if (p.stats) {
 #pragma unroll
                 for (int e = 0; e < PER16; ++e) {
@@ -299,13 +294,26 @@ __global__ __launch_bounds__(256, 2) void igemm_gather_kernel(const GatherParams
     }
 }
 
-template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
-    size_t pipe = 2 * BM * 128 + 2 * BN * 128;
+template <typename T, int BN, int NBUF> int launch_gather_v(const GatherParams& p, hipStream_t s) {
+    size_t pipe = NBUF * (BM * 128 + BN * 128);
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16) + (p.stats ? 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float) : 0);
     size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
-    hipLaunchKernelGGL((igemm_gather_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, NBUF>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
+}
+
+static int igemm_nbuf() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CNK_IGEMM_NBUF");
+        v = (e && e[0] == '2') ? 2 : 1;      // measured: 1 buffer / 3 WGs per CU wins (latency-bound loop)
+    }
+    return v;
+}
+
+template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
+    return igemm_nbuf() == 1 ? launch_gather_v<T, BN, 1>(p, s) : launch_gather_v<T, BN, 2>(p, s);
 }
 
 static bool pick_bn128(int M, int Nout) {
@@ -394,7 +402,7 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w]
 }
 
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                hipStream_t s) {
+                const void* addend, hipStream_t s) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     DgradClass cls[16];
@@ -406,6 +414,7 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
         const DgradClass& k = cls[c];
         GatherParams p = {};
         p.src = dy; p.wpk = (const char*)w_dgrad + woff * esz; p.dst = dx; p.bias = nullptr;
+        p.addend = addend;
         p.N = d->N; p.IH = Ho; p.IW = Wo; p.C = d->Cout;
         p.OH = k.OH; p.OW = k.OW; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
         p.sm_h = 1; p.sm_w = 1;

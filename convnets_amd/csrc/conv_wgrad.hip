@@ -10,6 +10,8 @@
 // workgroups (split-K); each writes an fp32 partial slab [split][co][t][ci] with plain stores and a
 // second kernel sums the slabs in fixed order (deterministic, unlike float atomics), applies the
 // .grad accumulation and re-lays into the master layout [Cout][Cin][kh][kw].
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -35,8 +37,8 @@ template <> struct WgCfg<float> {
     static constexpr int PAD = 0;
 };
 
-template <typename T, int BMW, int BNW>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
+template <typename T, int BMW, int BNW, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(const WgradParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;
     constexpr int KP = WgCfg<T>::KP;
     constexpr int ROWA = BMW * (int)sizeof(T) + WgCfg<T>::PAD;
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
     constexpr int PASSA = KP * CPRA / 256, PASSB = KP * CPRB / 256;
     constexpr int TM = BMW / 64, TN = BNW / 64;                // 32x32 blocks per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                      // [2][KP][ROWA]
-    unsigned char* Bs = smem + 2 * KP * ROWA;      // [2][KP][ROWB]
+    unsigned char* As = smem;                      // [NBUF][KP][ROWA]
+    unsigned char* Bs = smem + NBUF * KP * ROWA;   // [NBUF][KP][ROWB]
 
     int bid = blockIdx.x;
     const int tiles_nc = p.ntaps * p.tiles_ci;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
     }
     __syncthreads();
     for (int ks = ks0; ks < ks1; ++ks) {
-        const int buf = (ks - ks0) & 1;
+        const int buf = NBUF == 2 ? ((ks - ks0) & 1) : 0;
         if (ks + 1 < ks1) load_step(ks + 1);
         const unsigned char* Ab = As + buf * (KP * ROWA);
         const unsigned char* Bb = Bs + buf * (KP * ROWB);
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
                                                                          0, 0);
             }
         }
-        if (ks + 1 < ks1) store_step(buf ^ 1);
+        if (NBUF == 1) __syncthreads();          // all waves finished reading the single buffer
+        if (ks + 1 < ks1) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -246,11 +249,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     }
 }
 
+static int wgrad_nbuf() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CNK_WGRAD_NBUF");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+
 template <typename T, int BMW, int BNW> int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int KP = WgCfg<T>::KP;
-    size_t lds = 2 * KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + 2 * KP * (BNW * sizeof(T) + WgCfg<T>::PAD);
+    const int nb = wgrad_nbuf();
+    size_t lds = nb * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));
     int grid = p.splits * p.tiles_co * p.ntaps * p.tiles_ci;
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW>), dim3(grid), dim3(256), lds, s, p);
+    if (nb == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2>), dim3(grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 1>), dim3(grid), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("wgrad_mfma");
     return 0;
 }

@@ -39,16 +39,16 @@ class Conv2d(nn.Conv2d):
             new.__dict__[k] = ops.PackedWeights() if k == '_packed' else copy.deepcopy(v, memo)
         return new
 
-    def forward(self, x, want_bn_partial=False):
+    def forward(self, x, want_bn_partial=False, link=None):
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
-                                  self._packed, want_bn_partial)
+                                  self._packed, want_bn_partial, link)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d; `forward(x, residual=None, relu=False)` exposes the fused epilogue used by
     ConvBlock and the residual blocks.  Called plainly it is exactly BatchNorm2d."""
 
-    def forward(self, x, residual=None, relu=False, partial=None):
+    def forward(self, x, residual=None, relu=False, partial=None, link=None):
         if not (self.affine and self.track_running_stats):
             raise NotImplementedError('convnets_amd.BatchNorm2d: affine=True, '
                                       'track_running_stats=True only (the factory default)')
@@ -57,7 +57,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                 raise NotImplementedError('convnets_amd.BatchNorm2d: cumulative momentum (None)')
             y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
                                          self.running_var, float(self.eps), float(self.momentum),
-                                         bool(relu), partial)
+                                         bool(relu), partial, link)
             self.num_batches_tracked += 1
             return y
         return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var,
@@ -100,17 +100,20 @@ class ConvBlock(nn.Sequential):
     with children '0','1','2' (same state_dict keys), whose forward runs BN + ReLU (+ the residual
     add of the enclosing block) as ONE fused kernel pass instead of three."""
 
-    def forward(self, x, residual=None, relu_after_add=False):
+    def forward(self, x, residual=None, relu_after_add=False, in_link=None, res_link=None):
+        """in_link: GradLink shared with the other consumer of x (fused gradient sum at a residual
+        block's input); res_link: the same link seen from the residual operand's side."""
         mods = list(self)
         conv = mods[0]
         bn = mods[1] if len(mods) > 1 and isinstance(mods[1], BatchNorm2d) else None
         act = isinstance(mods[-1], ReLU)
         if bn is not None:
             if bn.training:      # the conv epilogue also emits the BN statistics partials
-                y, partial = conv(x, want_bn_partial=True)
-                return bn(y, residual=residual, relu=act or relu_after_add, partial=partial)
+                y, partial = conv(x, want_bn_partial=True, link=in_link)
+                return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
+                          link=res_link)
             return bn(conv(x), residual=residual, relu=act or relu_after_add)
-        y = conv(x)
+        y = conv(x, link=in_link)
         if residual is not None:
             if act:
                 y = ops.ReLUFn.apply(y)

@@ -95,6 +95,29 @@ def make_desc(x_shape, weight_shape, stride, padding, dtype_code):
                     dtype_code)
 
 
+class GradLink:
+    """Hands the gradient of one consumer of a tensor to another consumer's backward so the sum of
+    the two is formed inside a kernel epilogue instead of by autograd's accumulation pass.
+    Used at a residual block's input x, consumed by the block's first conv and by the shortcut
+    (identity: the last BN's residual operand; projection: the dim_synch conv).  Whichever
+    backward runs first parks its gradient here and reports None to autograd; the one that runs
+    last folds the parked tensor in (conv dgrad: fused `addend`) and returns the total."""
+
+    def __init__(self, count=2):
+        self.count, self.arrived, self.parked = count, 0, None
+
+    def contribute(self, make_grad):
+        """make_grad(addend_or_None) -> gradient tensor.  Returns the tensor to report to autograd
+        (None for all but the last contributor)."""
+        self.arrived += 1
+        if self.arrived < self.count:
+            g = make_grad(None)
+            self.parked = g if self.parked is None else self.parked + g
+            return None
+        parked, self.arrived, self.parked = self.parked, 0, None
+        return make_grad(parked)
+
+
 class PackedWeights:
     """The two operand images of one conv weight (cnk_conv2d_pack_weights), re-made when the
     master weight changes."""
@@ -126,9 +149,10 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d forward / dgrad / wgrad (reference: basemodel.py:974)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False):
+    def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None):
         """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
-        of y emitted by the conv epilogue (None when this conv shape cannot produce them)."""
+        of y emitted by the conv epilogue (None when this conv shape cannot produce them).
+        link: optional GradLink shared with the other consumer of x (residual blocks)."""
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
@@ -150,6 +174,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.desc, ctx.w_dgrad, ctx.has_bias = desc, w_dgrad, bias is not None
         ctx.params = (weight, bias)
+        ctx.link = link if x.requires_grad else None
         if want_bn_partial:
             if partial is None:
                 partial = torch.empty(0, device=x.device)         # placeholder: "not available"
@@ -165,9 +190,14 @@ class Conv2dFn(torch.autograd.Function):
         dy = _nhwc(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=CL)
-            check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(dx), None, 0,
-                                       _stream()))
+            def dgrad(addend):
+                if addend is not None:
+                    addend = _nhwc(addend)
+                out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=CL)
+                check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(out),
+                                           _p(addend), None, 0, _stream()))
+                return out
+            dx = ctx.link.contribute(dgrad) if ctx.link is not None else dgrad(None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             weight, bias = ctx.params
             # accumulate straight into .grad when it is a dense fp32 buffer (the flat arena): same
@@ -189,7 +219,7 @@ class Conv2dFn(torch.autograd.Function):
                 _grad_written(weight)
                 if ctx.has_bias:
                     _grad_written(bias)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -198,7 +228,7 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu,
-                partial=None):
+                partial=None, link=None):
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
@@ -224,6 +254,7 @@ class BatchNormActFn(torch.autograd.Function):
                               save_mean, save_invstd)
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.params = (gamma, beta)
+        ctx.link = link if (residual is not None and residual.requires_grad) else None
         return y
 
     @staticmethod
@@ -256,7 +287,11 @@ class BatchNormActFn(torch.autograd.Function):
         if direct:
             _grad_written(pg)
             _grad_written(pb)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        if ctx.link is not None and dres is not None:
+            # identity shortcut: park the residual gradient for the block's first conv, whose
+            # dgrad epilogue adds it (falls back to a plain add if this backward is the last one)
+            dres = ctx.link.contribute(lambda parked: dres if parked is None else dres + parked)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):

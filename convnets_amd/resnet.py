@@ -6,9 +6,20 @@ Module names match the reference so state_dict keys interchange (features.2.dim_
 features.2.res_bottleneck.1.1.running_var, classifier.1.weight, ...).  The block tail
 `output += identity; output = F.relu(output)` (:191-194) is fused into the last BN's apply pass.
 """
+import torch
 import torch.nn as nn
 
 from .basemodel import MultiClassBaseModel
+
+
+def _input_link(block, x):
+    """The block input x feeds the main branch and the shortcut; in training their two gradients
+    are summed inside the last-running conv dgrad (ops.GradLink) instead of by autograd."""
+    from . import ops
+    first = block.res_block[0] if hasattr(block, 'res_block') else block.res_bottleneck[0]
+    fused = block.training and torch.is_grad_enabled() and x.requires_grad and len(first) > 1 \
+        and isinstance(first[1], nn.BatchNorm2d)
+    return ops.GradLink(2) if fused else None
 
 
 class ResBlock(nn.Module):                                   # src/resnet.py:119-156
@@ -21,8 +32,12 @@ class ResBlock(nn.Module):                                   # src/resnet.py:119
                                  kernel_size=3, padding=1))
 
     def forward(self, x):
-        identity = x if self.dim_synch is None else self.dim_synch(x)
-        output = self.res_block[0](x)
+        link = _input_link(self, x)
+        if self.dim_synch is None:
+            output = self.res_block[0](x, in_link=link)
+            return self.res_block[1](output, residual=x, relu_after_add=True, res_link=link)
+        identity = self.dim_synch(x, in_link=link)
+        output = self.res_block[0](x, in_link=link)
         return self.res_block[1](output, residual=identity, relu_after_add=True)
 
 
@@ -37,8 +52,13 @@ class ResBottleneck(nn.Module):                              # src/resnet.py:158
                                  kernel_size=1))
 
     def forward(self, x):
-        identity = x if self.dim_synch is None else self.dim_synch(x)
-        output = self.res_bottleneck[0](x)
+        link = _input_link(self, x)
+        if self.dim_synch is None:
+            output = self.res_bottleneck[0](x, in_link=link)
+            output = self.res_bottleneck[1](output)
+            return self.res_bottleneck[2](output, residual=x, relu_after_add=True, res_link=link)
+        identity = self.dim_synch(x, in_link=link)
+        output = self.res_bottleneck[0](x, in_link=link)
         output = self.res_bottleneck[1](output)
         return self.res_bottleneck[2](output, residual=identity, relu_after_add=True)
 

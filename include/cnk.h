@@ -73,10 +73,13 @@ int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d);
 int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
                    void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream);
 
-/* dx = conv2d_transpose(dy, w): autograd's input gradient of the call above
- * (loss.backward(), basemodel.py:258/278). */
+/* dx = conv2d_transpose(dy, w) [+ addend]: autograd's input gradient of the call above
+ * (loss.backward(), basemodel.py:258/278).  `addend` (may be NULL; shaped like dx) is the
+ * gradient arriving at the same tensor through another branch -- the identity / projection
+ * shortcut of a residual block (resnet.py:141-151,181-191); summing it in the epilogue replaces
+ * the separate accumulation pass autograd would run. */
 int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     const void* addend, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[Cout][Cin][kh][kw] (fp32) = sum over N,Ho,Wo of dy * x ; dbias[Cout] = sum dy (may be NULL).
  * accumulate != 0 adds into dw/dbias (torch's .grad accumulation), else overwrites. */
