@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
 CONV_CLASSES = ['conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'conv1x1_fwd', 'conv1x1_dgrad',
                 'conv1x1_wgrad']
+# kernel -> the cnk_prof classes its launches fall in.  The implicit-GEMM gather kernel runs the
+# forward AND the data gradient of every 3x3 / 1x1 conv, so it is timed as one kernel.
+KERNELS = {'igemm_gather_kernel (conv fwd+dgrad, 3x3 and 1x1)': ['conv3x3_fwd', 'conv3x3_dgrad', 'conv1x1_fwd', 'conv1x1_dgrad'],
+           'wgrad_mfma_kernel (conv wgrad, 3x3 and 1x1)': ['conv3x3_wgrad', 'conv1x1_wgrad']}
 MODEL_CFG = {
     'resnet50': ('resnet', 50, (3, 224, 224), 1000, 256),
     'resnet152': ('resnet', 152, (3, 224, 224), 1000, 128),
@@ -40,6 +44,23 @@ def prof_collect(lib, cls_bit):
     rc = lib.cnk_prof_collect(cls_bit, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
     assert rc == 0
     return n.value, ms.value, fl.value, by.value
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM);
+    bench.py cannot drive the profiler itself, so this is the last profiled value, or None."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    try:
+        tab = json.load(open(path))
+        for k, v in tab.get('kernels', {}).items():
+            if k.split(' ')[0] in kernel:
+                return v
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(model_key, dtype_note):
@@ -83,11 +104,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        distributed = True
     else:
+        distributed = False
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
 
@@ -102,7 +125,7 @@ def main():
                           mixed_precision=args.dtype == 'bf16', device=dev)
     model = ca.MODELS[family](setting).to(dev)
     model.init_optimizer()
-    if world > 1:
+    if world > 1 or os.environ.get('CNK_DP_FORCE') == '1':
         dp.attach(model)
     model.train()
     g = torch.Generator(device=dev).manual_seed(21 + rank)  # each rank its own shard of synthetic data
@@ -111,7 +134,7 @@ def main():
     batch = (x, y)
 
     def sync():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,22 +149,26 @@ def main():
             torch.cuda.synchronize()
             table = {name: prof_collect(lib, _lib.CLS[name]) for name in _lib.CLS}
             lib.cnk_prof_end()
-    dom = max(CONV_CLASSES, key=lambda k: table[k][1])
+    dom_kernel = max(KERNELS, key=lambda k: sum(table[c][1] for c in KERNELS[k]))
+    dom_mask = 0
+    for c in KERNELS[dom_kernel]:
+        dom_mask |= _lib.CLS[c]
     if args.breakdown and rank == 0:
         for name, (n, ms, fl, by) in sorted(table.items(), key=lambda kv: -kv[1][1]):
             print('  %-14s n=%4d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)' %
                   (name, n, ms, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0), file=sys.stderr)
 
-    lib.cnk_prof_begin(_lib.CLS[dom])
+    lib.cnk_prof_begin(dom_mask)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = model.train_batch(batch)
     sync()
     elapsed = time.perf_counter() - t0
-    n_l, ms_l, fl_l, by_l = prof_collect(lib, _lib.CLS[dom])
+    n_l, ms_l, fl_l, by_l = prof_collect(lib, dom_mask)
+    per_class = {c: prof_collect(lib, _lib.CLS[c]) for c in KERNELS[dom_kernel]}
     lib.cnk_prof_end()
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -163,14 +190,17 @@ def main():
                                    % (args.model, in_size[1], in_size[2], bs),
                        'global_batch': world * bs, 'parallelism': 'dp%d' % world,
                        'final_loss': round(loss_val, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None,
-                         'launches': n_l, 'avg_launch_ms': round(ms_l / n_l, 4) if n_l else None},
+            'roofline': {'bound': 'mfma', 'kernel': dom_kernel, 'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                         'traffic': pmc_traffic(dom_kernel),
+                         'launches': n_l, 'avg_launch_ms': round(ms_l / n_l, 4) if n_l else None,
+                         'avg_launch_gflop': round(fl_l / n_l / 1e9, 3) if n_l else None,
+                         'by_class_tflops': {c: round(v[2] / v[1] / 1e9, 1) for c, v in per_class.items() if v[1] > 0}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model, args.dtype)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -49,11 +49,20 @@ struct SliceGeom {
 SliceGeom make_geom(int64_t M, int C, int vec) {
     SliceGeom g;
     g.cols = C / vec;
-    g.cpb = g.cols < 256 ? g.cols : 256;
+    // <= 32 vector columns (512 B of a row) per block: wide-C tensors then have 8 row-threads per
+    // column and spread their column groups over grid.y, so small late-stage tensors still launch
+    // ~2048 blocks without shrinking the rows per slice (each slice costs C*12 B of partials)
+    g.cpb = g.cols < 32 ? g.cols : 32;
     g.rpb = 256 / g.cpb;
     g.colgroups = ceil_div(g.cols, g.cpb);
-    int64_t sr = (int64_t)g.rpb * 32;
-    if (ceil_div64(M, sr) > 2048) sr = ceil_div64(ceil_div64(M, 2048), g.rpb) * g.rpb;
+    int64_t want_slices = 2048 / g.colgroups;
+    if (want_slices < 1) want_slices = 1;
+    int64_t sr = ceil_div64(M, want_slices);
+    int64_t rpt = ceil_div64(sr, g.rpb);
+    rpt = rpt < 8 ? 8 : (rpt > 32 ? 32 : rpt);
+    sr = (int64_t)g.rpb * rpt;
+    if (sr < 64) sr = ceil_div64(64, g.rpb) * g.rpb;          // partial traffic 6/sr of the tensor: < 10 %
+    if (ceil_div64(M, sr) > 8192) sr = ceil_div64(ceil_div64(M, 8192), g.rpb) * g.rpb;
     g.slice_rows = (int)sr;
     g.slices = (int)ceil_div64(M, sr);
     return g;

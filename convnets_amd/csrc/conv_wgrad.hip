@@ -50,7 +50,14 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
     unsigned char* As = smem;                      // [NBUF][KP][ROWA]
     unsigned char* Bs = smem + NBUF * KP * ROWA;   // [NBUF][KP][ROWB]
 
+    // XCD-aware order: blocks b, b+8, ... share an XCD (and its L2).  Give each XCD a contiguous run
+    // of logical ids so the workgroups of ONE pixel split -- which re-read the same dy / x rows for
+    // every (co tile, tap, ci tile) -- run on one XCD close in time and hit its L2.
     int bid = blockIdx.x;
+    {
+        int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int tiles_nc = p.ntaps * p.tiles_ci;
     const int per_split = p.tiles_co * tiles_nc;
     const int split = bid / per_split;

@@ -27,6 +27,8 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
+        import os
+        self.force = os.environ.get('CNK_DP_FORCE') == '1'      # run the collective even on 1 rank (path test)
         self.side = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         # buckets from the END of the arena (last layers first)
         self.buckets = []            # (start_elem, end_elem, [param indices])
@@ -75,7 +77,7 @@ class GradReducer:
         if self._launched[b]:
             return
         self._launched[b] = True
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         s, e, _ = self.buckets[b]
         view = self.flat_grad[s:e]

@@ -226,3 +226,71 @@ def test_model_bf16_vs_bf16_emulated_oracle(name, family, kind, in_size, bn):
     assert abs(float(loss) - loss_a) < 5e-3 * abs(loss_a)
     assert e_logits < 1.5 * sens_logits + 2e-2
     assert e_grads < 1.5 * sens_grads + 5e-2
+
+
+def test_fullsize_layer_vs_cpu_reference():
+    """BASELINE-size check (bs=256): the 64->64 3x3 layer of ResNet-50's first stage at 56x56, i.e.
+    M = 802,816 GEMM rows, 6272 M-tiles, 113-way split-K in wgrad.  fp32 path against torch-CPU on
+    the same tensors: catches index overflow / tiling errors that small fixtures cannot."""
+    import torch.nn.functional as F
+    from convnets_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, C, H = 256, 64, 56
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    dy = torch.randn(N, C, H, H, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    yr = F.conv2d(xr, wr, padding=1)
+    yr.backward(dy)
+    xt = x.cuda().contiguous(memory_format=CL).requires_grad_(True)
+    wt = w.cuda().requires_grad_(True)
+    y = ops.Conv2dFn.apply(xt, wt, None, (1, 1), (1, 1), ops.PackedWeights())
+    y.backward(dy.cuda().contiguous(memory_format=CL))
+    torch.cuda.synchronize()
+    assert rel_l2(host(y), yr.detach().numpy()) < 1e-5
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < 1e-5
+    assert rel_l2(host(wt.grad), wr.grad.numpy()) < 5e-5        # 802,816-term fp32 reductions
+    # linearity at full size, bf16 path: conv(a + b) == conv(a) + conv(b) up to bf16 rounding
+    a = x.cuda().bfloat16().contiguous(memory_format=CL)
+    b = torch.roll(a, 1, 0)
+    wb = wt.detach()
+    pk = ops.PackedWeights()
+    ya, yb = ops.Conv2dFn.apply(a, wb, None, (1, 1), (1, 1), pk), ops.Conv2dFn.apply(b, wb, None, (1, 1), (1, 1), pk)
+    yab = ops.Conv2dFn.apply((a.float() + b.float()).bfloat16().contiguous(memory_format=CL), wb, None, (1, 1), (1, 1), pk)
+    assert float((yab.float() - (ya.float() + yb.float())).norm() / yab.float().norm()) < 1e-2
+
+
+def test_fullsize_resnet50_step_properties():
+    """BASELINE config 4 on one GPU: ResNet-50, 224x224, bs=256, bf16.  Size-independent properties
+    of a real step: the initial loss is 256*ln(1000) (zero-mean N(0,0.01) classifier => ~uniform
+    softmax), every gradient / statistic is finite, BN variances are positive, the arena optimizer
+    moves the weights and a second step on the same batch lowers the loss."""
+    import math
+    import convnets_amd as ca
+    torch.manual_seed(21)
+    s = ca.Settings(kind=50, input_size=(3, 224, 224), num_classes=1000, batch_size=256, mixed_precision=True)
+    model = ca.ResNet(s).cuda()
+    assert sum(p.numel() for p in model.parameters()) == 25557032
+    model.init_optimizer()
+    model.train()
+    gen = torch.Generator(device='cuda').manual_seed(21)
+    x = torch.randn(256, 3, 224, 224, generator=gen, device='cuda')
+    y = torch.randint(0, 1000, (256,), generator=gen, device='cuda')
+    before = model.optimizer.flat_p.clone()
+    loss1, correct = model.train_batch((x, y))
+    torch.cuda.synchronize()
+    assert abs(float(loss1) - 256 * math.log(1000)) < 0.06 * 256 * math.log(1000)   # dropout 0.5 on the head inflates it a few %
+    assert 0 <= int(correct) <= 256
+    gflat = model.optimizer.flat_g
+    assert bool(torch.isfinite(gflat).all()) and float(gflat.abs().max()) > 0
+    for k, b in model.named_buffers():
+        assert bool(torch.isfinite(b.float()).all()), k
+        if k.endswith('running_var'):
+            assert float(b.min()) > 0, k
+    assert float((model.optimizer.flat_p - before).abs().max()) > 1e-3      # Adam moved the weights
+    loss2, _ = model.train_batch((x, y))
+    loss3, _ = model.train_batch((x, y))
+    assert float(loss3) < float(loss1)
+    del model
+    torch.cuda.empty_cache()
