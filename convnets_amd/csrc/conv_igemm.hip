@@ -59,8 +59,13 @@ template <> struct Mma32<float> {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
 
-template <typename T, int BN, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void igemm_gather_kernel(const GatherParams p) {
+// 16 zero bytes in global memory: the source of LDS-DMA loads for padded / out-of-range A rows
+__device__ __attribute__((aligned(16))) unsigned int cnk_zero16[4] = {0, 0, 0, 0};
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+template <typename T, int BN, int NBUF, bool GLDS>
+__global__ __launch_bounds__(256, GLDS ? (NBUF == 2 ? 2 : 4) : (NBUF == 2 ? 2 : 3)) void igemm_gather_kernel(const GatherParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
     constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
     constexpr int NJ = BN / 64;                      // 32-wide MFMA blocks per wave along n
@@ -119,6 +124,85 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void igemm_gather_kernel(co
     const int nk = p.ntaps * csteps;
     const size_t wrow = (size_t)p.ntaps * p.C;
 
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto compute = [&](int buf) {
+        const unsigned char* Ab = As + buf * (BM * 128);
+        const unsigned char* Bb = Bs + buf * (BN * 128);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 fa[2], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r = wm * 64 + i * 32 + l31;
+                fa[i] = *(const u32x4*)(Ab + r * 128 + swz(r, 2 * s + lh));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int r = wn * (BN / 2) + j * 32 + l31;
+                fb[j] = *(const u32x4*)(Bb + r * 128 + swz(r, 2 * s + lh));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) Mma32<T>::run(acc[i][j], fb[j], fa[i]);   // C^T block
+        }
+    };
+
+    if constexpr (GLDS) {
+        // LDS-DMA pipeline: global_load_lds_dwordx4 writes 64 lanes x 16 B = 8 rows x 128 B straight
+        // into LDS (no staging VGPRs, no ds_write).  The LDS image is lane-linear, so the XOR
+        // swizzle goes on the SOURCE: lane (row r, physical chunk pc) fetches logical chunk
+        // pc ^ ((r>>1)&7).  Padded / out-of-range rows fetch a 16-byte zero block instead.
+        lds_u8* As3 = (lds_u8*)As;
+        lds_u8* Bs3 = (lds_u8*)Bs;
+        int ld_t = 0, ld_cs = 0;
+        auto issue = [&](int buf) {
+            const int t = ld_t, cb = ld_cs * KSTEP;
+            if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
+            const int dh = p.dh[t], dw = p.dw[t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = lrow + 32 * i;
+                const int c = chunk ^ ((r >> 1) & 7);
+                const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+                const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+                const T* gp = ok ? src + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + cb + c * PER16
+                                 : (const T*)cnk_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + buf * (BM * 128) + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int r = lrow + 32 * i;
+                const int c = chunk ^ ((r >> 1) & 7);
+                const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.C + cb + c * PER16;
+                __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + buf * (BN * 128) + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+            }
+        };
+        if (NBUF == 2) {
+            if (nk > 0) issue(0);
+            __syncthreads();                         // vmcnt(0) + barrier: tile 0 landed
+            for (int ks = 0; ks < nk; ++ks) {
+                if (ks + 1 < nk) issue((ks + 1) & 1);   // lands while this tile is consumed
+                compute(ks & 1);
+                __syncthreads();
+            }
+        } else {
+            for (int ks = 0; ks < nk; ++ks) {
+                issue(0);
+                __syncthreads();
+                compute(0);
+                __syncthreads();
+            }
+            if (nk == 0) __syncthreads();
+        }
+    } else {
     // Register-staged pipeline, prefetch distance 1: the global loads of tile ks+1 are issued before
     // the MFMA phase of tile ks and written to LDS after it.  NBUF = 2: double-buffered LDS, one
     // barrier per K step (64 KiB -> 2 workgroups/CU).  NBUF = 1: one LDS buffer, two barriers per
@@ -160,15 +244,6 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void igemm_gather_kernel(co
         }
     };
 
-    f32x16 acc[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int l31 = lane & 31, lh = lane >> 5;
     if (nk > 0) {
         load_step();
         store_step(0);
@@ -201,6 +276,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void igemm_gather_kernel(co
         if (ks + 1 < nk) store_step(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
+    }   // register-staged path
 
     // Epilogue.  The MFMA computed the TRANSPOSED block (weights as the row operand), so lane
     // (l31, lh) holds pixel row l31 and, in registers 4g..4g+3, the four consecutive output
@@ -269,7 +345,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void igemm_gather_kernel(co
     // BN kernels would read back): per-channel sum / sum-of-squares over this tile's <=128 rows ->
     // (n, mean, M2) partial, merged across tiles by bn_finalize (Chan).  Saves one full read pass.
     if (p.stats) {
-        float* red = (float*)(Cs + BM * CS);          // [2][RPP][BN]
+        // the reduction scratch reuses the staged tile (everyone has finished reading it), which
+        // keeps the epilogue LDS at 35 KiB so four workgroups fit a CU
+        __syncthreads();
+        float* red = (float*)Cs;                      // [2][RPP][BN]
 #pragma unroll
         for (int e = 0; e < PER16; ++e) {
             red[crow * BN + cc * PER16 + e] = s8[e];
@@ -294,11 +373,13 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void igemm_gather_kernel(co
     }
 }
 
-template <typename T, int BN, int NBUF> int launch_gather_v(const GatherParams& p, hipStream_t s) {
+template <typename T, int BN, int NBUF, bool GLDS> int launch_gather_v(const GatherParams& p, hipStream_t s) {
     size_t pipe = NBUF * (BM * 128 + BN * 128);
-    size_t epi = (size_t)BM * (BN * sizeof(T) + 16) + (p.stats ? 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float) : 0);
+    size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
+    size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);     // aliases the staged tile
+    if (red > epi) epi = red;
     size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
-    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, NBUF>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, NBUF, GLDS>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
 }
@@ -312,8 +393,19 @@ static int igemm_nbuf() {
     return v;
 }
 
+static int igemm_glds() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CNK_IGEMM_GLDS");
+        v = (e && e[0] == '0') ? 0 : 1;       // measured: LDS-DMA + 1 buffer (4 WGs/CU) is fastest
+    }
+    return v;
+}
+
 template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
-    return igemm_nbuf() == 1 ? launch_gather_v<T, BN, 1>(p, s) : launch_gather_v<T, BN, 2>(p, s);
+    if (igemm_glds())
+        return igemm_nbuf() == 1 ? launch_gather_v<T, BN, 1, true>(p, s) : launch_gather_v<T, BN, 2, true>(p, s);
+    return igemm_nbuf() == 1 ? launch_gather_v<T, BN, 1, false>(p, s) : launch_gather_v<T, BN, 2, false>(p, s);
 }
 
 static bool pick_bn128(int M, int Nout) {
