@@ -21,6 +21,12 @@ class ConvDesc(ctypes.Structure):
                  'dtype')]
 
 
+class PackJob(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'ntaps', 'transpose', 'dtype', 'pad_')] + \
+               [('kh', ctypes.c_int8 * 32), ('kw', ctypes.c_int8 * 32)]
+
+
 _vp, _i32, _i64, _f32, _sz = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
                               ctypes.c_size_t)
 _dp = ctypes.POINTER(ConvDesc)
@@ -33,6 +39,8 @@ SIGNATURES = {
     'cnk_conv2d_packed_bytes': (_sz, [_dp, ctypes.c_int]),
     'cnk_conv2d_workspace_bytes': (_sz, [_dp, ctypes.c_int]),
     'cnk_conv2d_pack_weights': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp]),
+    'cnk_conv2d_pack_jobs': (ctypes.c_int, [_dp, _vp, _vp, _vp, ctypes.POINTER(PackJob), _i32]),
+    'cnk_pack_batch': (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     'cnk_conv2d_fwd_bn_partial_slices': (_i64, [_dp]),
     'cnk_conv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

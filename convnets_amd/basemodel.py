@@ -35,7 +35,37 @@ class MultiClassBaseModel(nn.Module):
         ReduceLROnPlateau / GradScaler belong to fit() (out of scope; bf16 needs no loss scaling)."""
         self.optimizer = FlatAdam(self.parameters(), lr=self.setting.learning_rate,
                                   weight_decay=self.setting.weight_decay)
+        # all BN step counters as views of one int64 arena: `num_batches_tracked += 1` for every
+        # layer becomes one kernel per step (flushed in train_batch / before state_dict())
+        bns = [m for m in self.modules() if isinstance(m, layers.BatchNorm2d)]
+        if bns:
+            arena = torch.stack([m.num_batches_tracked.detach().to(self.optimizer.flat_p.device) for m in bns])
+            self._bn_counter_arena, self._bn_pending = arena, []
+            for i, m in enumerate(bns):
+                m.num_batches_tracked = arena[i]
+                m._deferred_counter = [0]
+                self._bn_pending.append(m._deferred_counter)
         return self.optimizer
+
+    def flush_bn_counters(self):
+        """Adds each BN layer's pending training-forward count to its num_batches_tracked: one
+        kernel for the whole model (a scalar add in the usual case of equal counts)."""
+        pend = getattr(self, '_bn_pending', None)
+        if not pend:
+            return
+        counts = [c[0] for c in pend]
+        if any(counts):
+            if min(counts) == max(counts):
+                self._bn_counter_arena += counts[0]
+            else:
+                self._bn_counter_arena += torch.tensor(counts, dtype=self._bn_counter_arena.dtype,
+                                                       device=self._bn_counter_arena.device)
+            for c in pend:
+                c[0] = 0
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_bn_counters()
+        return super().state_dict(*args, **kwargs)
 
     def init_params(self):
         for m in self.modules():
@@ -97,6 +127,7 @@ class MultiClassBaseModel(nn.Module):
             self.grad_reducer.finish_step()
         self.gradient_clipping()
         self.optimizer.step()
+        self.flush_bn_counters()
         return loss.detach(), score
 
     @torch.enable_grad()

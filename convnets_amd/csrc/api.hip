@@ -37,6 +37,7 @@ int smallc_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s
 int smallc_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, hipStream_t s);
 size_t smallc_wgrad_workspace(const cnk_conv_desc* d);
 int smallc_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int nblocks, hipStream_t s);
 size_t bn_workspace_bytes(int64_t M, int C);
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
@@ -190,6 +191,43 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
         }
     }
     return 0;
+}
+
+int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad, cnk_pack_job* jobs, int32_t max_jobs) {
+    if (int rc = check_desc(d, "cnk_conv2d_pack_jobs")) return -1;
+    int n = 0;
+    auto add = [&](void* out, int ntaps, const signed char* kh, const signed char* kw, int transpose) {
+        if (ntaps == 0) return true;
+        if (n >= max_jobs || ntaps > 32) return false;
+        cnk_pack_job& j = jobs[n++];
+        memset(&j, 0, sizeof(j));
+        j.w = w; j.out = out; j.Cout = d->Cout; j.Cin = d->Cin; j.KH = d->kh; j.KW = d->kw;
+        j.ntaps = ntaps; j.transpose = transpose; j.dtype = d->dtype;
+        for (int t = 0; t < ntaps; ++t) { j.kh[t] = kh[t]; j.kw[t] = kw[t]; }
+        return true;
+    };
+    if (w_fwd) {
+        if (!igemm_supported(d, CNK_PASS_FWD)) return -1;            // only the implicit-GEMM images batch
+        signed char kh[32], kw[32];
+        for (int t = 0; t < d->kh * d->kw; ++t) { kh[t] = (signed char)(t / d->kw); kw[t] = (signed char)(t % d->kw); }
+        if (!add(w_fwd, d->kh * d->kw, kh, kw, 0)) return -1;
+    }
+    if (w_dgrad) {
+        if (!igemm_supported(d, CNK_PASS_DGRAD) || d->stride_h * d->stride_w > 16) return -1;
+        DgradClass cls[16];
+        int nc = dgrad_classes(d, cls);
+        size_t off = 0;
+        for (int c = 0; c < nc; ++c) {
+            if (!add((char*)w_dgrad + off * esize(d->dtype), cls[c].ntaps, cls[c].kh, cls[c].kw, 1)) return -1;
+            off += (size_t)cls[c].ntaps * d->Cin * d->Cout;
+        }
+    }
+    return n;
+}
+
+int cnk_pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int32_t nblocks, void* stream) {
+    CNK_CHECK_ARG(jobs_dev && block_map_dev && nblocks >= 0, "cnk_pack_batch: bad arguments");
+    return pack_batch(jobs_dev, block_map_dev, nblocks, S(stream));
 }
 
 int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d) {

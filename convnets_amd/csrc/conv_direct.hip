@@ -150,6 +150,30 @@ __global__ void pack_direct_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
+// Multi-tensor form: one launch re-lays every conv weight of the model.  jobs[] and the
+// block -> (job, first block of the job) table live in device memory (built once by the host).
+__global__ __launch_bounds__(256) void pack_batch_kernel(const cnk_pack_job* __restrict__ jobs,
+                                                         const int2* __restrict__ block_map) {
+    const int2 bm = block_map[blockIdx.x];
+    const cnk_pack_job& j = jobs[bm.x];
+    const int R = j.transpose ? j.Cin : j.Cout, Cred = j.transpose ? j.Cout : j.Cin;
+    const size_t total = (size_t)R * j.ntaps * Cred;
+    const size_t base = (size_t)(blockIdx.x - bm.y) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t i = base + u * 256 + threadIdx.x;
+        if (i < total) {
+            int c = (int)(i % Cred);
+            size_t q = i / Cred;
+            int t = (int)(q % j.ntaps), r = (int)(q / j.ntaps);
+            int co = j.transpose ? c : r, ci = j.transpose ? r : c;
+            float v = j.w[(((size_t)co * j.Cin + ci) * j.KH + j.kh[t]) * j.KW + j.kw[t]];
+            if (j.dtype == CNK_BF16) ((bf16*)j.out)[i] = (bf16)v;
+            else ((float*)j.out)[i] = v;
+        }
+    }
+}
+
 DirectParams make_params(const cnk_conv_desc* d) {
     DirectParams p = {};
     int Ho, Wo;
@@ -278,5 +302,12 @@ int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, cons
     if (d->dtype == CNK_BF16) hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, s, p);
     CNK_CHECK_LAUNCH("pack_taps");
+    return 0;
+}
+
+int pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int nblocks, hipStream_t s) {
+    if (nblocks <= 0) return 0;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, (const int2*)block_map_dev);
+    CNK_CHECK_LAUNCH("pack_batch");
     return 0;
 }

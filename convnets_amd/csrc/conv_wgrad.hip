@@ -303,7 +303,15 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
     *bnw = d->Cin % 128 == 0 ? 128 : 64;
     int tiles = (d->Cout / *bmw) * (d->Cin / *bnw) * d->kh * d->kw;
     *ksteps = ceil_div(M, kp);
-    int want = ceil_div(1024, tiles);
+    // The kernel is resident at 2 workgroups per CU (80 KiB LDS each): 512 slots on 256 CUs.  Fill
+    // them exactly once -- tiles*splits just ABOVE a multiple of 512 costs a whole extra round.
+    static int slots = 0;
+    if (!slots) {
+        const char* e = getenv("CNK_WGRAD_SLOTS");
+        slots = e ? atoi(e) : 512;
+        if (slots < 64) slots = 512;
+    }
+    int want = tiles >= slots ? 1 : slots / tiles;
     int max_by_k = *ksteps / 4 > 0 ? *ksteps / 4 : 1;       // at least 4 K steps per split
     int sp = want < max_by_k ? want : max_by_k;
     if (sp < 1) sp = 1;

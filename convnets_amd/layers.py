@@ -48,6 +48,10 @@ class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d; `forward(x, residual=None, relu=False)` exposes the fused epilogue used by
     ConvBlock and the residual blocks.  Called plainly it is exactly BatchNorm2d."""
 
+    # set by MultiClassBaseModel.init_optimizer(): a [count] cell of pending training forwards; the
+    # model then bumps every layer's num_batches_tracked with ONE kernel per step, not one per layer
+    _deferred_counter = None
+
     def forward(self, x, residual=None, relu=False, partial=None, link=None):
         if not (self.affine and self.track_running_stats):
             raise NotImplementedError('convnets_amd.BatchNorm2d: affine=True, '
@@ -58,7 +62,10 @@ class BatchNorm2d(nn.BatchNorm2d):
             y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
                                          self.running_var, float(self.eps), float(self.momentum),
                                          bool(relu), partial, link)
-            self.num_batches_tracked += 1
+            if self._deferred_counter is not None:
+                self._deferred_counter[0] += 1        # flushed for all BN layers at once by the model
+            else:
+                self.num_batches_tracked += 1
             return y
         return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var,
                                    float(self.eps), residual, relu)

@@ -118,17 +118,105 @@ class GradLink:
         return make_grad(parked)
 
 
+class WeightPacker:
+    """Re-lays the weight images of EVERY registered conv with one kernel launch
+    (cnk_pack_batch) per weights epoch, instead of two to five small launches per conv."""
+
+    def __init__(self):
+        self._refs = []            # weak references to the PackedWeights that asked to be batched
+        self.table_key = None
+        self.jobs_dev = self.map_dev = None
+        self.nblocks = 0
+        self.done_epoch = -1
+
+    def register(self, pw):
+        import weakref
+        if not any(r() is pw for r in self._refs):
+            self._refs.append(weakref.ref(pw))      # weak: a packer must not keep dead models alive
+            self.table_key = None
+
+    @property
+    def entries(self):
+        live = [r() for r in self._refs]
+        if any(p is None for p in live):
+            self._refs = [r for r in self._refs if r() is not None]
+            self.table_key = None
+        return [p for p in live if p is not None]
+
+    def _build(self, entries):
+        lib = _lib.load()
+        jobs, blocks = [], []
+        buf = (_lib.PackJob * 24)()
+        for pw in entries:
+            n = lib.cnk_conv2d_pack_jobs(ctypes.byref(pw.desc), _p(pw.weight), _p(pw.w_fwd), _p(pw.w_dgrad),
+                                         buf, 24)
+            if n < 0:
+                raise RuntimeError('WeightPacker: conv images cannot be batched')
+            for k in range(n):
+                j = _lib.PackJob()
+                ctypes.memmove(ctypes.byref(j), ctypes.byref(buf[k]), ctypes.sizeof(j))
+                total = (j.Cin if j.transpose else j.Cout) * j.ntaps * (j.Cout if j.transpose else j.Cin)
+                first = len(blocks)
+                blocks += [(len(jobs), first)] * ((total + 1023) // 1024)
+                jobs.append(j)
+        dev = entries[0].weight.device
+        raw = b''.join(bytes(j) for j in jobs)
+        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.map_dev = torch.tensor(blocks, dtype=torch.int32).to(dev)
+        self.nblocks = len(blocks)
+
+    def ensure(self):
+        """Called by a registered PackedWeights whose images are stale: repack ALL of them."""
+        ep = weights_epoch()
+        if self.done_epoch == ep:
+            return
+        entries = self.entries
+        if not entries:
+            return
+        key = tuple((pw.weight.data_ptr(), pw.w_fwd.data_ptr(),
+                     0 if pw.w_dgrad is None else pw.w_dgrad.data_ptr()) for pw in entries)
+        if key != self.table_key:
+            self._build(entries)
+            self.table_key = key
+        with torch.no_grad():
+            check(_lib.load().cnk_pack_batch(_p(self.jobs_dev), _p(self.map_dev), self.nblocks, _stream()))
+        self.done_epoch = ep
+        for pw in entries:
+            pw.batched_epoch = ep
+
+
+_packers = {}
+
+
+def packer_for(device):
+    p = _packers.get(device)
+    if p is None:
+        p = _packers[device] = WeightPacker()
+    return p
+
+
 class PackedWeights:
     """The two operand images of one conv weight (cnk_conv2d_pack_weights), re-made when the
-    master weight changes."""
+    master weight changes.  After its first use a conv whose images can be batched registers with
+    the device's WeightPacker, which from then on re-lays all registered convs in one launch."""
 
     def __init__(self):
         self.key = None
         self.w_fwd = None
         self.w_dgrad = None
+        self.weight = self.desc = None
+        self.batched = False
+        self.batched_epoch = -1
 
     def get(self, weight, desc, need_dgrad):
         lib = _lib.load()
+        if self.batched and self.weight is weight and self.key is not None \
+                and self.key[0] == weight.data_ptr() and self.key[3] == desc.dtype and self.key[4] == need_dgrad \
+                and self.key[1] == weight._version:
+            if self.batched_epoch != weights_epoch():
+                packer_for(weight.device).ensure()
+            self.key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad)
+            return self.w_fwd, self.w_dgrad
         key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad)
         if self.key != key:
             dev = weight.device
@@ -142,6 +230,14 @@ class PackedWeights:
                 check(lib.cnk_conv2d_pack_weights(ctypes.byref(desc), _p(weight), _p(self.w_fwd),
                                                   _p(self.w_dgrad), _stream()))
             self.key = key
+            self.weight, self.desc = weight, desc
+            # batch from the next epoch on if every image of this conv is an implicit-GEMM image
+            probe = (_lib.PackJob * 24)()
+            self.batched = weight.requires_grad and lib.cnk_conv2d_pack_jobs(
+                ctypes.byref(desc), _p(weight), _p(self.w_fwd), _p(self.w_dgrad), probe, 24) >= 0
+            if self.batched:
+                self.batched_epoch = weights_epoch()
+                packer_for(weight.device).register(self)
         return self.w_fwd, self.w_dgrad
 
 

@@ -62,6 +62,23 @@ size_t cnk_conv2d_workspace_bytes(const cnk_conv_desc* d, int pass);
 int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
                             void* stream);
 
+/* Batched form of the re-layout for whole models: cnk_conv2d_pack_jobs appends to a HOST array the
+ * jobs that produce the same images as cnk_conv2d_pack_weights for one conv (returns the number
+ * written, or -1 if this conv's images cannot be batched: small-C / direct paths); the caller
+ * uploads the jobs of every conv plus a block map {job index, first block of that job} -- one
+ * block per 1024 output elements -- and then re-lays ALL weights with ONE launch per optimizer
+ * step (cnk_pack_batch) instead of two to five launches per conv. */
+typedef struct cnk_pack_job {
+    const float* w;            /* master weight [Cout][Cin][KH][KW]            */
+    void* out;                 /* image: [R][ntaps][Cred], R/Cred = Cout/Cin or swapped */
+    int32_t Cout, Cin, KH, KW, ntaps, transpose, dtype, pad_;
+    int8_t kh[32], kw[32];     /* tap list                                      */
+} cnk_pack_job;
+int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
+                         cnk_pack_job* jobs, int32_t max_jobs);
+int cnk_pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int32_t nblocks,
+                   void* stream);
+
 /* y = conv2d(x, w) (+ bias).  nn.Conv2d.forward reached from basemodel.py:974 via :1004.
  * bias (fp32[Cout]) may be NULL: the reference has a bias only when batch_norm is off (:973).
  * Optional fusion with the BatchNorm2d that follows the conv in conv2d_block (:1008): when

@@ -295,3 +295,36 @@ def test_fullsize_resnet50_step_properties():
     assert float(loss3) < float(loss1)
     del model
     torch.cuda.empty_cache()
+
+
+def test_batched_weight_pack_matches_per_conv_pack():
+    """From the second step on all conv weight images are re-laid by ONE cnk_pack_batch launch;
+    they must be byte-identical to what cnk_conv2d_pack_weights produces for the current weights,
+    and the BN step counters (one arena, one kernel per step) must count steps."""
+    import convnets_amd as ca
+    from convnets_amd import ops, layers
+    torch.manual_seed(21)
+    s = ca.Settings(kind=26, input_size=(3, 32, 32), num_classes=10, batch_size=8, dropout_rate=0, mixed_precision=True)
+    model = ca.ResNet(s).cuda()
+    model.init_optimizer()
+    model.train()
+    x, y = torch.randn(8, 3, 32, 32), torch.randint(0, 10, (8,))
+    for _ in range(3):
+        model.train_batch((x, y))
+    with torch.no_grad():
+        model.train()
+        model.features(ops.nchw_to_nhwc(x.cuda(), torch.bfloat16))     # forces a re-pack for the new weights
+    torch.cuda.synchronize()
+    convs = [m for m in model.modules() if isinstance(m, layers.Conv2d)]
+    batched = [c for c in convs if c._packed.batched]
+    assert len(batched) >= len(convs) - 1                               # everything but the stem
+    for c in batched:
+        fresh = ops.PackedWeights()
+        wf, wd = fresh.get(c.weight, c._packed.desc, c._packed.w_dgrad is not None)
+        torch.cuda.synchronize()
+        assert torch.equal(wf, c._packed.w_fwd)
+        if wd is not None:
+            assert torch.equal(wd, c._packed.w_dgrad)
+    sd = model.state_dict()
+    nbt = [int(v) for k, v in sd.items() if k.endswith('num_batches_tracked')]
+    assert nbt and all(v == 4 for v in nbt)
