@@ -106,8 +106,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 or 'RANK' in os.environ:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(local_rank if torch.cuda.device_count() > local_rank else 0)
+        backend = os.environ.get('CNK_DIST_BACKEND', 'nccl')      # 'nccl' IS RCCL on ROCm; gloo only for 1-GPU rehearsals
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
         distributed = True
     else:
         distributed = False

@@ -53,13 +53,17 @@ class GradReducer:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._listener = lambda p: self._param_ready(self._index.get(id(p)))
         ops._grad_ready_listeners.append(self._listener)
-        self._pending, self._launched, self._works = None, None, None
+        self._pending, self._launched, self._works, self._seen = None, None, None, None
         if flat_param is not None and self.world > 1:
             dist.broadcast(flat_param, src=0, group=process_group)      # identical replicas
 
     def _param_ready(self, i):
-        if self._pending is None or i is None:
+        """Idempotent per parameter and step: a gradient written in place by a kernel is reported
+        by convnets_amd.ops, and torch (2.10) ALSO fires the post-accumulate hook for a parameter
+        whose Function returned None -- only the first report counts."""
+        if self._pending is None or i is None or self._seen[i]:
             return
+        self._seen[i] = True
         b = self.bucket_of[i]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -71,6 +75,7 @@ class GradReducer:
     def begin_step(self):
         self._pending = [sum(1 for i in ids if self.params[i].requires_grad) for _, _, ids in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._seen = [False] * len(self.params)
         self._works = []
 
     def _launch(self, b):

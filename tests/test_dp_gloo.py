@@ -97,5 +97,11 @@ def test_bucket_layout_covers_arena_once():
     red.begin_step()
     m.cost_function(m(torch.randn(4, 1, 28, 28)), torch.tensor([1, 2, 3, 4])).backward()
     assert all(red._launched)                   # every bucket fired from the autograd hooks
+    # a second report of the same parameter in one step (in-place kernels + torch's own hook) is ignored
+    red.begin_step()
+    red._param_ready(0)
+    before = list(red._pending)
+    red._param_ready(0)
+    assert red._pending == before
     red.finish_step()
     red.remove()
