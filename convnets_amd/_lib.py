@@ -46,11 +46,12 @@ SIGNATURES = {
     'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'cnk_conv2d_wgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_bn_workspace_bytes': (_sz, [_i64, _i32]),
-    'cnk_bn_fwd_train': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
+    'cnk_bn_mask_bytes': (_sz, [_i64, _i32, ctypes.c_int]),
+    'cnk_bn_fwd_train': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
                                         _f32, _f32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_bn_fwd_eval': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32,
                                        ctypes.c_int, ctypes.c_int, _vp]),
-    'cnk_bn_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+    'cnk_bn_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                                   _i64, _i32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_maxpool2d_fwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_maxpool2d_bwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),

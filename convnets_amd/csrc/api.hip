@@ -39,9 +39,10 @@ size_t smallc_wgrad_workspace(const cnk_conv_desc* d);
 int smallc_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int nblocks, hipStream_t s);
 size_t bn_workspace_bytes(int64_t M, int C);
-int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
+size_t bn_mask_bytes(int64_t M, int C, int dtype);
+int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
-int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
+int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
 int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
 int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
@@ -294,14 +295,17 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
 
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(M, C); }
 
-int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* partial, int64_t partial_slices, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+size_t cnk_bn_mask_bytes(int64_t M, int32_t C, int dtype) { return bn_mask_bytes(M, C, dtype); }
+
+int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual, void* y, uint8_t* relu_mask, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* partial, int64_t partial_slices, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd, "cnk_bn_fwd_train: null pointer");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_train: empty tensor");
     CNK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cnk_bn_fwd_train: running stats must both be given or both NULL");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_fwd_train: workspace too small");
     CNK_CHECK_ARG((partial == nullptr) == (partial_slices == 0) && partial_slices >= 0, "cnk_bn_fwd_train: partial and partial_slices must come together");
     ProfScope ps(CNK_CLS_BN_FWD, S(stream), 0.0, (partial ? 2.0 : 3.0) * (double)M * C * esize(dtype));
-    return bn_fwd_train(x, gamma, beta, residual, y, running_mean, running_var, save_mean, save_invstd, partial, partial_slices, M, C, eps, momentum, relu, dtype, (float*)workspace, S(stream));
+    CNK_CHECK_ARG(!relu_mask || relu, "cnk_bn_fwd_train: relu_mask without relu");
+    return bn_fwd_train(x, gamma, beta, residual, y, relu_mask, running_mean, running_var, save_mean, save_invstd, partial, partial_slices, M, C, eps, momentum, relu, dtype, (float*)workspace, S(stream));
 }
 
 int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var, const void* residual, void* y, int64_t M, int32_t C, float eps, int relu, int dtype, void* stream) {
@@ -310,13 +314,13 @@ int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const 
     return bn_fwd_eval(x, gamma, beta, running_mean, running_var, residual, y, M, C, eps, relu, dtype, S(stream));
 }
 
-int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu_mask, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "cnk_bn_bwd: null pointer");
-    CNK_CHECK_ARG(!relu || y || (beta && !dresidual), "cnk_bn_bwd: relu backward needs the forward output, or beta and no residual");
+    CNK_CHECK_ARG(!relu || y || relu_mask || (beta && !dresidual), "cnk_bn_bwd: relu backward needs the saved mask, the forward output, or (no residual) beta");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd: empty tensor");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd: workspace too small");
     ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, 5.0 * (double)M * C * esize(dtype));
-    return bn_bwd(dy, x, y, gamma, beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, M, C, relu, dtype, (float*)workspace, S(stream));
+    return bn_bwd(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, M, C, relu, dtype, (float*)workspace, S(stream));
 }
 
 int cnk_maxpool2d_fwd(const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {

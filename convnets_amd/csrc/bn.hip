@@ -202,7 +202,8 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
                                                        const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int64_t M,
+                                                       const float* __restrict__ shift,
+                                                       unsigned char* __restrict__ mask, int64_t M,
                                                        int C, int relu, SliceGeom g) {
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
@@ -233,6 +234,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
         }
         v0.store(y + off0);
         v1.store(y + off1);
+        if (mask) {                              // one byte per VEC-channel vector: bit k = (y_k > 0)
+            unsigned b0 = 0, b1 = 0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                b0 |= (v0.f[k] > 0.f ? 1u : 0u) << k;
+                b1 |= (v1.f[k] > 0.f ? 1u : 0u) << k;
+            }
+            mask[m * g.cols + vcol] = (unsigned char)b0;
+            mask[(m + g.rpb) * g.cols + vcol] = (unsigned char)b1;
+        }
     }
     if (m < m1) {
         const int64_t off = m * C + (int64_t)vcol * VEC;
@@ -247,6 +258,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
             v.f[k] = o;
         }
         v.store(y + off);
+        if (mask) {
+            unsigned b = 0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) b |= (v.f[k] > 0.f ? 1u : 0u) << k;
+            mask[m * g.cols + vcol] = (unsigned char)b;
+        }
     }
 }
 
@@ -282,11 +299,13 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const T* __restrict__ x,
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
-    int64_t M, int C, int relu, SliceGeom g) {
+    const unsigned char* __restrict__ mask, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ partial, int64_t M, int C, int relu,
+    SliceGeom g) {
     __shared__ float sh[2][256 * (VEC > 1 ? VEC : 1)];
-    const bool remask = relu && y == nullptr;      // mask from x*scale+shift (same fp32 ops as forward)
+    // ReLU mask source: saved bit mask > forward output y > recomputed x*scale+shift (no residual)
+    const bool remask = relu && y == nullptr && mask == nullptr;
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     const bool active = trow < g.rpb && vcol < g.cols;
@@ -306,12 +325,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const bool two = m + g.rpb < m1;
             int64_t off[2] = {m * C + (int64_t)vcol * VEC, (m + g.rpb) * C + (int64_t)vcol * VEC};
             VLoad<T, VEC> vd[2], vx[2], vy[2];
+            unsigned mb[2] = {0, 0};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u == 0 || two) {
                     vd[u].load(dy + off[u]);
                     vx[u].load(x + off[u]);
-                    if (relu && !remask) vy[u].load(y + off[u]);
+                    if (mask) mb[u] = mask[(m + u * g.rpb) * g.cols + vcol];
+                    else if (relu && !remask) vy[u].load(y + off[u]);
                 }
             }
 #pragma unroll
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                     for (int i = 0; i < VEC; ++i) {
                         float d = vd[u].f[i];
                         if (remask) vy[u].f[i] = vx[u].f[i] * sc[i] + sf[i];
+                        if (mask) vy[u].f[i] = ((mb[u] >> i) & 1u) ? 1.f : 0.f;
                         if (relu && !(vy[u].f[i] > 0.f)) d = 0.f;
                         s1[i] += d;
                         s2[i] += d * (vx[u].f[i] - mu[i]) * is[i];
@@ -383,14 +405,14 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ dx,
-    T* __restrict__ dres, const float* __restrict__ beta, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ coefA,
-    const float* __restrict__ coefB1, const float* __restrict__ coefB2, int64_t M, int C, int relu,
-    SliceGeom g) {
+    T* __restrict__ dres, const unsigned char* __restrict__ mask, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ coefA, const float* __restrict__ coefB1,
+    const float* __restrict__ coefB2, int64_t M, int C, int relu, SliceGeom g) {
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     if (trow >= g.rpb || vcol >= g.cols) return;
-    const bool remask = relu && y == nullptr;
+    const bool remask = relu && y == nullptr && mask == nullptr;
     // dx = a*(d - b1 - (x-mu)*(is*b2)); the centred form keeps fp32 accuracy when |mu| >> sigma
     float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC], ksf[VEC];
 #pragma unroll
@@ -408,12 +430,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const bool two = m + g.rpb < m1;
         int64_t off[2] = {m * C + (int64_t)vcol * VEC, (m + g.rpb) * C + (int64_t)vcol * VEC};
         VLoad<T, VEC> vd[2], vx[2], vy[2], vo[2];
+        unsigned mb[2] = {0, 0};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 0 || two) {
                 vd[u].load(dy + off[u]);
                 vx[u].load(x + off[u]);
-                if (relu && !remask) vy[u].load(y + off[u]);
+                if (mask) mb[u] = mask[(m + u * g.rpb) * g.cols + vcol];
+                else if (relu && !remask) vy[u].load(y + off[u]);
             }
         }
 #pragma unroll
@@ -423,6 +447,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
                 for (int k = 0; k < VEC; ++k) {
                     float d = vd[u].f[k];
                     if (remask) vy[u].f[k] = vx[u].f[k] * ka[k] + ksf[k];
+                    if (mask) vy[u].f[k] = ((mb[u] >> k) & 1u) ? 1.f : 0.f;
                     if (relu && !(vy[u].f[k] > 0.f)) d = 0.f;
                     vd[u].f[k] = d;
                     vo[u].f[k] = ka[k] * (d - kb1[k] - (vx[u].f[k] - kmu[k]) * kis[k]);
@@ -457,8 +482,8 @@ size_t bn_workspace_bytes(int64_t M, int C) {
 
 template <typename T, int VEC>
 static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* res,
-                          void* y, float* rm, float* rv, float* sm, float* si, const float* ext_partial,
-                          int64_t ext_slices, int64_t M, int C, float eps, float mom, int relu,
+                          void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si,
+                          const float* ext_partial, int64_t ext_slices, int64_t M, int C, float eps, float mom, int relu,
                           float* ws, hipStream_t s) {
     SliceGeom g = make_geom(M, C, VEC);
     float* scale = ws;
@@ -477,20 +502,20 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
                        M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
     CNK_CHECK_LAUNCH("bn_finalize");
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)x, (const T*)res, (T*)y, scale, shift, M, C, relu, g);
+                       (const T*)x, (const T*)res, (T*)y, scale, shift, mask, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_apply");
     return 0;
 }
 
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y,
-                 float* rm, float* rv, float* sm, float* si, const float* ep, int64_t es, int64_t M, int C,
+                 unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* ep, int64_t es, int64_t M, int C,
                  float eps, float mom, int relu, int dtype, float* ws, hipStream_t s) {
     if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_fwd_train_t<bf16, 8>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
-        return bn_fwd_train_t<bf16, 1>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+        if (C % 8 == 0) return bn_fwd_train_t<bf16, 8>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+        return bn_fwd_train_t<bf16, 1>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
     }
-    if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
-    return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+    if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+    return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
 }
 
 template <typename T, int VEC>
@@ -516,7 +541,7 @@ int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const floa
 }
 
 template <typename T, int VEC>
-static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* gamma,
+static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma,
                     const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma,
                     float* dbeta, int accumulate, int64_t M, int C, int relu, float* ws,
                     hipStream_t s) {
@@ -526,25 +551,31 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const float* g
     float* coefB2 = ws + 3 * C;
     float* partial = ws + ws_partials_off(C);
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)dy, (const T*)x, (const T*)y, gamma, beta, sm, si, partial, M, C, relu, g);
+                       (const T*)dy, (const T*)x, (const T*)y, mask, gamma, beta, sm, si, partial, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, g.slices,
                        C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
     CNK_CHECK_LAUNCH("bn_bwd_final");
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, beta, sm, si, coefA, coefB1,
+                       (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, mask, beta, sm, si, coefA, coefB1,
                        coefB2, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }
 
-int bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* sm,
+int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm,
            const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
            int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s) {
     if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_bwd_t<bf16, 8>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
-        return bn_bwd_t<bf16, 1>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+        if (C % 8 == 0) return bn_bwd_t<bf16, 8>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+        return bn_bwd_t<bf16, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
     }
-    if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
-    return bn_bwd_t<float, 1>(dy, x, y, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+    if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+    return bn_bwd_t<float, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+}
+
+// bytes of the packed ReLU mask: one byte per 16-byte channel vector the kernels use for (C, dtype)
+size_t bn_mask_bytes(int64_t M, int C, int dtype) {
+    int vec = dtype == CNK_BF16 ? (C % 8 == 0 ? 8 : 1) : (C % 4 == 0 ? 4 : 1);
+    return (size_t)M * (C / vec);
 }

@@ -341,13 +341,18 @@ class BatchNormActFn(torch.autograd.Function):
         if partial is not None and partial.numel() == 0:
             partial = None
         nsl = 0 if partial is None else partial.shape[0]
-        check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean),
-                                   _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
+        # with a residual operand the ReLU mask cannot be re-derived from x alone: keep it as a
+        # packed bit mask (1/16 of y's bytes) for the backward instead of re-reading y twice
+        mask = None
+        if relu and residual is not None and x.requires_grad:
+            mask = torch.empty(lib.cnk_bn_mask_bytes(M, C, _dtype_code(x)), dtype=torch.uint8, device=x.device)
+        check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mask),
+                                   _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
                                    M, C, eps, momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(),
                                    _stream()))
         # the ReLU mask needs y only with a residual operand; otherwise the backward re-derives it
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta,
-                              save_mean, save_invstd)
+        ctx.save_for_backward(x, y if (relu and residual is not None and mask is None) else None,
+                              mask, gamma, beta, save_mean, save_invstd)
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.params = (gamma, beta)
         ctx.link = link if (residual is not None and residual.requires_grad) else None
@@ -356,7 +361,7 @@ class BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        x, y, mask, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
         dy = _nhwc(dy)
         N, C, H, W = x.shape
         M = N * H * W
@@ -377,7 +382,7 @@ class BatchNormActFn(torch.autograd.Function):
             dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
-        check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+        check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(mask), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
                              _p(dx), _p(dres_out), _p(dg_buf), _p(db_buf), int(direct), M, C,
                              int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
         if direct:

@@ -111,10 +111,13 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
  * fp32; running_mean/var (may be NULL) get momentum updates with the UNBIASED variance;
  * save_mean/save_invstd (fp32[C]) are outputs kept for the backward.  partial/partial_slices:
  * optional statistics partials from cnk_conv2d_fwd (NULL/0: computed here).
+ * relu_mask (may be NULL; cnk_bn_mask_bytes(M, C, dtype) bytes): packed ReLU mask of the output,
+ * one bit per element; handing it to cnk_bn_bwd replaces two full reads of y by 1/16 of the bytes.
  * workspace: cnk_bn_workspace_bytes(M, C). */
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C);
+size_t cnk_bn_mask_bytes(int64_t M, int32_t C, int dtype);
 int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual,
-                     void* y, float* running_mean, float* running_var, float* save_mean,
+                     void* y, uint8_t* relu_mask, float* running_mean, float* running_var, float* save_mean,
                      float* save_invstd, const float* partial, int64_t partial_slices, int64_t M,
                      int32_t C, float eps, float momentum, int relu, int dtype, void* workspace,
                      size_t workspace_bytes, void* stream);
@@ -125,11 +128,12 @@ int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const 
                     float eps, int relu, int dtype, void* stream);
 
 /* Backward of cnk_bn_fwd_train.  The ReLU mask is taken from the forward OUTPUT like nn.ReLU's
- * backward: from y when given; when y is NULL (allowed only without a residual operand) it is
- * re-derived as x*scale+shift > 0 with the same fp32 arithmetic as the forward, which saves two
- * full reads of y.  dresidual (may be NULL) receives the gradient of the residual operand
+ * backward: from relu_mask when given (the packed mask the forward wrote), else from y; when both
+ * are NULL (allowed only without a residual operand) it is re-derived as x*scale+shift > 0 with
+ * the same fp32 arithmetic as the forward.  dresidual (may be NULL) receives the gradient of the residual operand
  * (= masked dy).  dgamma/dbeta fp32[C]; accumulate as in wgrad. */
-int cnk_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
+int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu_mask,
+               const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
                float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu,
                int dtype, void* workspace, size_t workspace_bytes, void* stream);
