@@ -43,7 +43,8 @@ SIGNATURES = {
     'cnk_pack_batch': (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     'cnk_conv2d_fwd_bn_partial_slices': (_i64, [_dp]),
     'cnk_conv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'cnk_conv2d_dgrad_accepts_mask': (ctypes.c_int, [_dp]),
+    'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'cnk_conv2d_wgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_bn_workspace_bytes': (_sz, [_i64, _i32]),
     'cnk_bn_mask_bytes': (_sz, [_i64, _i32, ctypes.c_int]),

@@ -12,7 +12,7 @@
 bool igemm_supported(const cnk_conv_desc* d, int pass);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
-int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, hipStream_t s);
+int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, hipStream_t s);
 int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
 bool wgrad_mfma_supported(const cnk_conv_desc* d);
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
@@ -249,14 +249,19 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
     return direct_fwd(d, x, w_fwd, bias, y, S(stream));
 }
 
-int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* workspace, size_t workspace_bytes, void* stream) {
+int cnk_conv2d_dgrad_accepts_mask(const cnk_conv_desc* d) {
+    return igemm_supported(d, CNK_PASS_DGRAD) && d->Cin % (d->dtype == CNK_BF16 ? 8 : 4) == 0;
+}
+
+int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const uint8_t* addend_mask, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (int rc = check_desc(d, "cnk_conv2d_dgrad")) return rc;
     CNK_CHECK_ARG(dy && w_dgrad && dx, "cnk_conv2d_dgrad: null pointer");
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
-    if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, addend, S(stream));
+    CNK_CHECK_ARG(!addend_mask || (addend && igemm_supported(d, CNK_PASS_DGRAD) && d->Cin % (d->dtype == CNK_BF16 ? 8 : 4) == 0), "cnk_conv2d_dgrad: addend_mask needs an addend and the implicit-GEMM path");
+    if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, addend, addend_mask, S(stream));
     return direct_dgrad(d, dy, w_dgrad, dx, addend, S(stream));
 }
 

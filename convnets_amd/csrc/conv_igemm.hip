@@ -27,6 +27,7 @@ struct GatherParams {
     void* dst;
     const float* bias;
     const void* addend;      // optional tensor shaped like dst: dst = conv + addend (fused grad sum)
+    const unsigned char* addend_mask;   // optional packed ReLU mask (1 byte per 16-B vector) gating addend
     float* stats;            // optional [tiles_m][Nout][3] BN partials (n, mean, M2) of the OUTPUT
     int N, IH, IW, C;
     int OH, OW;
@@ -327,8 +328,12 @@ __global__ __launch_bounds__(256, GLDS ? (NBUF == 2 ? 2 : 4) : (NBUF == 2 ? 2 : 
             if (p.addend) {              // same rounding as a separate add kernel: round(round(conv) + addend)
                 Vec16<T> a;
                 a.v = *(const decltype(a.v)*)((const unsigned char*)p.addend + goff);
+                // with a mask the addend is dy of the block output and the mask its ReLU pattern:
+                // addend*mask is the residual-branch gradient, formed here instead of being written
+                // out by the BN backward and read back
+                const unsigned mb = p.addend_mask ? p.addend_mask[goff >> 4] : 0xFFu;
 #pragma unroll
-                for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + a.get(e));
+                for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + (((mb >> e) & 1u) ? a.get(e) : 0.f));
             }
             *(decltype(v.v)*)(dst + goff) = v.v;
             if (p.stats) {
@@ -494,7 +499,7 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w]
 }
 
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                const void* addend, hipStream_t s) {
+                const void* addend, const unsigned char* addend_mask, hipStream_t s) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     DgradClass cls[16];
@@ -506,7 +511,7 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
         const DgradClass& k = cls[c];
         GatherParams p = {};
         p.src = dy; p.wpk = (const char*)w_dgrad + woff * esz; p.dst = dx; p.bias = nullptr;
-        p.addend = addend;
+        p.addend = addend; p.addend_mask = addend_mask;
         p.N = d->N; p.IH = Ho; p.IW = Wo; p.C = d->Cout;
         p.OH = k.OH; p.OW = k.OW; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
         p.sm_h = 1; p.sm_w = 1;

@@ -95,6 +95,15 @@ def make_desc(x_shape, weight_shape, stride, padding, dtype_code):
                     dtype_code)
 
 
+def masked_grad(dy, mask):
+    """dy * relu_mask for a packed mask (fallback when a consumer cannot apply the mask itself)."""
+    N, C, H, W = dy.shape
+    vec = dy.numel() // mask.numel()
+    bits = (mask.view(-1, 1) >> torch.arange(vec, device=mask.device, dtype=torch.uint8)) & 1
+    m = bits.view(N, H, W, C).permute(0, 3, 1, 2)
+    return (dy * m.to(dy.dtype)).contiguous(memory_format=CL)
+
+
 class GradLink:
     """Hands the gradient of one consumer of a tensor to another consumer's backward so the sum of
     the two is formed inside a kernel epilogue instead of by autograd's accumulation pass.
@@ -112,7 +121,13 @@ class GradLink:
         self.arrived += 1
         if self.arrived < self.count:
             g = make_grad(None)
-            self.parked = g if self.parked is None else self.parked + g
+            if self.parked is None:
+                self.parked = g
+            else:
+                a, b = self.parked, g
+                a = masked_grad(*a) if isinstance(a, tuple) else a
+                b = masked_grad(*b) if isinstance(b, tuple) else b
+                self.parked = a + b
             return None
         parked, self.arrived, self.parked = self.parked, 0, None
         return make_grad(parked)
@@ -287,11 +302,16 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             def dgrad(addend):
+                amask = None
+                if isinstance(addend, tuple):        # (block-output gradient, its packed ReLU mask)
+                    addend, amask = addend
+                    if not lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(desc)):
+                        addend, amask = masked_grad(addend, amask), None
                 if addend is not None:
                     addend = _nhwc(addend)
                 out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=CL)
                 check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(out),
-                                           _p(addend), None, 0, _stream()))
+                                           _p(addend), _p(amask), None, 0, _stream()))
                 return out
             dx = ctx.link.contribute(dgrad) if ctx.link is not None else dgrad(None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -367,6 +387,12 @@ class BatchNormActFn(torch.autograd.Function):
         M = N * H * W
         dx = torch.empty_like(x, memory_format=CL)
         want_res = ctx.has_res and ctx.needs_input_grad[3]
+        # identity shortcut with a saved bit mask: the residual gradient dy*mask is NOT written here;
+        # (dy, mask) is parked for the block's first conv, whose dgrad epilogue applies the mask
+        defer_res = want_res and ctx.relu and mask is not None and ctx.link is not None \
+            and ctx.link.arrived + 1 < ctx.link.count
+        if defer_res:
+            want_res = False
         if want_res and not ctx.relu:
             dres = dy                       # identity branch of a plain add: gradient passes through
             dres_out = None
@@ -388,7 +414,10 @@ class BatchNormActFn(torch.autograd.Function):
         if direct:
             _grad_written(pg)
             _grad_written(pb)
-        if ctx.link is not None and dres is not None:
+        if defer_res:
+            ctx.link.contribute(lambda parked: (dy, mask))
+            dres = None
+        elif ctx.link is not None and dres is not None:
             # identity shortcut: park the residual gradient for the block's first conv, whose
             # dgrad epilogue adds it (falls back to a plain add if this backward is the last one)
             dres = ctx.link.contribute(lambda parked: dres if parked is None else dres + parked)

@@ -94,9 +94,14 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
  * (loss.backward(), basemodel.py:258/278).  `addend` (may be NULL; shaped like dx) is the
  * gradient arriving at the same tensor through another branch -- the identity / projection
  * shortcut of a residual block (resnet.py:141-151,181-191); summing it in the epilogue replaces
- * the separate accumulation pass autograd would run. */
+ * the separate accumulation pass autograd would run.  addend_mask (may be NULL): the packed ReLU
+ * mask cnk_bn_fwd_train wrote for the block output; then `addend` is the gradient of the block
+ * OUTPUT and addend*mask -- the identity-shortcut gradient -- is formed in the epilogue instead of
+ * being materialised by the BN backward (implicit-GEMM path only). */
+int cnk_conv2d_dgrad_accepts_mask(const cnk_conv_desc* d);      /* 1 if addend_mask is usable */
 int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                     const void* addend, void* workspace, size_t workspace_bytes, void* stream);
+                     const void* addend, const uint8_t* addend_mask, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* dw[Cout][Cin][kh][kw] (fp32) = sum over N,Ho,Wo of dy * x ; dbias[Cout] = sum dy (may be NULL).
  * accumulate != 0 adds into dw/dbias (torch's .grad accumulation), else overwrites. */
