@@ -157,7 +157,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     __shared__ float sh[3][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
     float na = 0.f, ma = 0.f, qa = 0.f;
-    for (int s = tid; s < slices; s += 256) {
+    int s = tid;
+    for (; s + 768 < slices; s += 1024) {       // four independent loads in flight per thread
+        const float* o0 = partial + ((size_t)s * C + c) * 3;
+        const float* o1 = o0 + (size_t)256 * C * 3;
+        const float* o2 = o1 + (size_t)256 * C * 3;
+        const float* o3 = o2 + (size_t)256 * C * 3;
+        float n0 = o0[0], m0 = o0[1], q0 = o0[2], n1 = o1[0], m1 = o1[1], q1 = o1[2];
+        float n2 = o2[0], m2 = o2[1], q2 = o2[2], n3 = o3[0], m3 = o3[1], q3 = o3[2];
+        chan_merge(n0, m0, q0, n1, m1, q1);
+        chan_merge(n2, m2, q2, n3, m3, q3);
+        chan_merge(n0, m0, q0, n2, m2, q2);
+        chan_merge(na, ma, qa, n0, m0, q0);
+    }
+    for (; s < slices; s += 256) {
         const float* o = partial + ((size_t)s * C + c) * 3;
         chan_merge(na, ma, qa, o[0], o[1], o[2]);
     }
@@ -384,17 +397,32 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(
     const float* __restrict__ partial, int slices, int C, int64_t M, const float* __restrict__ gamma,
     const float* __restrict__ invstd, float* dgamma, float* dbeta, float* coefA, float* coefB1,
     float* coefB2, int accumulate) {
-    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    // one 256-thread block per channel, fixed summation order (deterministic)
+    __shared__ float sh[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
     float a = 0.f, b = 0.f;
-    for (int s = lane; s < slices; s += 64) {
+    int s = tid;
+    for (; s + 768 < slices; s += 1024) {
+        const float* o0 = partial + ((size_t)s * C + c) * 2;
+        const float* o1 = o0 + (size_t)256 * C * 2;
+        const float* o2 = o1 + (size_t)256 * C * 2;
+        const float* o3 = o2 + (size_t)256 * C * 2;
+        float a0 = o0[0], b0 = o0[1], a1 = o1[0], b1 = o1[1], a2 = o2[0], b2 = o2[1], a3 = o3[0], b3 = o3[1];
+        a += (a0 + a1) + (a2 + a3);
+        b += (b0 + b1) + (b2 + b3);
+    }
+    for (; s < slices; s += 256) {
         const float* o = partial + ((size_t)s * C + c) * 2;
         a += o[0];
         b += o[1];
     }
     a = wave_sum(a);
     b = wave_sum(b);
-    if (lane != 0) return;
+    if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; }
+    __syncthreads();
+    if (tid != 0) return;
+    a = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    b = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     dbeta[c] = accumulate ? dbeta[c] + a : a;
     dgamma[c] = accumulate ? dgamma[c] + b : b;
     coefA[c] = gamma[c] * invstd[c];
@@ -553,7 +581,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
                        (const T*)dy, (const T*)x, (const T*)y, mask, gamma, beta, sm, si, partial, M, C, relu, g);
     CNK_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, g.slices,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, g.slices,
                        C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
     CNK_CHECK_LAUNCH("bn_bwd_final");
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,

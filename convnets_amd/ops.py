@@ -266,6 +266,7 @@ class Conv2dFn(torch.autograd.Function):
         link: optional GradLink shared with the other consumer of x (residual blocks)."""
         _require_gpu(x)
         lib = _lib.load()
+        ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) bn_partial
         x = _nhwc(x)
         w = weight if weight.is_contiguous() else weight.contiguous()
         desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x))
@@ -296,6 +297,8 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
+        if dy is None:                        # y took no part in the loss
+            return (None,) * 8
         x, w = ctx.saved_tensors
         desc = ctx.desc
         dy = _nhwc(dy)
