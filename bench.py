@@ -55,9 +55,9 @@ def pmc_traffic(kernel):
         return None
     try:
         tab = json.load(open(path))
-        for k, v in tab.get('kernels', {}).items():
-            if k.split(' ')[0] in kernel:
-                return v
+        for k, v in tab.get('families', {}).items():
+            if k and k in kernel:
+                return dict(v, source='profiles/pmc_traffic.json (%s)' % tab.get('tag', '?'))
     except Exception:
         return None
     return None

@@ -35,7 +35,7 @@ def main(fetch_dir, write_dir, stats_dir, tag):
     f = glob.glob(os.path.join(stats_dir, '*', '*_kernel_stats.csv'))[0]
     for r in csv.DictReader(open(f)):
         stats[short(r['Name'])] = (int(r['Calls']), float(r['TotalDurationNs']), float(r['AverageNs']))
-    rows, out = [], {}
+    rows, out, fam = [], {}, collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     for k in fa:
         nf, fs = fa[k]
         nw, ws = wa.get(k, (1, 0.0))
@@ -43,6 +43,8 @@ def main(fetch_dir, write_dir, stats_dir, tag):
         write = ws * 1024 / max(nw, 1)
         calls, tot, avg = stats.get(k, (0, 0.0, 0.0))
         rows.append((tot, k, nf, fetch, write, avg))
+        f_ = fam[k.split('<')[0].strip()]
+        f_[0] += nf; f_[1] += fetch * nf; f_[2] += write * nf; f_[3] += avg * nf
         out[k] = {'unit': 'bytes/launch', 'fetch': round(fetch), 'write': round(write), 'total': round(fetch + write),
                   'avg_launch_us': round(avg / 1e3, 2),
                   'hbm_side_GBps': round((fetch + write) / avg, 1) if avg else None}
@@ -54,7 +56,11 @@ def main(fetch_dir, write_dir, stats_dir, tag):
     print(txt)
     os.makedirs('profiles', exist_ok=True)
     json.dump({'tag': tag, 'note': 'FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact; KiB->bytes; separate --pmc passes',
-               'kernels': out}, open('profiles/pmc_traffic.json', 'w'), indent=1)
+               'kernels': out,
+               'families': {k: {'unit': 'bytes/launch (launch-weighted mean over template variants)', 'launches_profiled': v[0],
+                                'fetch': round(v[1] / v[0]), 'write': round(v[2] / v[0]), 'total': round((v[1] + v[2]) / v[0]),
+                                'avg_launch_us': round(v[3] / v[0] / 1e3, 2)} for k, v in fam.items() if v[0]}},
+              open('profiles/pmc_traffic.json', 'w'), indent=1)
     open('profiles/%s_pmc_traffic.txt' % tag, 'w').write(txt + '\n')
 
 
