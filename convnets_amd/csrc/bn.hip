@@ -10,6 +10,7 @@
 //                   pass 2  bn_bwd_apply  dx = a*(dy' - b1 - xhat*b2); optional dresidual = dy'
 // Algorithmic bytes: forward 3*E*s (x twice, y once), backward reads dy,x(,y) twice + writes dx.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -55,11 +56,13 @@ SliceGeom make_geom(int64_t M, int C, int vec) {
     g.cpb = g.cols < 32 ? g.cols : 32;
     g.rpb = 256 / g.cpb;
     g.colgroups = ceil_div(g.cols, g.cpb);
-    int64_t want_slices = 2048 / g.colgroups;
+    static const int target = [] { const char* e = getenv("CNK_BN_BLOCKS"); return e ? atoi(e) : 2048; }();
+    static const int rpt_max = [] { const char* e = getenv("CNK_BN_RPT"); return e ? atoi(e) : 32; }();
+    int64_t want_slices = target / g.colgroups;
     if (want_slices < 1) want_slices = 1;
     int64_t sr = ceil_div64(M, want_slices);
     int64_t rpt = ceil_div64(sr, g.rpb);
-    rpt = rpt < 8 ? 8 : (rpt > 32 ? 32 : rpt);
+    rpt = rpt < 8 ? 8 : (rpt > rpt_max ? rpt_max : rpt);
     sr = (int64_t)g.rpb * rpt;
     if (sr < 64) sr = ceil_div64(64, g.rpb) * g.rpb;          // partial traffic 6/sr of the tensor: < 10 %
     if (ceil_div64(M, sr) > 8192) sr = ceil_div64(ceil_div64(M, 8192), g.rpb) * g.rpb;
@@ -208,75 +211,96 @@ __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const
     shift[c] = beta[c] - rmean[c] * sc;
 }
 
-// y = act(x*scale + shift [+ res]).  Same (column-thread, row-thread) geometry as the statistics
-// pass: a thread owns VEC channels for all its rows, so the per-channel coefficients live in
-// registers and the only memory instructions in the loop are the 16-byte payload loads/stores.
-template <typename T, int VEC>
+// ---- streaming passes ---------------------------------------------------------------------------
+// All three streaming kernels share one shape: a thread owns VEC channels (one 16-byte vector) for
+// all its rows, so per-channel coefficients live in registers and the loop body is payload loads,
+// arithmetic and payload stores only.  Every mode (residual operand, ReLU, mask source, optional
+// outputs) is a template parameter: the main loop has no branches, issues the loads of ROWS_U rows
+// back to back and only then consumes them, which keeps ROWS_U x streams x 16 B in flight per lane.
+constexpr int ROWS_U = 4;
+
+template <int VEC> __device__ __forceinline__ void load_coef(float (&d)[VEC], const float* __restrict__ p) {
+    if constexpr (VEC % 4 == 0) {
+        if (((uintptr_t)p & 15) == 0) {              // wave-uniform: the arrays of one launch share alignment
+#pragma unroll
+            for (int i = 0; i < VEC; i += 4) {
+                f32x4 v = *(const f32x4*)(p + i);
+                d[i] = v[0]; d[i + 1] = v[1]; d[i + 2] = v[2]; d[i + 3] = v[3];
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) d[i] = p[i];
+}
+
+template <typename T, int VEC> struct Raw {          // one thread's 16-byte payload (or one element)
+    using V = typename std::conditional<VEC == 1, T, decltype(Vec16<T>::v)>::type;
+    V v;
+    __device__ __forceinline__ void load(const T* p) { v = *(const V*)p; }
+    __device__ __forceinline__ void store(T* p) const { *(V*)p = v; }
+    __device__ __forceinline__ float get(int i) const {
+        if constexpr (VEC == 1) return to_f32(v); else return to_f32(v[i]);
+    }
+    __device__ __forceinline__ void set(int i, float f) {
+        if constexpr (VEC == 1) v = from_f32<T>(f); else v[i] = from_f32<T>(f);
+    }
+};
+
+// y = act(x*scale + shift [+ res]); optional packed ReLU mask (one byte per vector: bit k = y_k > 0)
+template <typename T, int VEC, bool HAS_RES, bool RELU, bool WMASK>
+__device__ __forceinline__ void bn_apply_row(const Raw<T, VEC>& xv, const Raw<T, VEC>& rv, const float (&sc)[VEC],
+                                             const float (&sh)[VEC], T* __restrict__ yp,
+                                             unsigned char* __restrict__ mp) {
+    Raw<T, VEC> o;
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float a = xv.get(k) * sc[k] + sh[k];
+        if constexpr (HAS_RES) a += rv.get(k);
+        if constexpr (RELU) a = a > 0.f ? a : 0.f;
+        if constexpr (WMASK) bits |= (a > 0.f ? 1u : 0u) << k;
+        o.set(k, a);
+    }
+    o.store(yp);
+    if constexpr (WMASK) *mp = (unsigned char)bits;
+}
+
+template <typename T, int VEC, bool HAS_RES, bool RELU, bool WMASK>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
                                                        const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        unsigned char* __restrict__ mask, int64_t M,
-                                                       int C, int relu, SliceGeom g) {
+                                                       int C, SliceGeom g) {
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     if (trow >= g.rpb || vcol >= g.cols) return;
-    float sc[VEC], sh[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        sc[k] = scale[vcol * VEC + k];
-        sh[k] = shift[vcol * VEC + k];
-    }
     const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
     const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
-    // two rows per iteration: twice the bytes in flight per wave (these kernels are bound by
-    // outstanding-request depth, not by arithmetic)
+    const int64_t rstep = (int64_t)g.rpb * C;
     int64_t m = m0 + trow;
-    for (; m + g.rpb < m1; m += 2 * g.rpb) {
-        const int64_t off0 = m * C + (int64_t)vcol * VEC, off1 = off0 + (int64_t)g.rpb * C;
-        VLoad<T, VEC> v0, v1, r0, r1;
-        v0.load(x + off0);
-        v1.load(x + off1);
-        if (res) { r0.load(res + off0); r1.load(res + off1); }
+    int64_t off = m * C + (int64_t)vcol * VEC;
+    float sc[VEC], sh[VEC];
+    load_coef<VEC>(sc, scale + vcol * VEC);
+    load_coef<VEC>(sh, shift + vcol * VEC);
+    for (; m + (ROWS_U - 1) * g.rpb < m1; m += ROWS_U * g.rpb, off += ROWS_U * rstep) {
+        Raw<T, VEC> xv[ROWS_U], rv[ROWS_U];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            float a = v0.f[k] * sc[k] + sh[k], b = v1.f[k] * sc[k] + sh[k];
-            if (res) { a += r0.f[k]; b += r1.f[k]; }
-            if (relu) { a = a > 0.f ? a : 0.f; b = b > 0.f ? b : 0.f; }
-            v0.f[k] = a; v1.f[k] = b;
+        for (int u = 0; u < ROWS_U; ++u) {
+            xv[u].load(x + off + u * rstep);
+            if constexpr (HAS_RES) rv[u].load(res + off + u * rstep);
         }
-        v0.store(y + off0);
-        v1.store(y + off1);
-        if (mask) {                              // one byte per VEC-channel vector: bit k = (y_k > 0)
-            unsigned b0 = 0, b1 = 0;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                b0 |= (v0.f[k] > 0.f ? 1u : 0u) << k;
-                b1 |= (v1.f[k] > 0.f ? 1u : 0u) << k;
-            }
-            mask[m * g.cols + vcol] = (unsigned char)b0;
-            mask[(m + g.rpb) * g.cols + vcol] = (unsigned char)b1;
-        }
+        for (int u = 0; u < ROWS_U; ++u)
+            bn_apply_row<T, VEC, HAS_RES, RELU, WMASK>(xv[u], rv[u], sc, sh, y + off + u * rstep,
+                                                       mask + (m + (int64_t)u * g.rpb) * g.cols + vcol);
     }
-    if (m < m1) {
-        const int64_t off = m * C + (int64_t)vcol * VEC;
-        VLoad<T, VEC> v, r;
-        v.load(x + off);
-        if (res) r.load(res + off);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            float o = v.f[k] * sc[k] + sh[k];
-            if (res) o += r.f[k];
-            if (relu) o = o > 0.f ? o : 0.f;
-            v.f[k] = o;
-        }
-        v.store(y + off);
-        if (mask) {
-            unsigned b = 0;
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) b |= (v.f[k] > 0.f ? 1u : 0u) << k;
-            mask[m * g.cols + vcol] = (unsigned char)b;
-        }
+    for (; m < m1; m += g.rpb, off += rstep) {
+        Raw<T, VEC> xv, rv;
+        xv.load(x + off);
+        if constexpr (HAS_RES) rv.load(res + off);
+        bn_apply_row<T, VEC, HAS_RES, RELU, WMASK>(xv, rv, sc, sh, y + off, mask + m * g.cols + vcol);
     }
 }
 
@@ -309,60 +333,95 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const T* __restrict__ x,
     }
 }
 
-template <typename T, int VEC>
+// Where the backward takes the ReLU mask from: nothing (no ReLU), re-derived from x*scale+shift
+// (no residual operand), the packed bit mask the forward saved, or the forward output y.
+enum { ACT_NONE = 0, ACT_REMASK = 1, ACT_BITS = 2, ACT_Y = 3 };
+
+// masked gradient d' of one vector; `aux` is the mask byte (ACT_BITS) -- yv the forward output (ACT_Y)
+template <typename T, int VEC, int ACT>
+__device__ __forceinline__ void bn_masked(const Raw<T, VEC>& dv, const Raw<T, VEC>& xv, const Raw<T, VEC>& yv,
+                                          unsigned aux, const float (&sc)[VEC], const float (&sf)[VEC],
+                                          float (&d)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float v = dv.get(i);
+        if constexpr (ACT == ACT_REMASK) { if (!(xv.get(i) * sc[i] + sf[i] > 0.f)) v = 0.f; }
+        if constexpr (ACT == ACT_BITS) { if (!((aux >> i) & 1u)) v = 0.f; }
+        if constexpr (ACT == ACT_Y) { if (!(yv.get(i) > 0.f)) v = 0.f; }
+        d[i] = v;
+    }
+}
+
+template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
     const unsigned char* __restrict__ mask, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean,
-    const float* __restrict__ invstd, float* __restrict__ partial, int64_t M, int C, int relu,
-    SliceGeom g) {
+    const float* __restrict__ invstd, float* __restrict__ partial, int64_t M, int C, SliceGeom g) {
     __shared__ float sh[2][256 * (VEC > 1 ? VEC : 1)];
-    // ReLU mask source: saved bit mask > forward output y > recomputed x*scale+shift (no residual)
-    const bool remask = relu && y == nullptr && mask == nullptr;
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     const bool active = trow < g.rpb && vcol < g.cols;
     const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
     const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
-    float s1[VEC], s2[VEC], mu[VEC], is[VEC], sc[VEC], sf[VEC];
+    float s1[VEC], s2[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        s1[i] = s2[i] = 0.f;
-        mu[i] = active ? mean[vcol * VEC + i] : 0.f;
-        is[i] = active ? invstd[vcol * VEC + i] : 0.f;
-        sc[i] = (active && remask) ? gamma[vcol * VEC + i] * is[i] : 0.f;
-        sf[i] = (active && remask) ? beta[vcol * VEC + i] - mu[i] * sc[i] : 0.f;
-    }
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
     if (active) {
-        for (int64_t m = m0 + trow; m < m1; m += 2 * g.rpb) {
-            const bool two = m + g.rpb < m1;
-            int64_t off[2] = {m * C + (int64_t)vcol * VEC, (m + g.rpb) * C + (int64_t)vcol * VEC};
-            VLoad<T, VEC> vd[2], vx[2], vy[2];
-            unsigned mb[2] = {0, 0};
+        float mu[VEC], sc[VEC], sf[VEC];
+        load_coef<VEC>(mu, mean + vcol * VEC);
+        if constexpr (ACT == ACT_REMASK) {
+            float is[VEC];
+            load_coef<VEC>(is, invstd + vcol * VEC);
+            load_coef<VEC>(sc, gamma + vcol * VEC);
+            load_coef<VEC>(sf, beta + vcol * VEC);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 0 || two) {
-                    vd[u].load(dy + off[u]);
-                    vx[u].load(x + off[u]);
-                    if (mask) mb[u] = mask[(m + u * g.rpb) * g.cols + vcol];
-                    else if (relu && !remask) vy[u].load(y + off[u]);
-                }
+            for (int i = 0; i < VEC; ++i) { sc[i] *= is[i]; sf[i] -= mu[i] * sc[i]; }
+        }
+        const int64_t rstep = (int64_t)g.rpb * C;
+        int64_t m = m0 + trow;
+        int64_t off = m * C + (int64_t)vcol * VEC;
+        // s2 accumulates d'*(x - mu); the common factor invstd is applied once at the end
+        for (; m + (ROWS_U - 1) * g.rpb < m1; m += ROWS_U * g.rpb, off += ROWS_U * rstep) {
+            Raw<T, VEC> dv[ROWS_U], xv[ROWS_U], yv[ROWS_U];
+            unsigned aux[ROWS_U];
+#pragma unroll
+            for (int u = 0; u < ROWS_U; ++u) {
+                dv[u].load(dy + off + u * rstep);
+                xv[u].load(x + off + u * rstep);
+                if constexpr (ACT == ACT_BITS) aux[u] = mask[(m + (int64_t)u * g.rpb) * g.cols + vcol];
+                if constexpr (ACT == ACT_Y) yv[u].load(y + off + u * rstep);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 0 || two) {
+            for (int u = 0; u < ROWS_U; ++u) {
+                float d[VEC];
+                bn_masked<T, VEC, ACT>(dv[u], xv[u], yv[u], aux[u], sc, sf, d);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        float d = vd[u].f[i];
-                        if (remask) vy[u].f[i] = vx[u].f[i] * sc[i] + sf[i];
-                        if (mask) vy[u].f[i] = ((mb[u] >> i) & 1u) ? 1.f : 0.f;
-                        if (relu && !(vy[u].f[i] > 0.f)) d = 0.f;
-                        s1[i] += d;
-                        s2[i] += d * (vx[u].f[i] - mu[i]) * is[i];
-                    }
+                for (int i = 0; i < VEC; ++i) {
+                    s1[i] += d[i];
+                    s2[i] += d[i] * (xv[u].get(i) - mu[i]);
                 }
             }
         }
+        for (; m < m1; m += g.rpb, off += rstep) {
+            Raw<T, VEC> dv, xv, yv;
+            unsigned aux = 0;
+            dv.load(dy + off);
+            xv.load(x + off);
+            if constexpr (ACT == ACT_BITS) aux = mask[m * g.cols + vcol];
+            if constexpr (ACT == ACT_Y) yv.load(y + off);
+            float d[VEC];
+            bn_masked<T, VEC, ACT>(dv, xv, yv, aux, sc, sf, d);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                s1[i] += d[i];
+                s2[i] += d[i] * (xv.get(i) - mu[i]);
+            }
+        }
+        float is[VEC];
+        load_coef<VEC>(is, invstd + vcol * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s2[i] *= is[i];
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -430,60 +489,78 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(
     coefB2[c] = b / (float)M;
 }
 
-template <typename T, int VEC>
+// dx = a*(d' - b1 - (x-mu)*(is*b2)); the centred form keeps fp32 accuracy when |mu| >> sigma
+template <typename T, int VEC, int ACT, bool WRES>
+__device__ __forceinline__ void bn_bwd_row(const Raw<T, VEC>& dv, const Raw<T, VEC>& xv, const Raw<T, VEC>& yv,
+                                           unsigned aux, const float (&ka)[VEC], const float (&kb1)[VEC],
+                                           const float (&kmu)[VEC], const float (&kis)[VEC],
+                                           const float (&ksf)[VEC], T* __restrict__ dxp, T* __restrict__ drp) {
+    float d[VEC];
+    bn_masked<T, VEC, ACT>(dv, xv, yv, aux, ka, ksf, d);
+    Raw<T, VEC> o, r;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        o.set(k, ka[k] * (d[k] - kb1[k] - (xv.get(k) - kmu[k]) * kis[k]));
+        if constexpr (WRES) r.set(k, d[k]);
+    }
+    o.store(dxp);
+    if constexpr (WRES) r.store(drp);
+}
+
+template <typename T, int VEC, int ACT, bool WRES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ dx,
     T* __restrict__ dres, const unsigned char* __restrict__ mask, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ coefA, const float* __restrict__ coefB1,
-    const float* __restrict__ coefB2, int64_t M, int C, int relu, SliceGeom g) {
+    const float* __restrict__ coefB2, int64_t M, int C, SliceGeom g) {
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     if (trow >= g.rpb || vcol >= g.cols) return;
-    const bool remask = relu && y == nullptr && mask == nullptr;
-    // dx = a*(d - b1 - (x-mu)*(is*b2)); the centred form keeps fp32 accuracy when |mu| >> sigma
-    float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC], ksf[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        int c = vcol * VEC + k;
-        ka[k] = coefA[c];                       // gamma*invstd == the forward's scale
-        kb1[k] = coefB1[c];
-        kmu[k] = mean[c];
-        kis[k] = invstd[c] * coefB2[c];
-        ksf[k] = remask ? beta[c] - kmu[k] * ka[k] : 0.f;
-    }
     const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
     const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
-    for (int64_t m = m0 + trow; m < m1; m += 2 * g.rpb) {
-        const bool two = m + g.rpb < m1;
-        int64_t off[2] = {m * C + (int64_t)vcol * VEC, (m + g.rpb) * C + (int64_t)vcol * VEC};
-        VLoad<T, VEC> vd[2], vx[2], vy[2], vo[2];
-        unsigned mb[2] = {0, 0};
+    const int64_t rstep = (int64_t)g.rpb * C;
+    int64_t m = m0 + trow;
+    int64_t off = m * C + (int64_t)vcol * VEC;
+    float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC], ksf[VEC];
+    load_coef<VEC>(ka, coefA + vcol * VEC);             // gamma*invstd == the forward's scale
+    load_coef<VEC>(kb1, coefB1 + vcol * VEC);
+    load_coef<VEC>(kmu, mean + vcol * VEC);
+    load_coef<VEC>(kis, invstd + vcol * VEC);
+    {
+        float b2[VEC];
+        load_coef<VEC>(b2, coefB2 + vcol * VEC);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 0 || two) {
-                vd[u].load(dy + off[u]);
-                vx[u].load(x + off[u]);
-                if (mask) mb[u] = mask[(m + u * g.rpb) * g.cols + vcol];
-                else if (relu && !remask) vy[u].load(y + off[u]);
-            }
+        for (int k = 0; k < VEC; ++k) kis[k] *= b2[k];
+    }
+    if constexpr (ACT == ACT_REMASK) {
+        load_coef<VEC>(ksf, beta + vcol * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) ksf[k] -= kmu[k] * ka[k];
+    }
+    for (; m + (ROWS_U - 1) * g.rpb < m1; m += ROWS_U * g.rpb, off += ROWS_U * rstep) {
+        Raw<T, VEC> dv[ROWS_U], xv[ROWS_U], yv[ROWS_U];
+        unsigned aux[ROWS_U];
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) {
+            dv[u].load(dy + off + u * rstep);
+            xv[u].load(x + off + u * rstep);
+            if constexpr (ACT == ACT_BITS) aux[u] = mask[(m + (int64_t)u * g.rpb) * g.cols + vcol];
+            if constexpr (ACT == ACT_Y) yv[u].load(y + off + u * rstep);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 0 || two) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    float d = vd[u].f[k];
-                    if (remask) vy[u].f[k] = vx[u].f[k] * ka[k] + ksf[k];
-                    if (mask) vy[u].f[k] = ((mb[u] >> k) & 1u) ? 1.f : 0.f;
-                    if (relu && !(vy[u].f[k] > 0.f)) d = 0.f;
-                    vd[u].f[k] = d;
-                    vo[u].f[k] = ka[k] * (d - kb1[k] - (vx[u].f[k] - kmu[k]) * kis[k]);
-                }
-                vo[u].store(dx + off[u]);
-                if (dres) vd[u].store(dres + off[u]);
-            }
-        }
+        for (int u = 0; u < ROWS_U; ++u)
+            bn_bwd_row<T, VEC, ACT, WRES>(dv[u], xv[u], yv[u], aux[u], ka, kb1, kmu, kis, ksf,
+                                          dx + off + u * rstep, dres + off + u * rstep);
+    }
+    for (; m < m1; m += g.rpb, off += rstep) {
+        Raw<T, VEC> dv, xv, yv;
+        unsigned aux = 0;
+        dv.load(dy + off);
+        xv.load(x + off);
+        if constexpr (ACT == ACT_BITS) aux = mask[m * g.cols + vcol];
+        if constexpr (ACT == ACT_Y) yv.load(y + off);
+        bn_bwd_row<T, VEC, ACT, WRES>(dv, xv, yv, aux, ka, kb1, kmu, kis, ksf, dx + off, dres + off);
     }
 }
 
@@ -529,8 +606,22 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, slices, C,
                        M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
     CNK_CHECK_LAUNCH("bn_finalize");
-    hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)x, (const T*)res, (T*)y, scale, shift, mask, M, C, relu, g);
+    const dim3 grid(g.slices, g.colgroups);
+#define CNK_BN_APPLY(R, A, W)                                                                              \
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, R, A, W>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
+                       (T*)y, scale, shift, mask, M, C, g)
+    const int key = (res ? 4 : 0) | (relu ? 2 : 0) | (mask ? 1 : 0);
+    switch (key) {
+        case 0: CNK_BN_APPLY(false, false, false); break;
+        case 1: CNK_BN_APPLY(false, false, true); break;
+        case 2: CNK_BN_APPLY(false, true, false); break;
+        case 3: CNK_BN_APPLY(false, true, true); break;
+        case 4: CNK_BN_APPLY(true, false, false); break;
+        case 5: CNK_BN_APPLY(true, false, true); break;
+        case 6: CNK_BN_APPLY(true, true, false); break;
+        default: CNK_BN_APPLY(true, true, true); break;
+    }
+#undef CNK_BN_APPLY
     CNK_CHECK_LAUNCH("bn_apply");
     return 0;
 }
@@ -578,15 +669,37 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
     float* coefB1 = ws + 2 * C;
     float* coefB2 = ws + 3 * C;
     float* partial = ws + ws_partials_off(C);
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)dy, (const T*)x, (const T*)y, mask, gamma, beta, sm, si, partial, M, C, relu, g);
+    // ReLU mask source: saved bit mask > forward output y > re-derived from x*scale+shift (no residual)
+    const int act = !relu ? ACT_NONE : mask ? ACT_BITS : y ? ACT_Y : ACT_REMASK;
+    const dim3 grid(g.slices, g.colgroups);
+#define CNK_BN_RED(A)                                                                                       \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, A>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \
+                       (const T*)y, mask, gamma, beta, sm, si, partial, M, C, g)
+    switch (act) {
+        case ACT_NONE: CNK_BN_RED(ACT_NONE); break;
+        case ACT_REMASK: CNK_BN_RED(ACT_REMASK); break;
+        case ACT_BITS: CNK_BN_RED(ACT_BITS); break;
+        default: CNK_BN_RED(ACT_Y); break;
+    }
+#undef CNK_BN_RED
     CNK_CHECK_LAUNCH("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, g.slices,
                        C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
     CNK_CHECK_LAUNCH("bn_bwd_final");
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC>), dim3(g.slices, g.colgroups), dim3(256), 0, s,
-                       (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, mask, beta, sm, si, coefA, coefB1,
-                       coefB2, M, C, relu, g);
+#define CNK_BN_BAPP(A, W)                                                                                     \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, A, W>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \
+                       (const T*)y, (T*)dx, (T*)dres, mask, beta, sm, si, coefA, coefB1, coefB2, M, C, g)
+    switch (act * 2 + (dres ? 1 : 0)) {
+        case ACT_NONE * 2: CNK_BN_BAPP(ACT_NONE, false); break;
+        case ACT_NONE * 2 + 1: CNK_BN_BAPP(ACT_NONE, true); break;
+        case ACT_REMASK * 2: CNK_BN_BAPP(ACT_REMASK, false); break;
+        case ACT_REMASK * 2 + 1: CNK_BN_BAPP(ACT_REMASK, true); break;
+        case ACT_BITS * 2: CNK_BN_BAPP(ACT_BITS, false); break;
+        case ACT_BITS * 2 + 1: CNK_BN_BAPP(ACT_BITS, true); break;
+        case ACT_Y * 2: CNK_BN_BAPP(ACT_Y, false); break;
+        default: CNK_BN_BAPP(ACT_Y, true); break;
+    }
+#undef CNK_BN_BAPP
     CNK_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }

@@ -16,6 +16,9 @@
 
 #include "common.h"
 
+#ifndef CNK_ABLATE
+#define CNK_ABLATE 0      // debug builds only (tools/ablate.sh): 1 no MFMA phase, 2 no global loads, 4 no LDS reads
+#endif
 namespace {
 
 constexpr int BM = 128;
@@ -64,6 +67,114 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >
 __device__ __attribute__((aligned(16))) unsigned int cnk_zero16[4] = {0, 0, 0, 0};
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef const __attribute__((address_space(1))) void* gptr_t;
+
+// Shared epilogue of the implicit-GEMM kernels (see the comment inside): bias, LDS-staged
+// coalesced row stores, optional gradient addend (+ReLU mask), optional BN statistics partials.
+template <typename T, int BN>
+__device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned char* smem,
+                                               const int* row_dst, f32x16 (&acc)[2][BN / 64],
+                                               int tile_m, int tile_n, int tid, int wm, int wn,
+                                               int l31, int lh) {
+    constexpr int PER16 = ElemTraits<T>::PER16;
+    constexpr int NJ = BN / 64;
+    // Epilogue.  The MFMA computed the TRANSPOSED block (weights as the row operand), so lane
+    // (l31, lh) holds pixel row l31 and, in registers 4g..4g+3, the four consecutive output
+    // channels 8g + 4*lh + {0..3}: one 8-byte (bf16) / 16-byte (fp32) LDS store per group.  The
+    // tile is then written to HBM as whole rows, 16 bytes per lane, coalesced.
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CS = BN * ES + 16;                 // staged row stride
+    unsigned char* Cs = smem + BM * sizeof(int);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int row = wm * 64 + i * 32 + l31;
+                const int col = wn * (BN / 2) + j * 32 + 8 * gq + 4 * lh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.bias[tile_n * BN + col + e];
+                }
+                if constexpr (ES == 2) {
+                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *(bf16x4*)(Cs + row * CS + col * 2) = o;
+                } else {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(Cs + row * CS + col * 4) = o;
+                }
+            }
+    __syncthreads();
+    constexpr int CPR = BN * ES / 16;                // 16-B chunks per row
+    constexpr int RPP = 256 / CPR;                   // rows per pass
+    unsigned char* dst = (unsigned char*)p.dst;
+    const int crow = tid / CPR, cc = tid - crow * CPR;
+    float s8[PER16], q8[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) s8[e] = q8[e] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+        const int row = ps * RPP + crow;
+        const int pix = row_dst[row];
+        if (pix >= 0) {
+            Vec16<T> v;
+            v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
+            const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
+            if (p.addend) {              // same rounding as a separate add kernel: round(round(conv) + addend)
+                Vec16<T> a;
+                a.v = *(const decltype(a.v)*)((const unsigned char*)p.addend + goff);
+                // with a mask the addend is dy of the block output and the mask its ReLU pattern:
+                // addend*mask is the residual-branch gradient, formed here instead of being written
+                // out by the BN backward and read back
+                const unsigned mb = p.addend_mask ? p.addend_mask[goff >> 4] : 0xFFu;
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + (((mb >> e) & 1u) ? a.get(e) : 0.f));
+            }
+            *(decltype(v.v)*)(dst + goff) = v.v;
+            if (p.stats) {
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) {
+                    float f = v.get(e);
+                    s8[e] += f;
+                    q8[e] += f * f;
+                }
+            }
+        }
+    }
+    // Fused BN statistics of the values just stored (i.e. of the ROUNDED output, exactly what the
+    // BN kernels would read back): per-channel sum / sum-of-squares over this tile's <=128 rows ->
+    // (n, mean, M2) partial, merged across tiles by bn_finalize (Chan).  Saves one full read pass.
+    if (p.stats) {
+        // the reduction scratch reuses the staged tile (everyone has finished reading it), which
+        // keeps the epilogue LDS at 35 KiB so four workgroups fit a CU
+        __syncthreads();
+        float* red = (float*)Cs;                      // [2][RPP][BN]
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) {
+            red[crow * BN + cc * PER16 + e] = s8[e];
+            red[(RPP + crow) * BN + cc * PER16 + e] = q8[e];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < RPP; ++r) {
+                S += red[r * BN + tid];
+                Q += red[(RPP + r) * BN + tid];
+            }
+            const int nvalid = min(BM, p.M - tile_m * BM);
+            const float mean = S / (float)nvalid;
+            float m2 = Q - S * mean;
+            float* o = p.stats + ((size_t)tile_m * p.Nout + tile_n * BN + tid) * 3;
+            o[0] = (float)nvalid;
+            o[1] = mean;
+            o[2] = m2 > 0.f ? m2 : 0.f;
+        }
+    }
+}
 
 template <typename T, int BN, int NBUF, bool GLDS>
 __global__ __launch_bounds__(256, GLDS ? (NBUF == 2 ? 2 : 4) : (NBUF == 2 ? 2 : 3)) void igemm_gather_kernel(const GatherParams p) {
@@ -279,103 +390,294 @@ __global__ __launch_bounds__(256, GLDS ? (NBUF == 2 ? 2 : 4) : (NBUF == 2 ? 2 : 
     }
     }   // register-staged path
 
-    // Epilogue.  The MFMA computed the TRANSPOSED block (weights as the row operand), so lane
-    // (l31, lh) holds pixel row l31 and, in registers 4g..4g+3, the four consecutive output
-    // channels 8g + 4*lh + {0..3}: one 8-byte (bf16) / 16-byte (fp32) LDS store per group.  The
-    // tile is then written to HBM as whole rows, 16 bytes per lane, coalesced.
-    constexpr int ES = (int)sizeof(T);
-    constexpr int CS = BN * ES + 16;                 // staged row stride
-    unsigned char* Cs = smem + BM * sizeof(int);
+    igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
+}
+
+// 3x3 / stride 1 / "same" convolutions (forward, and the data gradient of such a conv): halo reuse.
+// All nine taps of an output pixel read input pixels within +-1 row / +-1 column, i.e. within
+// +-(W+1) positions of the flattened NHW pixel index.  So instead of gathering a fresh 128-row A
+// tile for every tap (9x the input bytes through L2), the workgroup loads the pixel range
+// [m0-W-1, m0+128+W+1) of one 64(32)-channel chunk into LDS ONCE and the nine taps read SHIFTED
+// windows of that patch; only the 16 KiB weight tile is streamed per tap.  L2 bytes per K step drop
+// from 32 KiB to ~19 KiB (BN=128) / 24 -> 11 KiB (BN=64).  Image-border and cross-image positions
+// are real (wrong) pixels in the patch, so each lane keeps a 9-bit validity mask per MFMA row and
+// zeroes the fragment when the tap falls outside the image.
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 3) void igemm_halo3x3_kernel(const GatherParams p) {
+    constexpr int PER16 = ElemTraits<T>::PER16;
+    constexpr int KSTEP = 8 * PER16;
+    constexpr int NJ = BN / 64;
+    constexpr int B_LOADS = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* row_dst = (int*)smem;
+    const int W = p.IW, NP = BM + 2 * W + 2, NPG = (NP + 7) >> 3;
+    unsigned char* Ps = smem + BM * sizeof(int);         // [NPG*8][128 B] pixel patch
+    unsigned char* Bs = Ps + NPG * 8 * 128;              // [BN][128 B]
+    int bid = blockIdx.x;
+    {
+        int nwg = p.tiles_total, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    const int chunk = tid & 7, lrow = tid >> 3;
+    if (tid < BM) {
+        int m = tile_m * BM + tid, v = -1;
+        if (m < p.M) {
+            uint32_t img = fd_div(m, p.fd_ohw), rem = m - img * p.fd_ohw.d;
+            uint32_t oh = fd_div(rem, p.fd_ow), ow = rem - oh * p.fd_ow.d;
+            v = (img * p.FH + oh * p.dm_h + p.d_h0) * p.FW + ow * p.dm_w + p.d_w0;
+        }
+        row_dst[tid] = v;
+    }
+    unsigned vm[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = tile_m * BM + wm * 64 + i * 32 + l31;
+        unsigned bits = 0;
+        if (m < p.M) {
+            uint32_t img = fd_div(m, p.fd_ohw), rem = m - img * p.fd_ohw.d;
+            uint32_t oh = fd_div(rem, p.fd_ow), ow = rem - oh * p.fd_ow.d;
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)((int)oh + p.dh[t]) < (unsigned)p.IH && (unsigned)((int)ow + p.dw[t]) < (unsigned)p.IW)
+                    bits |= 1u << t;
+        }
+        vm[i] = bits;
+    }
+    const T* src = (const T*)p.src;
+    const T* wpk = (const T*)p.wpk;
+    const int csteps = p.C / KSTEP;
+    const size_t wrow = (size_t)9 * p.C;
+    const long long P0 = (long long)tile_m * BM - W - 1, Mtot = (long long)p.N * p.IH * p.IW;
+    lds_u8* Ps3 = (lds_u8*)Ps;
+    lds_u8* Bs3 = (lds_u8*)Bs;
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int row = wm * 64 + i * 32 + l31;
-                const int col = wn * (BN / 2) + j * 32 + 8 * gq + 4 * lh;
-                float v[4];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int cs = 0; cs < csteps; ++cs) {
+        // pixel patch of this channel chunk: row group g = 8 consecutive pixels, one wave instruction
+#if !(CNK_ABLATE & 2)
+        for (int gq = wave; gq < NPG; gq += 4) {
+            const int j = gq * 8 + (lane >> 3);
+            const long long q = P0 + j;
+            const int c = chunk ^ ((j >> 1) & 7);
+            const T* gp = (q >= 0 && q < Mtot && j < NP) ? src + (size_t)q * p.C + cs * KSTEP + c * PER16
+                                                         : (const T*)cnk_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Ps3 + gq * 8 * 128), 16, 0, 0);
+        }
+#endif
+        for (int t = 0; t < 9; ++t) {
+#if !(CNK_ABLATE & 2)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
-                if (p.bias) {
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int r = lrow + 32 * i;
+                const int c = chunk ^ ((r >> 1) & 7);
+                const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.C + cs * KSTEP + c * PER16;
+                __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+            }
+#endif
+            __syncthreads();                         // vmcnt(0) + barrier: patch (t == 0) and weights landed
+            const int off = W + 1 + p.dh[t] * W + p.dw[t];
+#if !(CNK_ABLATE & 1)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.bias[tile_n * BN + col + e];
+            for (int s = 0; s < 4; ++s) {
+                u32x4 fa[2], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int j = wm * 64 + i * 32 + l31 + off;
+#if (CNK_ABLATE & 4)
+                    u32x4 v = u32x4{(unsigned)j, (unsigned)s, (unsigned)t, (unsigned)cs};
+#else
+                    u32x4 v = *(const u32x4*)(Ps + j * 128 + swz(j, 2 * s + lh));
+#endif
+                    const bool ok = (vm[i] >> t) & 1u;
+                    fa[i] = ok ? v : u32x4{0, 0, 0, 0};
                 }
-                if constexpr (ES == 2) {
-                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *(bf16x4*)(Cs + row * CS + col * 2) = o;
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn) {
+                    const int r = wn * (BN / 2) + jn * 32 + l31;
+#if (CNK_ABLATE & 4)
+                    fb[jn] = u32x4{(unsigned)r, (unsigned)s, (unsigned)t, (unsigned)cs};
+#else
+                    fb[jn] = *(const u32x4*)(Bs + r * 128 + swz(r, 2 * s + lh));
+#endif
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) Mma32<T>::run(acc[i][jn], fb[jn], fa[i]);
+            }
+#endif
+            __syncthreads();                         // weights (and at t == 8 the patch) free again
+        }
+    }
+    igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
+}
+
+// Same algorithm with the weight stream software-pipelined: three weight buffers, the tiles of steps
+// g+1 and g+2 are in flight (LDS-DMA) while step g is computed.  An LDS-DMA is a pending write on
+// the vector-memory counter, so the pipeline uses counted `s_waitcnt vmcnt(N)` and raw `s_barrier`
+// (a __syncthreads() would drain everything): a tile is read one barrier AFTER the wait that
+// retires it, and a buffer is re-issued only after the barrier that follows its last read.
+// 32 KiB patch + 3 x 16 KiB weights = 80 KiB -> two workgroups per CU.
+#define CNK_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_halo3x3_pf_kernel(const GatherParams p) {
+    constexpr int PER16 = ElemTraits<T>::PER16;
+    constexpr int KSTEP = 8 * PER16;
+    constexpr int NJ = BN / 64;
+    constexpr int B_LOADS = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* row_dst = (int*)smem;
+    const int W = p.IW, NP = BM + 2 * W + 2, NPG = (NP + 7) >> 3;
+    unsigned char* Ps = smem + BM * sizeof(int);         // [NPG*8][128 B]
+    unsigned char* Bs = Ps + NPG * 8 * 128;              // [3][BN][128 B]
+    int bid = blockIdx.x;
+    {
+        int nwg = p.tiles_total, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    const int chunk = tid & 7, lrow = tid >> 3;
+    if (tid < BM) {
+        int m = tile_m * BM + tid, v = -1;
+        if (m < p.M) {
+            uint32_t img = fd_div(m, p.fd_ohw), rem = m - img * p.fd_ohw.d;
+            uint32_t oh = fd_div(rem, p.fd_ow), ow = rem - oh * p.fd_ow.d;
+            v = (img * p.FH + oh * p.dm_h + p.d_h0) * p.FW + ow * p.dm_w + p.d_w0;
+        }
+        row_dst[tid] = v;
+    }
+    unsigned vm[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = tile_m * BM + wm * 64 + i * 32 + l31;
+        unsigned bits = 0;
+        if (m < p.M) {
+            uint32_t img = fd_div(m, p.fd_ohw), rem = m - img * p.fd_ohw.d;
+            uint32_t oh = fd_div(rem, p.fd_ow), ow = rem - oh * p.fd_ow.d;
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)((int)oh + p.dh[t]) < (unsigned)p.IH && (unsigned)((int)ow + p.dw[t]) < (unsigned)p.IW)
+                    bits |= 1u << t;
+        }
+        vm[i] = bits;
+    }
+    const T* src = (const T*)p.src;
+    const T* wpk = (const T*)p.wpk;
+    const int csteps = p.C / KSTEP, G = csteps * 9;
+    const size_t wrow = (size_t)9 * p.C;
+    const long long P0 = (long long)tile_m * BM - W - 1, Mtot = (long long)p.N * p.IH * p.IW;
+    lds_u8* Ps3 = (lds_u8*)Ps;
+    lds_u8* Bs3 = (lds_u8*)Bs;
+    auto issue_patch = [&](int cs) {
+        for (int gq = wave; gq < NPG; gq += 4) {
+            const int j = gq * 8 + (lane >> 3);
+            const long long q = P0 + j;
+            const int c = chunk ^ ((j >> 1) & 7);
+            const T* gp = (q >= 0 && q < Mtot && j < NP) ? src + (size_t)q * p.C + cs * KSTEP + c * PER16
+                                                         : (const T*)cnk_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Ps3 + gq * 8 * 128), 16, 0, 0);
+        }
+    };
+    auto issue_b = [&](int gstep) {
+        const int cs = gstep / 9, t = gstep - cs * 9, buf = gstep % 3;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int r = lrow + 32 * i;
+            const int c = chunk ^ ((r >> 1) & 7);
+            const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.C + cs * KSTEP + c * PER16;
+            __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + buf * (BN * 128) + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const uint32_t ps_lds = (uint32_t)(uintptr_t)Ps3, bs_lds = (uint32_t)(uintptr_t)Bs3;
+    // tap -> patch row offset, fetched BEFORE any LDS-DMA is in flight: p.dh[t] with a run-time t is
+    // a vector load from the kernarg segment, and hipcc drains vmcnt(0) for any ordinary load result
+    // while DMAs are pending.
+    // (kept packed, 8 bits each, in three scalars: no memory access and no 9x unroll needed to index them)
+    uint32_t offp[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) offp[t >> 2] |= (uint32_t)(W + 1 + p.dh[t] * W + p.dw[t]) << ((t & 3) * 8);
+    issue_patch(0);
+    issue_b(0);
+    if (G > 1) issue_b(1);
+    int gs = 0;
+    for (int cs = 0; cs < csteps; ++cs) {
+        for (int t = 0; t < 9; ++t, ++gs) {
+            const int off_t = (int)(((t < 4 ? offp[0] : (t < 8 ? offp[1] : offp[2])) >> ((t & 3) * 8)) & 0xFFu);
+            // retire the weights of step gs (and, at the first tap of a chunk, the patch issued after them)
+            if (t == 0 || gs + 1 >= G) { CNK_WAIT_VM(0); }
+            else if (B_LOADS == 4) { CNK_WAIT_VM(4); }
+            else { CNK_WAIT_VM(2); }
+            __builtin_amdgcn_s_barrier();            // every wave's share has landed; step gs-1 fully read
+            if (gs + 2 < G) issue_b(gs + 2);         // buffer (gs+2)%3 held step gs-1
+            // Fragment reads are inline asm: hipcc cannot prove that a ds_read does not alias an
+            // LDS-DMA still in flight and would put `s_waitcnt vmcnt(0)` in front of them.  Reads of
+            // sub-step s+1 are issued before the MFMAs of sub-step s; a counted lgkmcnt retires
+            // exactly the older group.
+            const uint32_t Bb = bs_lds + (gs % 3) * (BN * 128);
+            uint32_t a_addr[2], b_addr[NJ];
+            int a_row[2], b_row[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a_row[i] = wm * 64 + i * 32 + l31 + off_t; a_addr[i] = ps_lds + a_row[i] * 128; }
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) { b_row[jn] = wn * (BN / 2) + jn * 32 + l31; b_addr[jn] = Bb + b_row[jn] * 128; }
+            const bool ok0 = (vm[0] >> t) & 1u, ok1 = (vm[1] >> t) & 1u;
+            u32x4 fa[2][2], fb[2][NJ];
+            auto issue_reads = [&](int s, int set) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][i]) : "v"(a_addr[i] + swz(a_row[i], 2 * s + lh)));
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][jn]) : "v"(b_addr[jn] + swz(b_row[jn], 2 * s + lh)));
+            };
+            issue_reads(0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1;
+                if (s < 3) {
+                    issue_reads(s + 1, cur ^ 1);
+                    if (NJ == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
                 } else {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(Cs + row * CS + col * 4) = o;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-            }
-    __syncthreads();
-    constexpr int CPR = BN * ES / 16;                // 16-B chunks per row
-    constexpr int RPP = 256 / CPR;                   // rows per pass
-    unsigned char* dst = (unsigned char*)p.dst;
-    const int crow = tid / CPR, cc = tid - crow * CPR;
-    float s8[PER16], q8[PER16];
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 za = ok0 ? fa[cur][0] : u32x4{0, 0, 0, 0};
+                u32x4 zb = ok1 ? fa[cur][1] : u32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < PER16; ++e) s8[e] = q8[e] = 0.f;
-#pragma unroll
-    for (int ps = 0; ps < BM / RPP; ++ps) {
-        const int row = ps * RPP + crow;
-        const int pix = row_dst[row];
-        if (pix >= 0) {
-            Vec16<T> v;
-            v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
-            const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
-            if (p.addend) {              // same rounding as a separate add kernel: round(round(conv) + addend)
-                Vec16<T> a;
-                a.v = *(const decltype(a.v)*)((const unsigned char*)p.addend + goff);
-                // with a mask the addend is dy of the block output and the mask its ReLU pattern:
-                // addend*mask is the residual-branch gradient, formed here instead of being written
-                // out by the BN backward and read back
-                const unsigned mb = p.addend_mask ? p.addend_mask[goff >> 4] : 0xFFu;
-#pragma unroll
-                for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + (((mb >> e) & 1u) ? a.get(e) : 0.f));
-            }
-            *(decltype(v.v)*)(dst + goff) = v.v;
-            if (p.stats) {
-#pragma unroll
-                for (int e = 0; e < PER16; ++e) {
-                    float f = v.get(e);
-                    s8[e] += f;
-                    q8[e] += f * f;
+                for (int jn = 0; jn < NJ; ++jn) {
+                    Mma32<T>::run(acc[0][jn], fb[cur][jn], za);
+                    Mma32<T>::run(acc[1][jn], fb[cur][jn], zb);
                 }
             }
         }
-    }
-    // Fused BN statistics of the values just stored (i.e. of the ROUNDED output, exactly what the
-    // BN kernels would read back): per-channel sum / sum-of-squares over this tile's <=128 rows ->
-    // (n, mean, M2) partial, merged across tiles by bn_finalize (Chan).  Saves one full read pass.
-    if (p.stats) {
-        // the reduction scratch reuses the staged tile (everyone has finished reading it), which
-        // keeps the epilogue LDS at 35 KiB so four workgroups fit a CU
-        __syncthreads();
-        float* red = (float*)Cs;                      // [2][RPP][BN]
-#pragma unroll
-        for (int e = 0; e < PER16; ++e) {
-            red[crow * BN + cc * PER16 + e] = s8[e];
-            red[(RPP + crow) * BN + cc * PER16 + e] = q8[e];
-        }
-        __syncthreads();
-        if (tid < BN) {
-            float S = 0.f, Q = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < RPP; ++r) {
-                S += red[r * BN + tid];
-                Q += red[(RPP + r) * BN + tid];
-            }
-            const int nvalid = min(BM, p.M - tile_m * BM);
-            const float mean = S / (float)nvalid;
-            float m2 = Q - S * mean;
-            float* o = p.stats + ((size_t)tile_m * p.Nout + tile_n * BN + tid) * 3;
-            o[0] = (float)nvalid;
-            o[1] = mean;
-            o[2] = m2 > 0.f ? m2 : 0.f;
+        if (cs + 1 < csteps) {
+            // the single patch buffer: every wave must be done with this chunk before the next
+            // chunk's pixels are DMA'd over it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_patch(cs + 1);
         }
     }
+    __syncthreads();                                 // LDS is reused by the epilogue
+    igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
 
 template <typename T, int BN, int NBUF, bool GLDS> int launch_gather_v(const GatherParams& p, hipStream_t s) {
@@ -419,6 +721,58 @@ static bool pick_bn128(int M, int Nout) {
     return (Nout % 128 == 0) && ((int64_t)tiles_m * (Nout / 128) >= 512);
 }
 
+static int igemm_halo_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CNK_IGEMM_HALO");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
+// Which halo kernel: the plain one runs three workgroups per CU, the weight-prefetching one two
+// (80 KiB of LDS each) but each of them ~1.16x faster than a third of a CU.  With T tiles on 256 CUs
+// the launch takes ceil(T/768) rounds of 3 or ceil(T/512) rounds of 2; prefetching pays when it
+// saves a round (measured: 256->256 @14x14, 784 tiles: 776 vs 687 TFLOP/s; every other ResNet
+// shape is faster on the plain kernel).  CNK_IGEMM_HALO_PF=0/1 forces one of them.
+static bool igemm_halo_pf(int tiles, int bn) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("CNK_IGEMM_HALO_PF");
+        forced = e ? (e[0] == '0' ? 0 : 1) : -1;
+    }
+    if (forced >= 0) return forced == 1;
+    if (bn != 128 || tiles <= 768) return false;
+    return ceil_div(tiles, 512) * 2 * 1.16 < ceil_div(tiles, 768) * 3;
+}
+
+template <typename T, int BN> size_t halo_lds(const GatherParams& p) {
+    size_t pipe = (size_t)((BM + 2 * p.IW + 2 + 7) / 8) * 8 * 128 + (size_t)BN * 128 * (igemm_halo_pf(p.tiles_total, BN) ? 3 : 1);
+    size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
+    size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);
+    if (red > epi) epi = red;
+    return BM * sizeof(int) + (pipe > epi ? pipe : epi);
+}
+
+// 3x3 taps within +-1, stride 1, output grid == source grid ("same" conv or its data gradient)
+static bool halo_shape(const GatherParams& p) {
+    if (p.ntaps != 9 || p.sm_h != 1 || p.sm_w != 1 || p.dm_h != 1 || p.dm_w != 1) return false;
+    if (p.IH != p.OH || p.IW != p.OW || p.FH != p.OH || p.FW != p.OW || p.d_h0 || p.d_w0) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.dh[t] < -1 || p.dh[t] > 1 || p.dw[t] < -1 || p.dw[t] > 1) return false;
+    return (long long)p.N * p.IH * p.IW == p.M;
+}
+
+template <typename T, int BN> int launch_halo(const GatherParams& p, hipStream_t s) {
+    const size_t lds = halo_lds<T, BN>(p);
+    if (igemm_halo_pf(p.tiles_total, BN))
+        hipLaunchKernelGGL((igemm_halo3x3_pf_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL((igemm_halo3x3_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    CNK_CHECK_LAUNCH("igemm_halo3x3");
+    return 0;
+}
+
 template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     int tiles_m = ceil_div(p.M, BM);
     bool use128 = pick_bn128(p.M, p.Nout);
@@ -426,6 +780,11 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     p.tiles_n = p.Nout / bn;
     p.tiles_total = tiles_m * p.tiles_n;
     if (p.tiles_total == 0) return 0;
+    if (igemm_halo_enabled() && halo_shape(p)) {
+        // three workgroups per CU need <= 53 KiB each; wider images fall back to the gather kernel
+        size_t lds = use128 ? halo_lds<T, 128>(p) : halo_lds<T, 64>(p);
+        if (lds <= (size_t)(igemm_halo_pf(p.tiles_total, bn) ? 80 : 53) * 1024) return use128 ? launch_halo<T, 128>(p, s) : launch_halo<T, 64>(p, s);
+    }
     return use128 ? launch_gather<T, 128>(p, s) : launch_gather<T, 64>(p, s);
 }
 
