@@ -21,6 +21,12 @@ class ConvDesc(ctypes.Structure):
                  'dtype')]
 
 
+class BnBwdFuse(ctypes.Structure):
+    """cnk_bn_bwd_fuse (include/cnk.h): BN backward folded into the conv dgrad epilogue."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'mean', 'invstd', 'gamma', 'beta', 'relu_mask', 'partial')] + \
+               [('relu', ctypes.c_int32)]
+
+
 class PackJob(ctypes.Structure):
     _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'ntaps', 'transpose', 'dtype', 'pad_')] + \
@@ -44,7 +50,8 @@ SIGNATURES = {
     'cnk_conv2d_fwd_bn_partial_slices': (_i64, [_dp]),
     'cnk_conv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'cnk_conv2d_dgrad_accepts_mask': (ctypes.c_int, [_dp]),
-    'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'cnk_conv2d_dgrad_bn_slices': (_i64, [_dp]),
+    'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnBwdFuse), _vp, _sz, _vp]),
     'cnk_conv2d_wgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_bn_workspace_bytes': (_sz, [_i64, _i32]),
     'cnk_bn_mask_bytes': (_sz, [_i64, _i32, ctypes.c_int]),
@@ -53,7 +60,7 @@ SIGNATURES = {
     'cnk_bn_fwd_eval': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32,
                                        ctypes.c_int, ctypes.c_int, _vp]),
     'cnk_bn_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
-                                  _i64, _i32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
+                                  _vp, _i64, _i64, _i32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_maxpool2d_fwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_maxpool2d_bwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_relu_fwd': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp]),

@@ -12,7 +12,8 @@
 bool igemm_supported(const cnk_conv_desc* d, int pass);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
-int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, hipStream_t s);
+int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
+int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
 int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
 bool wgrad_mfma_supported(const cnk_conv_desc* d);
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
@@ -42,7 +43,7 @@ size_t bn_workspace_bytes(int64_t M, int C);
 size_t bn_mask_bytes(int64_t M, int C, int dtype);
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
-int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
+int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, const float* ext_partial, int64_t ext_slices, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
 int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
 int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
@@ -195,7 +196,7 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
 }
 
 int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad, cnk_pack_job* jobs, int32_t max_jobs) {
-    if (int rc = check_desc(d, "cnk_conv2d_pack_jobs")) return -1;
+    if (check_desc(d, "cnk_conv2d_pack_jobs")) return -1;
     int n = 0;
     auto add = [&](void* out, int ntaps, const signed char* kh, const signed char* kw, int transpose) {
         if (ntaps == 0) return true;
@@ -253,7 +254,12 @@ int cnk_conv2d_dgrad_accepts_mask(const cnk_conv_desc* d) {
     return igemm_supported(d, CNK_PASS_DGRAD) && d->Cin % (d->dtype == CNK_BF16 ? 8 : 4) == 0;
 }
 
-int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const uint8_t* addend_mask, void* workspace, size_t workspace_bytes, void* stream) {
+int64_t cnk_conv2d_dgrad_bn_slices(const cnk_conv_desc* d) {
+    if (check_desc(d, "cnk_conv2d_dgrad_bn_slices")) return 0;
+    return igemm_supported(d, CNK_PASS_DGRAD) ? igemm_dgrad_bn_slices(d) : 0;
+}
+
+int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (int rc = check_desc(d, "cnk_conv2d_dgrad")) return rc;
     CNK_CHECK_ARG(dy && w_dgrad && dx, "cnk_conv2d_dgrad: null pointer");
@@ -261,7 +267,12 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
     CNK_CHECK_ARG(!addend_mask || (addend && igemm_supported(d, CNK_PASS_DGRAD) && d->Cin % (d->dtype == CNK_BF16 ? 8 : 4) == 0), "cnk_conv2d_dgrad: addend_mask needs an addend and the implicit-GEMM path");
-    if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, addend, addend_mask, S(stream));
+    if (bn) {
+        CNK_CHECK_ARG(cnk_conv2d_dgrad_bn_slices(d) > 0, "cnk_conv2d_dgrad: this conv shape cannot fuse the BN backward (cnk_conv2d_dgrad_bn_slices == 0)");
+        CNK_CHECK_ARG(bn->x && bn->mean && bn->invstd && bn->partial, "cnk_conv2d_dgrad: bn fuse: null pointer");
+        CNK_CHECK_ARG(!bn->relu || bn->relu_mask || (bn->gamma && bn->beta), "cnk_conv2d_dgrad: bn fuse: ReLU without a mask needs gamma and beta");
+    }
+    if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, addend, addend_mask, bn, S(stream));
     return direct_dgrad(d, dy, w_dgrad, dx, addend, S(stream));
 }
 
@@ -319,13 +330,14 @@ int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const 
     return bn_fwd_eval(x, gamma, beta, running_mean, running_var, residual, y, M, C, eps, relu, dtype, S(stream));
 }
 
-int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu_mask, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu_mask, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate, const float* ext_partial, int64_t ext_slices, int64_t M, int32_t C, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "cnk_bn_bwd: null pointer");
-    CNK_CHECK_ARG(!relu || y || relu_mask || (beta && !dresidual), "cnk_bn_bwd: relu backward needs the saved mask, the forward output, or (no residual) beta");
+    CNK_CHECK_ARG(!relu || ext_partial || y || relu_mask || (beta && !dresidual), "cnk_bn_bwd: relu backward needs the saved mask, the forward output, or (no residual) beta");
+    CNK_CHECK_ARG(!ext_partial || (ext_slices > 0 && !dresidual), "cnk_bn_bwd: ext_partial needs ext_slices > 0 and dresidual == NULL (dy is already the masked gradient)");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd: empty tensor");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd: workspace too small");
     ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, 5.0 * (double)M * C * esize(dtype));
-    return bn_bwd(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, M, C, relu, dtype, (float*)workspace, S(stream));
+    return bn_bwd(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, ext_partial, ext_slices, M, C, relu, dtype, (float*)workspace, S(stream));
 }
 
 int cnk_maxpool2d_fwd(const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {

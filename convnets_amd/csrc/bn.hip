@@ -662,16 +662,22 @@ int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const floa
 template <typename T, int VEC>
 static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma,
                     const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma,
-                    float* dbeta, int accumulate, int64_t M, int C, int relu, float* ws,
-                    hipStream_t s) {
+                    float* dbeta, int accumulate, const float* ext_partial, int64_t ext_slices, int64_t M,
+                    int C, int relu, float* ws, hipStream_t s) {
     SliceGeom g = make_geom(M, C, VEC);
     float* coefA = ws;
     float* coefB1 = ws + 2 * C;
     float* coefB2 = ws + 3 * C;
     float* partial = ws + ws_partials_off(C);
-    // ReLU mask source: saved bit mask > forward output y > re-derived from x*scale+shift (no residual)
-    const int act = !relu ? ACT_NONE : mask ? ACT_BITS : y ? ACT_Y : ACT_REMASK;
+    // ReLU mask source: saved bit mask > forward output y > re-derived from x*scale+shift (no residual);
+    // with partials from a fused conv dgrad, dy arrives masked and the reduction pass is skipped
+    const int act = (!relu || ext_partial) ? ACT_NONE : mask ? ACT_BITS : y ? ACT_Y : ACT_REMASK;
     const dim3 grid(g.slices, g.colgroups);
+    int nslices = g.slices;
+    if (ext_partial) {
+        partial = const_cast<float*>(ext_partial);
+        nslices = (int)ext_slices;
+    } else {
 #define CNK_BN_RED(A)                                                                                       \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, A>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \
                        (const T*)y, mask, gamma, beta, sm, si, partial, M, C, g)
@@ -683,7 +689,8 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
     }
 #undef CNK_BN_RED
     CNK_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, g.slices,
+    }
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, nslices,
                        C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
     CNK_CHECK_LAUNCH("bn_bwd_final");
 #define CNK_BN_BAPP(A, W)                                                                                     \
@@ -706,13 +713,13 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
 
 int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm,
            const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
-           int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s) {
+           const float* ep, int64_t es, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s) {
     if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_bwd_t<bf16, 8>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
-        return bn_bwd_t<bf16, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+        if (C % 8 == 0) return bn_bwd_t<bf16, 8>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, ep, es, M, C, relu, ws, s);
+        return bn_bwd_t<bf16, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, ep, es, M, C, relu, ws, s);
     }
-    if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
-    return bn_bwd_t<float, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, M, C, relu, ws, s);
+    if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, ep, es, M, C, relu, ws, s);
+    return bn_bwd_t<float, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, ep, es, M, C, relu, ws, s);
 }
 
 // bytes of the packed ReLU mask: one byte per 16-byte channel vector the kernels use for (C, dtype)

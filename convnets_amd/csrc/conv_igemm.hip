@@ -32,6 +32,15 @@ struct GatherParams {
     const void* addend;      // optional tensor shaped like dst: dst = conv + addend (fused grad sum)
     const unsigned char* addend_mask;   // optional packed ReLU mask (1 byte per 16-B vector) gating addend
     float* stats;            // optional [tiles_m][Nout][3] BN partials (n, mean, M2) of the OUTPUT
+    // optional fused backward of the BN(+ReLU) layer that produced this dgrad's input tensor
+    const void* bnf_x;       // that layer's input, shaped like dst (nullptr: off)
+    const float* bnf_mean;
+    const float* bnf_invstd;
+    const float* bnf_gamma;
+    const float* bnf_beta;
+    const unsigned char* bnf_mask;
+    float* bnf_partial;      // [slices][Nout][2]
+    int bnf_relu, bnf_tile0; // tile0: first slice of this launch (stride-parity classes)
     int N, IH, IW, C;
     int OH, OW;
     int FH, FW, Nout;
@@ -83,7 +92,17 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     // tile is then written to HBM as whole rows, 16 bytes per lane, coalesced.
     constexpr int ES = (int)sizeof(T);
     constexpr int CS = BN * ES + 16;                 // staged row stride
+    constexpr int CPR = BN * ES / 16;                // 16-B chunks per row
+    constexpr int RPP = 256 / CPR;                   // rows per pass
+    constexpr int NP = BM / RPP;                     // passes
+    constexpr int GP = NP > 4 ? 4 : NP;              // passes whose side loads are in flight together
     unsigned char* Cs = smem + BM * sizeof(int);
+    unsigned char* dst = (unsigned char*)p.dst;
+    const int crow = tid / CPR, cc = tid - crow * CPR;
+    float s8[PER16], q8[PER16];
+#pragma unroll
+    for (int e = 0; e < PER16; ++e) s8[e] = q8[e] = 0.f;
+    // stage the accumulators first: their registers are free before the side operands come in
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -107,39 +126,107 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                     *(f32x4*)(Cs + row * CS + col * 4) = o;
                 }
             }
-    __syncthreads();
-    constexpr int CPR = BN * ES / 16;                // 16-B chunks per row
-    constexpr int RPP = 256 / CPR;                   // rows per pass
-    unsigned char* dst = (unsigned char*)p.dst;
-    const int crow = tid / CPR, cc = tid - crow * CPR;
-    float s8[PER16], q8[PER16];
+    // fused BN backward (dgrad only): per-thread coefficients of this thread's PER16 channels
+    float bmu[PER16], bsc[PER16], bsf[PER16];
+    const bool bnf = p.bnf_x != nullptr;
+    const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
+    if (bnf) {
+        const int c0 = tile_n * BN + cc * PER16;
 #pragma unroll
-    for (int e = 0; e < PER16; ++e) s8[e] = q8[e] = 0.f;
+        for (int e = 0; e < PER16; ++e) {
+            bmu[e] = p.bnf_mean[c0 + e];
+            bsc[e] = bnf_remask ? p.bnf_gamma[c0 + e] * p.bnf_invstd[c0 + e] : 0.f;
+            bsf[e] = bnf_remask ? p.bnf_beta[c0 + e] - bmu[e] * bsc[e] : 0.f;
+        }
+    }
+    if (!p.addend && !bnf) {
+        // plain store loop (forward, and data gradients without side operands)
+        __syncthreads();
 #pragma unroll
-    for (int ps = 0; ps < BM / RPP; ++ps) {
-        const int row = ps * RPP + crow;
-        const int pix = row_dst[row];
-        if (pix >= 0) {
-            Vec16<T> v;
-            v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
-            const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
-            if (p.addend) {              // same rounding as a separate add kernel: round(round(conv) + addend)
-                Vec16<T> a;
-                a.v = *(const decltype(a.v)*)((const unsigned char*)p.addend + goff);
-                // with a mask the addend is dy of the block output and the mask its ReLU pattern:
-                // addend*mask is the residual-branch gradient, formed here instead of being written
-                // out by the BN backward and read back
-                const unsigned mb = p.addend_mask ? p.addend_mask[goff >> 4] : 0xFFu;
+        for (int ps = 0; ps < NP; ++ps) {
+            const int row = ps * RPP + crow;
+            const int pix = row_dst[row];
+            if (pix >= 0) {
+                Vec16<T> v;
+                v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
+                const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
+                *(decltype(v.v)*)(dst + goff) = v.v;
+                if (p.stats) {
 #pragma unroll
-                for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + (((mb >> e) & 1u) ? a.get(e) : 0.f));
+                    for (int e = 0; e < PER16; ++e) {
+                        float f = v.get(e);
+                        s8[e] += f;
+                        q8[e] += f * f;
+                    }
+                }
             }
-            *(decltype(v.v)*)(dst + goff) = v.v;
-            if (p.stats) {
+        }
+    } else
 #pragma unroll
-                for (int e = 0; e < PER16; ++e) {
-                    float f = v.get(e);
-                    s8[e] += f;
-                    q8[e] += f * f;
+    for (int g0 = 0; g0 < NP; g0 += GP) {
+        // Side operands of GP row passes (gradient addend, BN input, their masks) are requested
+        // together, ahead of the barrier and of the stores: the stores may alias them as far as the
+        // compiler knows, so loads left inside the store loop would run one latency per pass.
+        Vec16<T> av[GP], xv[GP];
+        unsigned am[GP], km[GP];
+        int pixs[GP];
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const int pix = row_dst[(g0 + u) * RPP + crow];
+            pixs[u] = pix;
+            am[u] = km[u] = 0xFFu;
+            if (pix >= 0) {
+                const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
+                if (p.addend) {
+                    av[u].v = *(const decltype(av[u].v)*)((const unsigned char*)p.addend + goff);
+                    if (p.addend_mask) am[u] = p.addend_mask[goff >> 4];
+                }
+                if (bnf) {
+                    xv[u].v = *(const decltype(xv[u].v)*)((const unsigned char*)p.bnf_x + goff);
+                    if (p.bnf_relu && p.bnf_mask) km[u] = p.bnf_mask[goff >> 4];
+                }
+            }
+        }
+        if (g0 == 0) __syncthreads();               // staged tile complete (side loads already in flight)
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const int row = (g0 + u) * RPP + crow;
+            const int pix = pixs[u];
+            if (pix >= 0) {
+                Vec16<T> v;
+                v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
+                const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
+                if (p.addend) {          // same rounding as a separate add kernel: round(round(conv) + addend)
+                    // with a mask the addend is dy of the block output and the mask its ReLU pattern:
+                    // addend*mask is the residual-branch gradient, formed here instead of being written
+                    // out by the BN backward and read back
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + (((am[u] >> e) & 1u) ? av[u].get(e) : 0.f));
+                }
+                if (bnf) {
+                    // dx' = dx * ReLU-mask of the producing BN layer; s8 += dx', q8 += dx'*(x - mean)
+                    unsigned keep = km[u];
+                    if (bnf_remask) {
+                        keep = 0;
+#pragma unroll
+                        for (int e = 0; e < PER16; ++e) keep |= (xv[u].get(e) * bsc[e] + bsf[e] > 0.f ? 1u : 0u) << e;
+                    }
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) {
+                        const float dv = ((keep >> e) & 1u) ? v.get(e) : 0.f;
+                        v.set(e, dv);
+                        s8[e] += dv;
+                        q8[e] += dv * (xv[u].get(e) - bmu[e]);
+                    }
+                }
+                *(decltype(v.v)*)(dst + goff) = v.v;
+                if (p.stats) {
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) {
+                        float f = v.get(e);
+                        s8[e] += f;
+                        q8[e] += f * f;
+                    }
                 }
             }
         }
@@ -147,7 +234,8 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     // Fused BN statistics of the values just stored (i.e. of the ROUNDED output, exactly what the
     // BN kernels would read back): per-channel sum / sum-of-squares over this tile's <=128 rows ->
     // (n, mean, M2) partial, merged across tiles by bn_finalize (Chan).  Saves one full read pass.
-    if (p.stats) {
+    // With bnf (data gradient) the two sums are those of the BN backward instead.
+    if (p.stats || bnf) {
         // the reduction scratch reuses the staged tile (everyone has finished reading it), which
         // keeps the epilogue LDS at 35 KiB so four workgroups fit a CU
         __syncthreads();
@@ -165,13 +253,20 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 S += red[r * BN + tid];
                 Q += red[(RPP + r) * BN + tid];
             }
-            const int nvalid = min(BM, p.M - tile_m * BM);
-            const float mean = S / (float)nvalid;
-            float m2 = Q - S * mean;
-            float* o = p.stats + ((size_t)tile_m * p.Nout + tile_n * BN + tid) * 3;
-            o[0] = (float)nvalid;
-            o[1] = mean;
-            o[2] = m2 > 0.f ? m2 : 0.f;
+            if (bnf) {
+                const int c = tile_n * BN + tid;
+                float* o = p.bnf_partial + ((size_t)(p.bnf_tile0 + tile_m) * p.Nout + c) * 2;
+                o[0] = S;
+                o[1] = Q * p.bnf_invstd[c];
+            } else {
+                const int nvalid = min(BM, p.M - tile_m * BM);
+                const float mean = S / (float)nvalid;
+                float m2 = Q - S * mean;
+                float* o = p.stats + ((size_t)tile_m * p.Nout + tile_n * BN + tid) * 3;
+                o[0] = (float)nvalid;
+                o[1] = mean;
+                o[2] = m2 > 0.f ? m2 : 0.f;
+            }
         }
     }
 }
@@ -857,8 +952,19 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w]
     return n;
 }
 
+// slices of the fused BN-backward partials: one per 128-row tile of every stride-parity class
+int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
+    if (d->stride_h * d->stride_w > 16 || d->Cin % (d->dtype == CNK_BF16 ? 8 : 4)) return 0;
+    DgradClass cls[16];
+    int nc = dgrad_classes(d, cls);
+    int64_t n = 0;
+    for (int c = 0; c < nc; ++c) n += ceil_div64((int64_t)d->N * cls[c].OH * cls[c].OW, BM);
+    return n;
+}
+
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                const void* addend, const unsigned char* addend_mask, hipStream_t s) {
+                const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn,
+                hipStream_t s) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     DgradClass cls[16];
@@ -866,6 +972,7 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
     int nc = dgrad_classes(d, cls);
     size_t esz = d->dtype == CNK_BF16 ? 2 : 4;
     size_t woff = 0;
+    int tile0 = 0;
     for (int c = 0; c < nc; ++c) {
         const DgradClass& k = cls[c];
         GatherParams p = {};
@@ -880,6 +987,12 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
         p.M = d->N * k.OH * k.OW;
         woff += (size_t)k.ntaps * d->Cin * d->Cout;
         if (p.M == 0) continue;
+        if (bn) {
+            p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;
+            p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
+            p.bnf_relu = bn->relu; p.bnf_tile0 = tile0;
+            tile0 += ceil_div(p.M, BM);
+        }
         p.fd_ohw = make_fastdiv(k.OH * k.OW);
         p.fd_ow = make_fastdiv(k.OW);
         int rc = d->dtype == CNK_BF16 ? launch_gather_bn<bf16>(p, s) : launch_gather_bn<float>(p, s);

@@ -40,8 +40,9 @@ class Conv2d(nn.Conv2d):
         return new
 
     def forward(self, x, want_bn_partial=False, link=None):
+        # x._cnk_bn: set when x is the output of a training-mode BatchNorm2d of this package (ops.BnRecord)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
-                                  self._packed, want_bn_partial, link)
+                                  self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None))
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -59,9 +60,12 @@ class BatchNorm2d(nn.BatchNorm2d):
         if self.training:
             if self.momentum is None:
                 raise NotImplementedError('convnets_amd.BatchNorm2d: cumulative momentum (None)')
+            rec = ops.BnRecord() if (torch.is_grad_enabled() and x.requires_grad) else None
             y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
                                          self.running_var, float(self.eps), float(self.momentum),
-                                         bool(relu), partial, link)
+                                         bool(relu), partial, link, rec)
+            if rec is not None and rec.x is not None:
+                y._cnk_bn = rec
             if self._deferred_counter is not None:
                 self._deferred_counter[0] += 1        # flushed for all BN layers at once by the model
             else:

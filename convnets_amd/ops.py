@@ -7,6 +7,7 @@ PyTorch is used for device memory, streams and autograd bookkeeping only; every 
 touches an activation is in libcnk.so.  Nothing here falls back to ATen/MIOpen.
 """
 import ctypes
+import os
 
 import torch
 
@@ -104,6 +105,24 @@ def masked_grad(dy, mask):
     return (dy * m.to(dy.dtype)).contiguous(memory_format=CL)
 
 
+class BnRecord:
+    """Travels with a training-mode BatchNormActFn output y (as y._cnk_bn) to the conv that consumes
+    it.  That conv's data gradient IS the gradient w.r.t. y, so its epilogue can run the first pass
+    of this BN layer's backward (ReLU masking + the two per-channel sums): the conv's backward fills
+    `fused = (dx, partial)`, and BatchNormActFn.backward uses it only if the gradient autograd then
+    delivers is that very tensor (any other consumer of y makes autograd sum into a new tensor, and
+    the regular two-pass backward runs: masking twice is idempotent, so that path stays exact)."""
+    __slots__ = ('x', 'mean', 'invstd', 'gamma', 'beta', 'mask', 'relu', 'fused')
+
+    def __init__(self):
+        self.x = self.mean = self.invstd = self.gamma = self.beta = self.mask = self.fused = None
+        self.relu = False
+
+
+BN_BWD_FUSE = os.environ.get('CNK_BN_BWD_FUSE', '1') != '0'
+FUSE_COUNTS = {'bn_bwd_fused': 0, 'bn_bwd_unfused': 0}      # which backward path ran (tests read this)
+
+
 class GradLink:
     """Hands the gradient of one consumer of a tensor to another consumer's backward so the sum of
     the two is formed inside a kernel epilogue instead of by autograd's accumulation pass.
@@ -113,12 +132,13 @@ class GradLink:
     last folds the parked tensor in (conv dgrad: fused `addend`) and returns the total."""
 
     def __init__(self, count=2):
-        self.count, self.arrived, self.parked = count, 0, None
+        self.count, self.arrived, self.parked, self.final = count, 0, None, False
 
     def contribute(self, make_grad):
         """make_grad(addend_or_None) -> gradient tensor.  Returns the tensor to report to autograd
         (None for all but the last contributor)."""
         self.arrived += 1
+        self.final = self.arrived >= self.count       # make_grad may ask: is this the total gradient?
         if self.arrived < self.count:
             g = make_grad(None)
             if self.parked is None:
@@ -260,7 +280,8 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d forward / dgrad / wgrad (reference: basemodel.py:974)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None):
+    def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None,
+                bn_rec=None):
         """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
         of y emitted by the conv epilogue (None when this conv shape cannot produce them).
         link: optional GradLink shared with the other consumer of x (residual blocks)."""
@@ -287,6 +308,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.desc, ctx.w_dgrad, ctx.has_bias = desc, w_dgrad, bias is not None
         ctx.params = (weight, bias)
         ctx.link = link if x.requires_grad else None
+        ctx.bn_rec = bn_rec if (x.requires_grad and BN_BWD_FUSE) else None
         if want_bn_partial:
             if partial is None:
                 partial = torch.empty(0, device=x.device)         # placeholder: "not available"
@@ -298,7 +320,7 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
         if dy is None:                        # y took no part in the loss
-            return (None,) * 8
+            return (None,) * 9
         x, w = ctx.saved_tensors
         desc = ctx.desc
         dy = _nhwc(dy)
@@ -313,8 +335,23 @@ class Conv2dFn(torch.autograd.Function):
                 if addend is not None:
                     addend = _nhwc(addend)
                 out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=CL)
+                # x is the output of a BN(+ReLU) layer and `out` the TOTAL gradient w.r.t. it: run the
+                # first pass of that layer's backward in this epilogue (BnRecord)
+                rec, fuse, partial = ctx.bn_rec, None, None
+                if rec is not None and (ctx.link is None or ctx.link.final) and rec.x is not None \
+                        and rec.x.shape == x.shape and rec.x.dtype == x.dtype:
+                    slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+                    if slices > 0:
+                        partial = torch.empty((slices, desc.Cin, 2), dtype=torch.float32, device=x.device)
+                        fuse = _lib.BnBwdFuse(rec.x.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr(),
+                                              rec.gamma.data_ptr(), rec.beta.data_ptr(),
+                                              rec.mask.data_ptr() if rec.mask is not None else None,
+                                              partial.data_ptr(), int(rec.relu))
                 check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(out),
-                                           _p(addend), _p(amask), None, 0, _stream()))
+                                           _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None,
+                                           None, 0, _stream()))
+                if fuse is not None:
+                    rec.fused = (out, partial)
                 return out
             dx = ctx.link.contribute(dgrad) if ctx.link is not None else dgrad(None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -338,7 +375,7 @@ class Conv2dFn(torch.autograd.Function):
                 _grad_written(weight)
                 if ctx.has_bias:
                     _grad_written(bias)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -347,7 +384,7 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu,
-                partial=None, link=None):
+                partial=None, link=None, rec=None):
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
@@ -379,17 +416,36 @@ class BatchNormActFn(torch.autograd.Function):
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.params = (gamma, beta)
         ctx.link = link if (residual is not None and residual.requires_grad) else None
+        ctx.rec = None
+        if rec is not None and x.requires_grad and (mask is not None or residual is None):
+            # what a consumer conv needs to run this layer's backward reduction in its dgrad epilogue
+            rec.x, rec.mean, rec.invstd, rec.gamma, rec.beta = x, save_mean, save_invstd, gamma.detach(), beta.detach()
+            rec.mask, rec.relu = mask, bool(relu)
+            ctx.rec = rec
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         x, y, mask, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        # first pass already done by the consumer conv's dgrad epilogue?  Only if autograd hands back
+        # exactly the tensor that conv wrote (no other gradient was accumulated on top of it)
+        fused, ext_partial = None, None
+        if ctx.rec is not None:
+            fused, ctx.rec.fused = ctx.rec.fused, None
+            ctx.rec.x = None
+        if fused is not None and fused[0].data_ptr() == dy.data_ptr() and fused[0].shape == dy.shape \
+                and dy.is_contiguous(memory_format=CL):
+            ext_partial = fused[1]
         dy = _nhwc(dy)
         N, C, H, W = x.shape
         M = N * H * W
         dx = torch.empty_like(x, memory_format=CL)
         want_res = ctx.has_res and ctx.needs_input_grad[3]
+        FUSE_COUNTS['bn_bwd_fused' if ext_partial is not None else 'bn_bwd_unfused'] += 1
+        if ext_partial is not None:
+            return BatchNormActFn._backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx,
+                                                  want_res, ext_partial, M, C)
         # identity shortcut with a saved bit mask: the residual gradient dy*mask is NOT written here;
         # (dy, mask) is parked for the block's first conv, whose dgrad epilogue applies the mask
         defer_res = want_res and ctx.relu and mask is not None and ctx.link is not None \
@@ -412,7 +468,7 @@ class BatchNormActFn(torch.autograd.Function):
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
         check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(mask), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
-                             _p(dx), _p(dres_out), _p(dg_buf), _p(db_buf), int(direct), M, C,
+                             _p(dx), _p(dres_out), _p(dg_buf), _p(db_buf), int(direct), None, 0, M, C,
                              int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
         if direct:
             _grad_written(pg)
@@ -424,7 +480,35 @@ class BatchNormActFn(torch.autograd.Function):
             # identity shortcut: park the residual gradient for the block's first conv, whose
             # dgrad epilogue adds it (falls back to a plain add if this backward is the last one)
             dres = ctx.link.contribute(lambda parked: dres if parked is None else dres + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx, want_res, ext_partial, M, C):
+        """Second half of the backward when the consumer conv's dgrad epilogue has already masked dy
+        and reduced it: dgamma/dbeta from the partials, then one apply pass.  The residual gradient
+        is dy itself."""
+        pg, pb = ctx.params
+        gg, gb = _arena_grad(pg), _arena_grad(pb)
+        direct = gg is not None and gb is not None
+        if direct:
+            dg_buf, db_buf, dgamma, dbeta = gg, gb, None, None
+        else:
+            dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+            db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        check(lib.cnk_bn_bwd(_p(dy), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                             _p(dx), None, _p(dg_buf), _p(db_buf), int(direct), _p(ext_partial),
+                             ext_partial.shape[0], M, C, int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(),
+                             _stream()))
+        if direct:
+            _grad_written(pg)
+            _grad_written(pb)
+        dres = None
+        if want_res:
+            dres = dy
+            if ctx.link is not None:
+                dres = ctx.link.contribute(lambda parked: dy if parked is None else dy + parked)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):

@@ -99,9 +99,31 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
  * OUTPUT and addend*mask -- the identity-shortcut gradient -- is formed in the epilogue instead of
  * being materialised by the BN backward (implicit-GEMM path only). */
 int cnk_conv2d_dgrad_accepts_mask(const cnk_conv_desc* d);      /* 1 if addend_mask is usable */
+
+/* Optional fusion of the data gradient with the backward of the BatchNorm(+ReLU) layer whose OUTPUT
+ * is this conv's input (conv2d_block chains, basemodel.py:999-1015: ... -> BN -> ReLU -> conv).
+ * dx is then the gradient w.r.t. that BN output; the epilogue, which holds each dx tile, also
+ *   - applies the layer's ReLU mask to it (relu != 0: from relu_mask, the packed mask
+ *     cnk_bn_fwd_train wrote, else re-derived from x*scale+shift > 0 as cnk_bn_bwd does), and
+ *   - emits per-tile per-channel partial sums  sum(dx')  and  sum(dx' * (x-mean)*invstd)
+ * i.e. the whole first pass of cnk_bn_bwd (one read of dy and one of x saved).  Hand `partial`
+ * to cnk_bn_bwd as ext_partial together with the (already masked) dx as its dy.
+ * x: the BN layer's INPUT, [N*H*W][Cin] like dx.  partial: fp32 [slices][Cin][2] with
+ * slices = cnk_conv2d_dgrad_bn_slices(d) (0: this conv shape cannot fuse; pass bn = NULL). */
+typedef struct cnk_bn_bwd_fuse {
+    const void* x;
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const uint8_t* relu_mask;
+    float* partial;
+    int32_t relu;
+} cnk_bn_bwd_fuse;
+int64_t cnk_conv2d_dgrad_bn_slices(const cnk_conv_desc* d);
 int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                     const void* addend, const uint8_t* addend_mask, void* workspace,
-                     size_t workspace_bytes, void* stream);
+                     const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[Cout][Cin][kh][kw] (fp32) = sum over N,Ho,Wo of dy * x ; dbias[Cout] = sum dy (may be NULL).
  * accumulate != 0 adds into dw/dbias (torch's .grad accumulation), else overwrites. */
@@ -136,11 +158,15 @@ int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const 
  * backward: from relu_mask when given (the packed mask the forward wrote), else from y; when both
  * are NULL (allowed only without a residual operand) it is re-derived as x*scale+shift > 0 with
  * the same fp32 arithmetic as the forward.  dresidual (may be NULL) receives the gradient of the residual operand
- * (= masked dy).  dgamma/dbeta fp32[C]; accumulate as in wgrad. */
+ * (= masked dy).  dgamma/dbeta fp32[C]; accumulate as in wgrad.
+ * ext_partial/ext_slices (NULL/0: computed here): the partial sums a fused cnk_conv2d_dgrad emitted;
+ * dy is then ALREADY masked (it is also the residual gradient: dresidual must be NULL) and the
+ * reduction pass is skipped. */
 int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu_mask,
                const float* gamma, const float* beta,
                const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
-               float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int relu,
+               float* dgamma, float* dbeta, int accumulate, const float* ext_partial,
+               int64_t ext_slices, int64_t M, int32_t C, int relu,
                int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.MaxPool2d (basemodel.py:1017-1024): floor mode, implicit -inf padding, dilation 1.

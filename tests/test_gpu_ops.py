@@ -163,6 +163,71 @@ def test_batchnorm_vs_oracle(shape, mode, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('conv', [(3, 1, 1), (3, 2, 1), (1, 1, 0), (1, 2, 0)], ids=['k3s1', 'k3s2', 'k1s1', 'k1s2'])
+@pytest.mark.parametrize('mode', ['plain', 'relu', 'add_relu'])
+def test_bn_backward_fused_into_conv_dgrad(mode, conv, dtype):
+    """BN(+ReLU) -> conv: the conv's dgrad epilogue masks the gradient and reduces it for the BN
+    backward (cnk_bn_bwd_fuse).  Checked against torch fp64 autograd and against the unfused path."""
+    from convnets_amd import layers, ops
+    k, s, p = conv
+    N, C, H, W, Co = 3, 64, 13, 11, 128
+    g = torch.Generator().manual_seed(7 * k + s + len(mode))
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
+    res = torch.randn(N, C, H, W, generator=g) if mode == 'add_relu' else None
+    w = torch.randn(Co, C, k, k, generator=g) * 0.1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        res = res.bfloat16().float() if res is not None else None
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dz = torch.randn(N, Co, Ho, Wo, generator=g)
+    if dtype == torch.bfloat16:
+        dz = dz.bfloat16().float()
+
+    def run(fuse):
+        ops.BN_BWD_FUSE = fuse
+        try:
+            bn = layers.BatchNorm2d(C).cuda().train()
+            cv = layers.Conv2d(C, Co, kernel_size=k, stride=s, padding=p, bias=False).cuda()
+            with torch.no_grad():
+                bn.weight.copy_(gamma); bn.bias.copy_(beta); cv.weight.copy_(w)
+            xt = dev(x.numpy(), dtype).requires_grad_(True)
+            rt = dev(res.numpy(), dtype).requires_grad_(True) if res is not None else None
+            before = dict(ops.FUSE_COUNTS)
+            y = bn(xt, residual=rt, relu=mode != 'plain')
+            z = cv(y)
+            z.backward(dev(dz.numpy(), dtype))
+            torch.cuda.synchronize()
+            hits = ops.FUSE_COUNTS['bn_bwd_fused'] - before['bn_bwd_fused']
+            return (host(xt.grad), host(bn.weight.grad), host(bn.bias.grad), host(cv.weight.grad),
+                    host(rt.grad) if rt is not None else None, hits)
+        finally:
+            ops.BN_BWD_FUSE = True
+
+    fz, un = run(True), run(False)
+    assert fz[5] == 1 and un[5] == 0, 'fused path must run exactly when enabled'
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if res is not None else None
+    gr, br, wr = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), w.double().requires_grad_(True)
+    a = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if rr is not None:
+        a = a + rr
+    if mode != 'plain':
+        a = torch.relu(a)
+    if dtype == torch.bfloat16:
+        a = a + (a.detach().float().bfloat16().double() - a.detach())     # the conv sees the bf16-rounded activation
+    F.conv2d(a, wr, None, s, p).backward(dz.double())
+    ref = (xr.grad.numpy(), gr.grad.numpy(), br.grad.numpy(), wr.grad.numpy(), rr.grad.numpy() if rr is not None else None)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    for name, got, other, want in zip(('dx', 'dgamma', 'dbeta', 'dw', 'dres'), fz, un, ref):
+        if want is None:
+            continue
+        assert rel_l2(got, want) < tol, name + ' vs fp64'
+        # same masked gradient, same rounding; only the fp32 summation order of the two sums differs
+        assert rel_l2(got, other) < (1e-5 if dtype == torch.float32 else 2e-3), name + ' fused vs unfused'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
 @pytest.mark.parametrize('name', _cases('block'))
 def test_conv_block_golden(name, dtype):
     """conv -> BN -> ReLU exactly as the reference's conv2d_block builds it, train and eval mode."""

@@ -33,7 +33,7 @@ for C, H, cnt in [(64, 112, 1), (64, 56, 6), (256, 56, 4), (128, 28, 8), (512, 2
     for mode, r, mk in (('relu', None, None), ('add+relu', res, mask)):
         f = lambda: _lib.check(lib.cnk_bn_fwd_train(P(x), P(g), P(b), P(r), P(y), P(mk), P(rm), P(rv), P(sm), P(si), P(part), nsl,
                                                     M, C, 1e-5, 0.1, 1, 1, P(ws), ws.numel(), st))
-        w = lambda: _lib.check(lib.cnk_bn_bwd(P(dy), P(x), None, P(mk), P(g), P(b), P(sm), P(si), P(dx), None, P(dg), P(db), 1,
+        w = lambda: _lib.check(lib.cnk_bn_bwd(P(dy), P(x), None, P(mk), P(g), P(b), P(sm), P(si), P(dx), None, P(dg), P(db), 1, None, 0,
                                               M, C, 1, 1, P(ws), ws.numel(), st))
         tf, tb = timeit(f), timeit(w)
         nf = 2 + (1 if r is not None else 0)

@@ -40,7 +40,7 @@ if which in ('all', 'conv'):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         t_f = timeit(lambda: lib.cnk_conv2d_fwd(ctypes.byref(desc), P(x), P(wf), None, P(y), None, None, 0, st))
         dx = torch.empty_like(x)
-        t_d = timeit(lambda: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dy), P(wd), P(dx), None, None, None, 0, st)) if Cin > 3 else float('nan')
+        t_d = timeit(lambda: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dy), P(wd), P(dx), None, None, None, None, 0, st)) if Cin > 3 else float('nan')
         dw = torch.empty_like(w)
         ws = ops.workspace(lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), 2), x.device)
         t_w = timeit(lambda: lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dy), P(x), P(dw), None, 0, P(ws), ws.numel(), st))
