@@ -26,10 +26,17 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
 CONV_CLASSES = ['conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'conv1x1_fwd', 'conv1x1_dgrad',
                 'conv1x1_wgrad']
-# kernel -> the cnk_prof classes its launches fall in.  The implicit-GEMM gather kernel runs the
-# forward AND the data gradient of every 3x3 / 1x1 conv, so it is timed as one kernel.
-KERNELS = {'igemm_gather_kernel (conv fwd+dgrad, 3x3 and 1x1)': ['conv3x3_fwd', 'conv3x3_dgrad', 'conv1x1_fwd', 'conv1x1_dgrad'],
-           'wgrad_mfma_kernel (conv wgrad, 3x3 and 1x1)': ['conv3x3_wgrad', 'conv1x1_wgrad']}
+# kernel family -> the cnk_prof classes its launches fall in (HIP events around every launch of the class).
+# 3x3 stride-1 convs run in igemm_halo3x3_kernel, every other igemm conv (1x1, strided 3x3) in
+# igemm_gather_kernel; both serve the forward AND the data gradient.  The dominant family of the step
+# (largest summed launch time) is the one the roofline object describes, priced against the roofline that
+# binds it: MFMA if flops/peak_flops > bytes/peak_bytes for its launches, else HBM.
+KERNELS = {'igemm_halo3x3_kernel (3x3 conv fwd+dgrad; stride-2 layers in igemm_gather_kernel)': ['conv3x3_fwd', 'conv3x3_dgrad'],
+           'igemm_gather_kernel (1x1 conv fwd+dgrad)': ['conv1x1_fwd', 'conv1x1_dgrad'],
+           'wgrad_mfma_kernel (conv wgrad, 3x3 and 1x1)': ['conv3x3_wgrad', 'conv1x1_wgrad'],
+           'bn_apply_kernel (+bn_finalize: BN training forward)': ['bn_fwd'],
+           'bn_bwd_apply_kernel (+bn_bwd_reduce/final: BN backward)': ['bn_bwd']}
+PEAK_HBM_GBPS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec bandwidth
 MODEL_CFG = {
     'resnet50': ('resnet', 50, (3, 224, 224), 1000, 256),
     'resnet152': ('resnet', 152, (3, 224, 224), 1000, 128),
@@ -170,7 +177,6 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     n_l, ms_l, fl_l, by_l = prof_collect(lib, dom_mask)
-    per_class = {c: prof_collect(lib, _lib.CLS[c]) for c in KERNELS[dom_kernel]}
     lib.cnk_prof_end()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -182,8 +188,13 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * bs * args.steps / elapsed
-        achieved = fl_l / ms_l / 1e9 if ms_l > 0 else 0.0          # TFLOP/s over the class's launches
-        peak = PEAK_TFLOPS[args.dtype]
+        tflops = fl_l / ms_l / 1e9 if ms_l > 0 else 0.0            # algorithmic flops / launch time
+        gbps = by_l / ms_l / 1e6 if ms_l > 0 else 0.0               # algorithmic bytes / launch time
+        peak_tf = PEAK_TFLOPS[args.dtype]
+        if tflops / peak_tf >= gbps / PEAK_HBM_GBPS:
+            bound, achieved, peak, unit = 'mfma', tflops, peak_tf, 'TFLOP/s'
+        else:
+            bound, achieved, peak, unit = 'hbm', gbps, PEAK_HBM_GBPS, 'GB/s'
         out = {
             'metric': 'images/sec training step, ResNet-50 224x224 bs=256/GPU' if args.model == 'resnet50'
                       else 'images/sec training step, %s bs=%d/GPU' % (args.model, bs),
@@ -194,12 +205,14 @@ def main():
                                    % (args.model, in_size[1], in_size[2], bs),
                        'global_batch': world * bs, 'parallelism': 'dp%d' % world,
                        'final_loss': round(loss_val, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': dom_kernel, 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+            'roofline': {'bound': bound, 'kernel': dom_kernel, 'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': unit, 'frac': round(achieved / peak, 4),
                          'traffic': pmc_traffic(dom_kernel),
                          'launches': n_l, 'avg_launch_ms': round(ms_l / n_l, 4) if n_l else None,
                          'avg_launch_gflop': round(fl_l / n_l / 1e9, 3) if n_l else None,
-                         'by_class_tflops': {c: round(v[2] / v[1] / 1e9, 1) for c, v in per_class.items() if v[1] > 0}},
+                         'avg_launch_alg_mbytes': round(by_l / n_l / 1e6, 2) if n_l else None,
+                         'step_ms_by_family': {k.split(' ')[0]: round(sum(table[c][1] for c in KERNELS[k]), 3) for k in KERNELS},
+                         'conv_tflops_by_class': {c: round(table[c][2] / table[c][1] / 1e9, 1) for c in CONV_CLASSES if table[c][1] > 0}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model, args.dtype)

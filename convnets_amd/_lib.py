@@ -69,6 +69,16 @@ SIGNATURES = {
     'cnk_gap_fwd': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_gap_bwd': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_nchw_to_nhwc': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_linear_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'cnk_linear_dgrad': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'cnk_linear_wgrad_workspace_bytes': (_sz, [_i32, _i32]),
+    'cnk_linear_wgrad': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _vp, _sz, _vp]),
+    'cnk_softmax_ce_sum': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    'cnk_dropout_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    'cnk_dropout_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    'cnk_grad_clip_workspace_bytes': (_sz, []),
+    'cnk_grad_clip_norm': (ctypes.c_int, [_vp, _i64, _f32, _vp, _vp, _sz, _vp]),
+    'cnk_grad_clip_value': (ctypes.c_int, [_vp, _i64, _f32, _vp]),
     'cnk_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32,
                                      _vp]),
     'cnk_prof_begin': (ctypes.c_int, [_i32]),

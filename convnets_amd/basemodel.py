@@ -25,7 +25,7 @@ class MultiClassBaseModel(nn.Module):
         self.setting = setting
         self.model_name = self.__class__.__name__ + str(setting.kind)
         self.in_channels, self.height, self.width = setting.input_size      # basemodel.py:41-43
-        self.cost_function = nn.CrossEntropyLoss(reduction='sum')           # basemodel.py:46
+        self.cost_function = layers.CrossEntropyLoss(reduction='sum')       # basemodel.py:46
         self.optimizer = None
         self.grad_reducer = None          # data-parallel hook (convnets_amd/dp.py); None on 1 GPU
 
@@ -92,13 +92,23 @@ class MultiClassBaseModel(nn.Module):
     def score(self, outputs, targets):
         """Count of correct predictions (basemodel.py:119-121) -- kept on the device; the caller
         decides when to pay the host sync."""
+        cf = self.cost_function
+        if getattr(cf, 'last_logits', None) is outputs and cf.last_pred is not None:
+            return (cf.last_pred == targets).sum()          # argmax came with the loss kernel
         return (outputs.argmax(dim=1) == targets).sum()
 
     def gradient_clipping(self):
+        """basemodel.py:131-178: norm clipping, then value clipping, each over ALL gradients -- one
+        pass over the flat gradient arena instead of one launch per parameter.  Returns the total
+        norm (device scalar) when norm clipping is on."""
+        if self.optimizer is None:
+            raise RuntimeError('gradient_clipping: call init_optimizer() first (the gradients live in its arena)')
+        total_norm = None
         if self.setting.grad_clip_norm:
-            torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=self.setting.gc_max_norm)
+            total_norm = self.optimizer.clip_grad_norm(self.setting.gc_max_norm)
         if self.setting.grad_clip_value:
-            torch.nn.utils.clip_grad_value_(self.parameters(), clip_value=self.setting.gc_value)
+            self.optimizer.clip_grad_value(self.setting.gc_value)
+        return total_norm
 
     def forward_step(self, batch):
         inputs, targets = self.setting.device.move(batch)

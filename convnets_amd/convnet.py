@@ -8,6 +8,7 @@ factory, with the canonical shapes BASELINE.json names (LeNet 5x5; AlexNet 11x11
 """
 import torch.nn as nn
 
+from . import layers
 from .basemodel import MultiClassBaseModel
 
 
@@ -20,8 +21,8 @@ class ConvNet(MultiClassBaseModel):
             self.conv2d_block(num_filters=64, kernel_size=5, stride=2, padding=1),
             self.maxpool2d(kernel_size=2, stride=2))
         self.classifier = nn.Sequential(
-            nn.Linear(self.num_flat_features(), 2048), nn.ReLU(inplace=True),
-            nn.Dropout(p=self.setting.dropout_rate), nn.Linear(2048, self.setting.num_classes))
+            layers.Linear(self.num_flat_features(), 2048), layers.ReLU(inplace=True),
+            layers.Dropout(p=self.setting.dropout_rate), layers.Linear(2048, self.setting.num_classes))
         if self.setting.init_params:
             self.init_params()
 
@@ -35,9 +36,9 @@ class LeNet5(MultiClassBaseModel):
             self.conv2d_block(num_filters=16, kernel_size=5),
             self.maxpool2d(kernel_size=2, stride=2))
         self.classifier = nn.Sequential(
-            nn.Linear(self.num_flat_features(), 120), nn.ReLU(inplace=True),
-            nn.Linear(120, 84), nn.ReLU(inplace=True),
-            nn.Dropout(p=self.setting.dropout_rate), nn.Linear(84, self.setting.num_classes))
+            layers.Linear(self.num_flat_features(), 120), layers.ReLU(inplace=True),
+            layers.Linear(120, 84), layers.ReLU(inplace=True),
+            layers.Dropout(p=self.setting.dropout_rate), layers.Linear(84, self.setting.num_classes))
         if self.setting.init_params:
             self.init_params()
 
@@ -56,8 +57,8 @@ class AlexNet(MultiClassBaseModel):
             self.maxpool2d(kernel_size=3, stride=2))
         p = self.setting.dropout_rate
         self.classifier = nn.Sequential(
-            nn.Dropout(p=p), nn.Linear(self.num_flat_features(), 4096), nn.ReLU(inplace=True),
-            nn.Dropout(p=p), nn.Linear(4096, 4096), nn.ReLU(inplace=True),
-            nn.Linear(4096, self.setting.num_classes))
+            layers.Dropout(p=p), layers.Linear(self.num_flat_features(), 4096), layers.ReLU(inplace=True),
+            layers.Dropout(p=p), layers.Linear(4096, 4096), layers.ReLU(inplace=True),
+            layers.Linear(4096, self.setting.num_classes))
         if self.setting.init_params:
             self.init_params()

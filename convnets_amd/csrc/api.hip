@@ -14,6 +14,15 @@ int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const fl
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
+int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, hipStream_t s);
+int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, hipStream_t s);
+int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, hipStream_t s);
+int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax, float* row_loss_ws, int B, int N, hipStream_t s);
+int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
+int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s);
+size_t grad_clip_workspace_bytes();
+int grad_clip_norm(float* g, int64_t n, float max_norm, float* norm_out, float* ws, hipStream_t s);
+int grad_clip_value(float* g, int64_t n, float c, hipStream_t s);
 int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
 bool wgrad_mfma_supported(const cnk_conv_desc* d);
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
@@ -265,6 +274,8 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
     CNK_CHECK_ARG(dy && w_dgrad && dx, "cnk_conv2d_dgrad: null pointer");
     double fl, by;
     conv_cost(d, &fl, &by);
+    if (bn) by += (double)d->N * d->H * d->W * d->Cin * esize(d->dtype);      // the fused BN backward reads that layer's input
+    if (addend) by += (double)d->N * d->H * d->W * d->Cin * esize(d->dtype);
     ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
     CNK_CHECK_ARG(!addend_mask || (addend && igemm_supported(d, CNK_PASS_DGRAD) && d->Cin % (d->dtype == CNK_BF16 ? 8 : 4) == 0), "cnk_conv2d_dgrad: addend_mask needs an addend and the implicit-GEMM path");
     if (bn) {
@@ -336,7 +347,8 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
     CNK_CHECK_ARG(!ext_partial || (ext_slices > 0 && !dresidual), "cnk_bn_bwd: ext_partial needs ext_slices > 0 and dresidual == NULL (dy is already the masked gradient)");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd: empty tensor");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd: workspace too small");
-    ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, 5.0 * (double)M * C * esize(dtype));
+    // reduce pass (2 reads) + apply pass (2 reads, 1 write); a fused conv dgrad already did the first
+    ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, (ext_partial ? 3.0 : 5.0) * (double)M * C * esize(dtype));
     return bn_bwd(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, ext_partial, ext_slices, M, C, relu, dtype, (float*)workspace, S(stream));
 }
 
@@ -383,6 +395,61 @@ int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     CNK_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "cnk_adam_step: bad arguments");
     CNK_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "cnk_adam_step: arenas must be 16-byte aligned");
     return adam_dispatch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
+
+int cnk_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t K, int32_t N, void* stream) {
+    CNK_CHECK_ARG(x && w && y && B > 0 && K > 0 && N > 0, "cnk_linear_fwd: bad arguments");
+    return linear_fwd(x, w, bias, y, B, K, N, S(stream));
+}
+
+int cnk_linear_dgrad(const float* dy, const float* w, float* dx, int32_t B, int32_t K, int32_t N, void* stream) {
+    CNK_CHECK_ARG(dy && w && dx && B > 0 && K > 0 && N > 0, "cnk_linear_dgrad: bad arguments");
+    return linear_dgrad(dy, w, dx, B, K, N, S(stream));
+}
+
+size_t cnk_linear_wgrad_workspace_bytes(int32_t B, int32_t N) { return colsum_workspace(B, N); }
+
+int cnk_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int accumulate, int32_t B, int32_t K, int32_t N, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(dy && x && dw && B > 0 && K > 0 && N > 0, "cnk_linear_wgrad: bad arguments");
+    if (int rc = linear_wgrad(dy, x, dw, B, K, N, accumulate, S(stream))) return rc;
+    if (dbias) {
+        CNK_CHECK_ARG(workspace && workspace_bytes >= colsum_workspace(B, N), "cnk_linear_wgrad: workspace too small");
+        return colsum(dy, dbias, B, N, CNK_F32, accumulate, workspace, workspace_bytes, S(stream));
+    }
+    return 0;
+}
+
+int cnk_softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax, int32_t B, int32_t N, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(logits && target && loss && B > 0 && N > 0, "cnk_softmax_ce_sum: bad arguments");
+    CNK_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * sizeof(float), "cnk_softmax_ce_sum: workspace too small");
+    return softmax_ce_sum(logits, target, loss, dlogits, argmax, (float*)workspace, B, N, S(stream));
+}
+
+int cnk_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    CNK_CHECK_ARG(x && y && mask && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_fwd: bad arguments (0 <= p < 1)");
+    if (n == 0) return 0;
+    return dropout_fwd(x, y, mask, n, p, seed, offset, S(stream));
+}
+
+int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
+    CNK_CHECK_ARG(dy && mask && dx && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_bwd: bad arguments (0 <= p < 1)");
+    if (n == 0) return 0;
+    return dropout_bwd(dy, mask, dx, n, p, S(stream));
+}
+
+size_t cnk_grad_clip_workspace_bytes(void) { return grad_clip_workspace_bytes(); }
+
+int cnk_grad_clip_norm(float* grads, int64_t n, float max_norm, float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(grads && n > 0 && max_norm > 0.f, "cnk_grad_clip_norm: bad arguments");
+    CNK_CHECK_ARG((uintptr_t)grads % 16 == 0, "cnk_grad_clip_norm: arena must be 16-byte aligned");
+    CNK_CHECK_ARG(workspace && workspace_bytes >= grad_clip_workspace_bytes(), "cnk_grad_clip_norm: workspace too small");
+    return grad_clip_norm(grads, n, max_norm, total_norm_out, (float*)workspace, S(stream));
+}
+
+int cnk_grad_clip_value(float* grads, int64_t n, float clip_value, void* stream) {
+    CNK_CHECK_ARG(grads && n > 0 && clip_value >= 0.f, "cnk_grad_clip_value: bad arguments");
+    CNK_CHECK_ARG((uintptr_t)grads % 16 == 0, "cnk_grad_clip_value: arena must be 16-byte aligned");
+    return grad_clip_value(grads, n, clip_value, S(stream));
 }
 
 int cnk_prof_begin(int32_t class_mask) {

@@ -151,6 +151,59 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, floa
     }
 }
 
+// Pre-merge for long partial lists (a conv-fused layer has one slice per 128-row tile: 6272 at 56x56,
+// bs 256).  Lane = channel, so a wave reads NV*64 consecutive floats per slice (coalesced); the four
+// waves of a block take interleaved slices of the block's share; grid = (channel groups, shares).
+// NV = 3: Chan merge of (n, mean, M2); NV = 2: plain sums (backward).  Output [shares][C][NV].
+template <int NV>
+__global__ __launch_bounds__(256) void bn_premerge_kernel(const float* __restrict__ partial, int slices, int C,
+                                                          float* __restrict__ out) {
+    __shared__ float sh[NV][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (slices + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(slices, s0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        int s = s0 + wave;
+        for (; s + 12 < s1; s += 16) {                 // four independent loads in flight per lane
+            float v[4][NV];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[u][k] = partial[((size_t)(s + 4 * u) * C + c) * NV + k];
+            if constexpr (NV == 3) {
+                chan_merge(v[0][0], v[0][1], v[0][2], v[1][0], v[1][1], v[1][2]);
+                chan_merge(v[2][0], v[2][1], v[2][2], v[3][0], v[3][1], v[3][2]);
+                chan_merge(v[0][0], v[0][1], v[0][2], v[2][0], v[2][1], v[2][2]);
+                chan_merge(a0, a1, a2, v[0][0], v[0][1], v[0][2]);
+            } else {
+                a0 += (v[0][0] + v[1][0]) + (v[2][0] + v[3][0]);
+                a1 += (v[0][1] + v[1][1]) + (v[2][1] + v[3][1]);
+            }
+        }
+        for (; s < s1; s += 4) {
+            const float* o = partial + ((size_t)s * C + c) * NV;
+            if constexpr (NV == 3) chan_merge(a0, a1, a2, o[0], o[1], o[2]);
+            else { a0 += o[0]; a1 += o[1]; }
+        }
+    }
+    sh[0][wave][lane] = a0;
+    sh[1][wave][lane] = a1;
+    if constexpr (NV == 3) sh[2][wave][lane] = a2;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        float* o = out + ((size_t)blockIdx.y * C + c) * NV;
+        if constexpr (NV == 3) {
+            for (int w = 1; w < 4; ++w) chan_merge(a0, a1, a2, sh[0][w][lane], sh[1][w][lane], sh[2][w][lane]);
+            o[0] = a0; o[1] = a1; o[2] = a2;
+        } else {
+            o[0] = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
+            o[1] = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+        }
+    }
+}
+
 // One 256-thread block per channel: threads stride over the slices (a conv-fused layer has one
 // slice per 128-row tile, thousands of them), butterfly merge per wave, then across the 4 waves.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
@@ -585,6 +638,22 @@ size_t bn_workspace_bytes(int64_t M, int C) {
     return n * sizeof(float);
 }
 
+// Long external partial lists are first merged down to <= 128 entries per channel (into the
+// workspace's own-partials area, unused when the partials are external).
+template <int NV>
+static int bn_premerge(const float*& partial, int& slices, int C, float* scratch, int64_t scratch_floats,
+                       hipStream_t s) {
+    if (slices < 1024) return 0;
+    int shares = slices >= 2048 ? 128 : 64;
+    if ((int64_t)shares * C * NV > scratch_floats) return 0;
+    hipLaunchKernelGGL((bn_premerge_kernel<NV>), dim3(ceil_div(C, 64), shares), dim3(256), 0, s, partial, slices,
+                       C, scratch);
+    CNK_CHECK_LAUNCH("bn_premerge");
+    partial = scratch;
+    slices = shares;
+    return 0;
+}
+
 template <typename T, int VEC>
 static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* res,
                           void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si,
@@ -602,6 +671,8 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
         CNK_CHECK_LAUNCH("bn_stats");
         partial = own;
         slices = g.slices;
+    } else if (int rc = bn_premerge<3>(partial, slices, C, ws + ws_partials_off(C), (int64_t)g.slices * C * 3, s)) {
+        return rc;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, slices, C,
                        M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
@@ -675,8 +746,10 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
     const dim3 grid(g.slices, g.colgroups);
     int nslices = g.slices;
     if (ext_partial) {
-        partial = const_cast<float*>(ext_partial);
+        const float* ep = ext_partial;
         nslices = (int)ext_slices;
+        if (int rc = bn_premerge<2>(ep, nslices, C, partial, (int64_t)g.slices * C * 3, s)) return rc;
+        partial = const_cast<float*>(ep);
     } else {
 #define CNK_BN_RED(A)                                                                                       \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, A>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \

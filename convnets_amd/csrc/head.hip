@@ -1,0 +1,232 @@
+// Classifier head on HIP: nn.Linear forward / input gradient / weight gradient,
+// softmax + CrossEntropyLoss(reduction='sum') (src/basemodel.py:46) and nn.Dropout
+// (src/resnet.py:105, src/vggnet.py:81-90).  The head computes in fp32 (exact-fp32 MFMA).
+#include "common.h"
+
+namespace {
+
+// ---- strided fp32 GEMM -----------------------------------------------------------------------------
+//   C[m][n] (+)= sum_k A(m,k) * B(n,k) [+ bias[n]],   A(m,k) = a[m*sam + k*sak],  B(n,k) = b[n*sbn + k*sbk]
+// One of the two strides of each operand is 1; the loader walks that one with consecutive lanes.
+// 64x64 output tile per 256-thread workgroup, 4 waves in 2x2, one 32x32 block per wave computed by
+// v_mfma_f32_32x32x2f32 (A: lane -> row lane%32, k lane/32); K step 32; LDS tiles [k][row], pitch 68
+// floats (rows of one k on consecutive banks: conflict-free fragment reads).
+//   Linear forward   y[B][N]  = x[B][K] W[N][K]^T + b : A = x (k contiguous), B = W (k contiguous)
+//   input gradient   dx[B][K] = dy[B][N] W[N][K]      : A = dy (k contiguous), B(n=k', k=n) = W (row contiguous)
+//   weight gradient  dW[N][K] = dy[B][N]^T x[B][K]    : A(m=n, k=b) = dy, B(n=k', k=b) = x (both row contiguous)
+struct GemmParams {
+    const float* a;
+    const float* b;
+    const float* bias;
+    float* c;
+    int M, N, K, ldc;
+    int64_t sam, sak, sbn, sbk;
+    int accumulate;
+};
+
+constexpr int GT = 64, GK = 32, GP = 68;
+
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tile(float* __restrict__ T, const float* __restrict__ src, int row0, int nrows,
+                                          int k0, int K, int64_t srow, int64_t sk, int tid) {
+#pragma unroll
+    for (int i = 0; i < GT * GK / 256; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = KCONTIG ? idx / GK : idx % GT;
+        const int k = KCONTIG ? idx % GK : idx / GT;
+        float v = 0.f;
+        if (row0 + r < nrows && k0 + k < K) v = src[(int64_t)(row0 + r) * srow + (int64_t)(k0 + k) * sk];
+        T[k * GP + r] = v;
+    }
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    __shared__ float As[GK * GP];
+    __shared__ float Bs[GK * GP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < p.K; k0 += GK) {
+        load_tile<AK>(As, p.a, m0, p.M, k0, p.K, p.sam, p.sak, tid);
+        load_tile<BK>(Bs, p.b, n0, p.N, k0, p.K, p.sbn, p.sbk, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ss = 0; ss < GK / 2; ++ss) {
+            const float fa = As[(2 * ss + lh) * GP + wm * 32 + l31];
+            const float fb = Bs[(2 * ss + lh) * GP + wn * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C layout of the 32x32 block: column = lane%32, rows (r&3) + 8*(r>>2) + 4*(lane/32)
+    const int n = n0 + wn * 32 + l31;
+    if (n >= p.N) return;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) {
+            float* o = p.c + (int64_t)m * p.ldc + n;
+            const float v = acc[r] + bias;
+            *o = p.accumulate ? *o + v : v;
+        }
+    }
+}
+
+// The accumulator's column index runs with the lane, so C rows are written with consecutive lanes on
+// consecutive n: coalesced for y / dx / dW alike.
+
+// ---- softmax + cross entropy, reduction='sum' --------------------------------------------------------
+// One block per sample: row max, sum of exponentials, loss_i = log(sum) + max - logit[target] and, in
+// the same pass, d(loss)/d(logits) = softmax - onehot (the backward only scales it by the upstream
+// scalar).  argmax (first maximum, as torch.argmax) feeds score() without another pass.
+__device__ __forceinline__ float block_max_256(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ float block_add_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits,
+                                                         const int64_t* __restrict__ target,
+                                                         float* __restrict__ row_loss, float* __restrict__ dlogits,
+                                                         int32_t* __restrict__ argmax_out, int N) {
+    __shared__ float sh[4];
+    __shared__ int shi[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (int64_t)b * N;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int i = tid; i < N; i += 256) {
+        const float v = x[i];
+        if (v > mx) { mx = v; mi = i; }            // strided scan keeps the smallest index per thread
+    }
+    const float gmax = block_max_256(mx, sh);
+    int cand = (mx == gmax) ? mi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if ((tid & 63) == 0) shi[tid >> 6] = cand;
+    float se = 0.f;
+    for (int i = tid; i < N; i += 256) se += __expf(x[i] - gmax);
+    const float sum = block_add_256(se, sh);          // (barriers inside also publish shi)
+    const int64_t t = target[b];
+    if (tid == 0) {
+        row_loss[b] = (t >= 0 && t < N) ? logf(sum) + gmax - x[t] : 0.f;
+        if (argmax_out) argmax_out[b] = min(min(shi[0], shi[1]), min(shi[2], shi[3]));
+    }
+    if (dlogits) {
+        const float inv = 1.f / sum;
+        float* d = dlogits + (int64_t)b * N;
+        for (int i = tid; i < N; i += 256) d[i] = __expf(x[i] - gmax) * inv - (i == t ? 1.f : 0.f);
+    }
+}
+
+// loss = sum_b row_loss[b], fixed order (one block)
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+    const float t = block_add_256(a, sh);
+    if (threadIdx.x == 0) *out = t;
+}
+
+// ---- dropout ------------------------------------------------------------------------------------------
+// Counter-based: element i of call `offset` under `seed` keeps iff hash(seed, offset, i) >= p*2^32; kept
+// values are scaled by 1/(1-p) (nn.Dropout training semantics).  The keep mask is saved as bytes.
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          unsigned char* __restrict__ mask, int64_t n,
+                                                          uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = mix32(seed * 0xD1342543DE82EF95ull + offset * 0x2545F4914F6CDD1Dull + (uint64_t)i);
+        const bool keep = r >= thresh;
+        y[i] = keep ? x[i] * scale : 0.f;
+        mask[i] = keep ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                          float* __restrict__ dx, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = mask[i] ? dy[i] * scale : 0.f;
+}
+
+inline int grid1d(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+}
+
+int launch_gemm(const GemmParams& p, bool ak, bool bk, hipStream_t s) {
+    dim3 grid(ceil_div(p.N, GT), ceil_div(p.M, GT));
+    if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
+    else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
+    CNK_CHECK_LAUNCH("gemm_f32");
+    return 0;
+}
+
+}  // namespace
+
+int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, hipStream_t s) {
+    GemmParams p = {x, w, bias, y, B, N, K, N, K, 1, K, 1, 0};
+    return launch_gemm(p, true, true, s);
+}
+
+int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, hipStream_t s) {
+    // dx[b][k'] = sum_n dy[b][n] * w[n][k']
+    GemmParams p = {dy, w, nullptr, dx, B, K, N, K, N, 1, 1, K, 0};
+    return launch_gemm(p, true, false, s);
+}
+
+int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, hipStream_t s) {
+    // dw[n][k'] = sum_b dy[b][n] * x[b][k']
+    GemmParams p = {dy, x, nullptr, dw, N, K, B, K, 1, N, 1, K, accumulate};
+    return launch_gemm(p, false, false, s);
+}
+
+int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax,
+                   float* row_loss_ws, int B, int N, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(256), 0, s, logits, target, row_loss_ws, dlogits, argmax, N);
+    CNK_CHECK_LAUNCH("softmax_ce");
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, s, row_loss_ws, B, loss);
+    CNK_CHECK_LAUNCH("sum_rows");
+    return 0;
+}
+
+int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                hipStream_t s) {
+    double t = (double)p * 4294967296.0;
+    uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, y, mask, n, thresh, 1.f / (1.f - p),
+                       seed, offset);
+    CNK_CHECK_LAUNCH("dropout_fwd");
+    return 0;
+}
+
+int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s) {
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, dy, mask, dx, n, 1.f / (1.f - p));
+    CNK_CHECK_LAUNCH("dropout_bwd");
+    return 0;
+}

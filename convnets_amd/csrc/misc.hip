@@ -213,6 +213,76 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---- gradient clipping over the flat gradient arena (basemodel.py:131-178) ----------------------
+// clip_grad_norm_: total = ||g||_2 over ALL gradients, g *= min(1, max_norm / (total + 1e-6)).
+// Pass 1: per-block sums of squares (fixed order).  Pass 2: every block re-derives the same total
+// from the partials (<= 1024 floats, fixed order => identical in every block, reproducible), then
+// scales its share; block 0 also stores the norm for the caller.
+constexpr int CLIP_BLOCKS = 1024;
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void grad_sqsum_kernel(const float* __restrict__ g, int64_t n4, int64_t n,
+                                                         float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t base = i * 4;
+        if (base + 4 <= n) {
+            f32x4 v = *(const f32x4*)(g + base);
+            a0 += v[0] * v[0]; a1 += v[1] * v[1]; a2 += v[2] * v[2]; a3 += v[3] * v[3];
+        } else {
+            for (int64_t j = base; j < n; ++j) a0 += g[j] * g[j];
+        }
+    }
+    float t = block_sum_256((a0 + a1) + (a2 + a3), sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void grad_clip_scale_kernel(float* __restrict__ g, int64_t n4, int64_t n,
+                                                              const float* __restrict__ partial, int nparts,
+                                                              float max_norm, float* __restrict__ norm_out) {
+    __shared__ float sh[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += partial[i];
+    const float total = sqrtf(block_sum_256(a, sh));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
+    float coef = max_norm / (total + 1e-6f);
+    if (!(coef < 1.f)) return;                       // clamp(coef, max=1): nothing to scale
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t base = i * 4;
+        if (base + 4 <= n) {
+            f32x4 v = *(f32x4*)(g + base);
+            v[0] *= coef; v[1] *= coef; v[2] *= coef; v[3] *= coef;
+            *(f32x4*)(g + base) = v;
+        } else {
+            for (int64_t j = base; j < n; ++j) g[j] *= coef;
+        }
+    }
+}
+
+// clip_grad_value_: g = clamp(g, -c, +c)
+__global__ __launch_bounds__(256) void grad_clip_value_kernel(float* __restrict__ g, int64_t n4, int64_t n, float c) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t base = i * 4;
+        if (base + 4 <= n) {
+            f32x4 v = *(f32x4*)(g + base);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], -c), c);
+            *(f32x4*)(g + base) = v;
+        } else {
+            for (int64_t j = base; j < n; ++j) g[j] = fminf(fmaxf(g[j], -c), c);
+        }
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096);
@@ -323,5 +393,25 @@ int adam_dispatch(float* p, const float* g, float* m, float* v, int64_t n, float
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4)), dim3(256), 0, s, p, g, m, v, n4, n, lr, b1, b2,
                        eps, wd, bc1, bc2_sqrt);
     CNK_CHECK_LAUNCH("adam");
+    return 0;
+}
+
+size_t grad_clip_workspace_bytes() { return CLIP_BLOCKS * sizeof(float); }
+
+int grad_clip_norm(float* g, int64_t n, float max_norm, float* norm_out, float* ws, hipStream_t s) {
+    int64_t n4 = (n + 3) / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > CLIP_BLOCKS) blocks = CLIP_BLOCKS;
+    hipLaunchKernelGGL(grad_sqsum_kernel, dim3(blocks), dim3(256), 0, s, g, n4, n, ws);
+    CNK_CHECK_LAUNCH("grad_sqsum");
+    hipLaunchKernelGGL(grad_clip_scale_kernel, dim3(blocks), dim3(256), 0, s, g, n4, n, ws, blocks, max_norm, norm_out);
+    CNK_CHECK_LAUNCH("grad_clip_scale");
+    return 0;
+}
+
+int grad_clip_value(float* g, int64_t n, float c, hipStream_t s) {
+    int64_t n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(grad_clip_value_kernel, dim3(grid_for(n4)), dim3(256), 0, s, g, n4, n, c);
+    CNK_CHECK_LAUNCH("grad_clip_value");
     return 0;
 }

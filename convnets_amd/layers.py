@@ -106,6 +106,42 @@ class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
         return ops.GlobalAvgPoolFn.apply(x)
 
 
+class Linear(nn.Linear):
+    """nn.Linear of the classifier heads (resnet.py:106, vggnet.py:83-92) on the HIP fp32 GEMM."""
+
+    def forward(self, x):
+        return ops.LinearFn.apply(x, self.weight, self.bias)
+
+
+class Dropout(nn.Dropout):
+    """nn.Dropout(p) (resnet.py:105): identity in eval mode or at p == 0, HIP kernel otherwise."""
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        if self.p >= 1.0:
+            return x * 0.0
+        return ops.DropoutFn.apply(x, self.p)
+
+
+class CrossEntropyLoss(nn.CrossEntropyLoss):
+    """nn.CrossEntropyLoss(reduction='sum') as the reference builds it (basemodel.py:46).  Calling it
+    returns the loss; `last_pred` then holds the per-sample argmax of the same logits (int32, device)
+    for score() (basemodel.py:119-121)."""
+
+    def __init__(self, reduction='sum'):
+        super().__init__(reduction=reduction)
+        if reduction != 'sum':
+            raise NotImplementedError("convnets_amd.CrossEntropyLoss: reduction='sum' only (basemodel.py:46)")
+        self.last_pred = None
+        self.last_logits = None
+
+    def forward(self, outputs, targets):
+        loss, pred = ops.SoftmaxCrossEntropySumFn.apply(outputs, targets)
+        self.last_pred, self.last_logits = pred, outputs
+        return loss
+
+
 class ConvBlock(nn.Sequential):
     """conv -> [BN] -> [ReLU] as conv2d_block builds it (basemodel.py:999-1015): an nn.Sequential
     with children '0','1','2' (same state_dict keys), whose forward runs BN + ReLU (+ the residual

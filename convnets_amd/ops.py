@@ -646,3 +646,124 @@ def nchw_to_nhwc(x, dtype):
     check(lib.cnk_nchw_to_nhwc(_p(x), _p(y), N, C, H, W, CNK_BF16 if dtype == torch.bfloat16 else CNK_F32,
                                _stream()))
     return y
+
+
+# ---- classifier head ---------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (resnet.py:106; vggnet.py:83-92) on the fp32 MFMA GEMM of csrc/head.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x)
+        lib = _lib.load()
+        if x.dim() != 2 or x.dtype != torch.float32 or weight.dtype != torch.float32:
+            raise ValueError('linear: expected fp32 x[B][K], got %s %s' % (tuple(x.shape), x.dtype))
+        x = x.contiguous()
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        B, K = x.shape
+        N = w.shape[0]
+        if w.shape[1] != K:
+            raise ValueError('linear: x has %d features, weight expects %d' % (K, w.shape[1]))
+        y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        check(lib.cnk_linear_fwd(_p(x), _p(w), _p(bias), _p(y), B, K, N, _stream()))
+        ctx.save_for_backward(x, w)
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        weight, bias = ctx.params
+        dy = dy.contiguous()
+        B, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, K), dtype=torch.float32, device=x.device)
+            check(lib.cnk_linear_dgrad(_p(dy), _p(w), _p(dx), B, K, N, _stream()))
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            gw = _arena_grad(weight) if weight.is_contiguous() else None
+            gb = _arena_grad(bias) if bias is not None else None
+            direct = gw is not None and (bias is None or gb is not None)
+            if direct:
+                dw_buf, db_buf = gw, gb
+            else:
+                dw_buf = dw = torch.empty_like(w)
+                db_buf = db = torch.empty(N, dtype=torch.float32, device=x.device) if bias is not None else None
+            ws = workspace(lib.cnk_linear_wgrad_workspace_bytes(B, N), x.device)
+            check(lib.cnk_linear_wgrad(_p(dy), _p(x), _p(dw_buf), _p(db_buf), int(direct), B, K, N,
+                                       _p(ws), ws.numel(), _stream()))
+            if direct:
+                _grad_written(weight)
+                if bias is not None:
+                    _grad_written(bias)
+        return dx, dw, db
+
+
+_dropout_calls = [0]
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout, training mode (resnet.py:105).  Keep pattern = hash(torch.initial_seed(), call
+    counter, element index): reproducible under torch.manual_seed, not torch's Philox stream."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        _require_gpu(x)
+        lib = _lib.load()
+        if x.dtype != torch.float32:
+            raise ValueError('dropout: the head runs in fp32')
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+        _dropout_calls[0] += 1
+        check(lib.cnk_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p),
+                                  torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_calls[0], _stream()))
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.cnk_dropout_bwd(_p(dy), _p(mask), _p(dx), dy.numel(), ctx.p, _stream()))
+        return dx, None
+
+
+class SoftmaxCrossEntropySumFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss(reduction='sum') (basemodel.py:46): loss and d(loss)/d(logits) in one pass.
+    Also returns the per-sample argmax (non-differentiable) so score() needs no second pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _require_gpu(logits)
+        lib = _lib.load()
+        if logits.dim() != 2 or logits.dtype != torch.float32:
+            raise ValueError('cross entropy: expected fp32 logits[B][N], got %s %s' % (tuple(logits.shape), logits.dtype))
+        if target.dtype != torch.int64 or target.shape != logits.shape[:1]:
+            raise ValueError('cross entropy: expected int64 class targets of shape [B]')
+        logits = logits.contiguous()
+        target = target.contiguous()
+        B, N = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        need = logits.requires_grad
+        dlogits = torch.empty_like(logits) if need else None
+        pred = torch.empty(B, dtype=torch.int32, device=logits.device)
+        ws = workspace(B * 4, logits.device)
+        check(lib.cnk_softmax_ce_sum(_p(logits), _p(target), _p(loss), _p(dlogits), _p(pred), B, N,
+                                     _p(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)
+        return loss, pred
+
+    @staticmethod
+    def backward(ctx, dloss, _dpred=None):
+        (dlogits,) = ctx.saved_tensors
+        if dloss is None or dlogits is None:
+            return None, None
+        return dlogits * dloss, None

@@ -74,6 +74,26 @@ class FlatAdam:
             self.step_count, s))
         ops.bump_weights_epoch()
 
+    @torch.no_grad()
+    def clip_grad_norm(self, max_norm):
+        """clip_grad_norm_(parameters, max_norm) of basemodel.py:156 over the whole arena in two
+        kernels; returns the total norm as a DEVICE scalar (no host sync)."""
+        lib = _lib.load()
+        ws = ops.workspace(lib.cnk_grad_clip_workspace_bytes(), self.flat_g.device)
+        norm = torch.empty((), dtype=torch.float32, device=self.flat_g.device)
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.cnk_grad_clip_norm(ctypes.c_void_p(self.flat_g.data_ptr()), self.numel, float(max_norm),
+                                     ctypes.c_void_p(norm.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                     ws.numel(), s))
+        return norm
+
+    @torch.no_grad()
+    def clip_grad_value(self, clip_value):
+        """clip_grad_value_(parameters, clip_value) of basemodel.py:171 as one kernel."""
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(_lib.load().cnk_grad_clip_value(ctypes.c_void_p(self.flat_g.data_ptr()), self.numel,
+                                              float(clip_value), s))
+
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg.clone(),
                     exp_avg_sq=self.exp_avg_sq.clone(),

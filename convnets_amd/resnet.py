@@ -9,6 +9,7 @@ features.2.res_bottleneck.1.1.running_var, classifier.1.weight, ...).  The block
 import torch
 import torch.nn as nn
 
+from . import layers
 from .basemodel import MultiClassBaseModel
 
 
@@ -103,5 +104,5 @@ class ResNet(MultiClassBaseModel):
                           stride=stride)
 
     def make_classifier_layers(self):                        # src/resnet.py:100-108
-        return nn.Sequential(nn.Dropout(p=self.setting.dropout_rate),
-                             nn.Linear(self.num_flat_features(), self.setting.num_classes))
+        return nn.Sequential(layers.Dropout(p=self.setting.dropout_rate),
+                             layers.Linear(self.num_flat_features(), self.setting.num_classes))

@@ -3,6 +3,7 @@
 Dropouts (VGG-16 @224/1000 classes = 37,698,472 parameters)."""
 import torch.nn as nn
 
+from . import layers
 from .basemodel import MultiClassBaseModel
 
 
@@ -35,6 +36,6 @@ class VGGNet(MultiClassBaseModel):
     def make_classifier_layers(self):                        # src/vggnet.py:76-94
         p = self.setting.dropout_rate
         return nn.Sequential(
-            nn.Dropout(p=p), nn.Linear(self.num_flat_features(), 4096), nn.ReLU(inplace=True),
-            nn.Dropout(p=p), nn.Linear(4096, 4096), nn.ReLU(inplace=True),
-            nn.Dropout(p=p), nn.Linear(4096, self.setting.num_classes))
+            layers.Dropout(p=p), layers.Linear(self.num_flat_features(), 4096), layers.ReLU(inplace=True),
+            layers.Dropout(p=p), layers.Linear(4096, 4096), layers.ReLU(inplace=True),
+            layers.Dropout(p=p), layers.Linear(4096, self.setting.num_classes))

@@ -203,6 +203,45 @@ int cnk_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int32_t N, int32_t C, in
 int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
+/* ---- classifier head -- fp32, row-major, no workspace ---------------------------
+ * nn.Linear (resnet.py:106, vggnet.py:83-92): y[B][N] = x[B][K] W[N][K]^T + bias (bias may be NULL);
+ * dx[B][K] = dy[B][N] W[N][K]; dW[N][K] (+)= dy^T x, dbias[N] (+)= column sums of dy (dbias may be
+ * NULL; needs workspace cnk_linear_wgrad_workspace_bytes(B, N)). */
+int cnk_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t K,
+                   int32_t N, void* stream);
+int cnk_linear_dgrad(const float* dy, const float* w, float* dx, int32_t B, int32_t K, int32_t N,
+                     void* stream);
+size_t cnk_linear_wgrad_workspace_bytes(int32_t B, int32_t N);
+int cnk_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int accumulate, int32_t B,
+                     int32_t K, int32_t N, void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.CrossEntropyLoss(reduction='sum') (basemodel.py:46) on logits[B][N] with int64 class targets:
+ * *loss = sum_b (logsumexp(logits_b) - logits_b[target_b]).  dlogits (may be NULL) receives
+ * softmax - onehot, i.e. d(loss)/d(logits) for an upstream gradient of 1; argmax (may be NULL,
+ * int32[B]) the predicted class per sample (score(), basemodel.py:119).  workspace: B floats. */
+int cnk_softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits,
+                       int32_t* argmax, int32_t B, int32_t N, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* nn.Dropout in training mode (resnet.py:105): y = keep ? x/(1-p) : 0 with a counter-based keep
+ * decision hash(seed, offset, index) -- reproducible for a given (seed, offset), independent of the
+ * launch geometry; mask (n bytes) is the keep pattern for the backward dx = mask ? dy/(1-p) : 0.
+ * It does not reproduce torch's Philox stream: parity runs use dropout_rate = 0. */
+int cnk_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                    uint64_t offset, void* stream);
+int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+
+/* Gradient clipping over the same flat fp32 gradient arena (gradient_clipping, basemodel.py:131-178).
+ * cnk_grad_clip_norm == torch.nn.utils.clip_grad_norm_(params, max_norm) (L2, basemodel.py:156): the
+ * norm is taken over all gradients together and every gradient is scaled by
+ * min(1, max_norm / (norm + 1e-6)); *total_norm_out (device float, may be NULL) receives the norm.
+ * Arena padding must be zero.  workspace: cnk_grad_clip_workspace_bytes().
+ * cnk_grad_clip_value == clip_grad_value_(params, clip_value) (basemodel.py:171): clamp to [-c, +c]. */
+size_t cnk_grad_clip_workspace_bytes(void);
+int cnk_grad_clip_norm(float* grads, int64_t n, float max_norm, float* total_norm_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int cnk_grad_clip_value(float* grads, int64_t n, float clip_value, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline
  * leg).  cnk_prof_begin(tag_mask) arms recording for kernels whose class bit is set;
  * cnk_prof_collect synchronises the recorded events (call after the timed region) and returns

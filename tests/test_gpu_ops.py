@@ -380,3 +380,93 @@ def test_flat_adam_matches_torch():
         for p, q in zip(ref, mine):
             assert rel_l2(host(q), p.detach().numpy()) < 2e-6, step
     assert all(q.data_ptr() >= opt.flat_p.data_ptr() for q in mine)
+
+
+@pytest.mark.parametrize('max_norm', [0.5, 1e6], ids=['clips', 'no-op'])
+def test_grad_clip_matches_torch(max_norm):
+    """gradient_clipping (basemodel.py:131-178): clip_grad_norm_ and clip_grad_value_ over the flat
+    gradient arena == torch's per-parameter utilities, including the returned total norm."""
+    from convnets_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 3, 7, 7), (64,), (150,), (1000, 77), (5,), (256, 64, 1, 1)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    opt = FlatAdam(mine, lr=0.01)
+    opt.zero_grad()
+    for p, q in zip(ref, mine):
+        gr = torch.randn(p.shape, generator=g) * 0.3
+        p.grad = gr.clone()
+        q.grad.add_(gr.cuda())
+    want_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm=max_norm)
+    got_norm = opt.clip_grad_norm(max_norm)
+    torch.cuda.synchronize()
+    assert abs(float(got_norm) - float(want_norm)) <= 2e-6 * float(want_norm)
+    for p, q in zip(ref, mine):
+        assert rel_l2(host(q.grad), p.grad.numpy()) < 2e-6
+    torch.nn.utils.clip_grad_value_(ref, clip_value=0.05)
+    opt.clip_grad_value(0.05)
+    torch.cuda.synchronize()
+    for p, q in zip(ref, mine):
+        assert np.array_equal(host(q.grad), p.grad.numpy()) or rel_l2(host(q.grad), p.grad.numpy()) < 2e-6
+    assert float(opt.flat_g.abs().max()) <= float(np.float32(0.05))
+
+
+@pytest.mark.parametrize('shape', [(256, 2048, 1000), (64, 400, 120), (5, 84, 10), (33, 130, 67), (128, 4096, 4096)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_linear_vs_torch(shape):
+    """nn.Linear forward / dx / dW / db (csrc/head.hip) against torch fp64 on the host."""
+    from convnets_amd import ops
+    B, K, N = shape
+    g = torch.Generator().manual_seed(B + K + N)
+    x, w, b = torch.randn(B, K, generator=g), torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    dy = torch.randn(B, N, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.linear(xr, wr, br).backward(dy.double())
+    xt, wt, bt = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.LinearFn.apply(xt, wt, bt)
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    assert rel_l2(host(y), F.linear(x.double(), w.double(), b.double()).numpy()) < 1e-5
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < 1e-5
+    assert rel_l2(host(wt.grad), wr.grad.numpy()) < 2e-5
+    assert rel_l2(host(bt.grad), br.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(256, 1000), (64, 10), (7, 3), (33, 2500)], ids=lambda s: 'x'.join(map(str, s)))
+def test_softmax_cross_entropy_sum_vs_torch(shape):
+    from convnets_amd import layers
+    B, N = shape
+    g = torch.Generator().manual_seed(B * N)
+    z = torch.randn(B, N, generator=g) * 3
+    t = torch.randint(0, N, (B,), generator=g)
+    zr = z.double().requires_grad_(True)
+    lr = F.cross_entropy(zr, t, reduction='sum')
+    (lr * 0.7).backward()
+    zt = z.cuda().requires_grad_(True)
+    cf = layers.CrossEntropyLoss(reduction='sum')
+    loss = cf(zt, t.cuda())
+    (loss * 0.7).backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(lr)) <= 2e-6 * abs(float(lr))
+    assert rel_l2(host(zt.grad), zr.grad.numpy()) < 2e-6
+    assert np.array_equal(cf.last_pred.cpu().numpy(), z.argmax(dim=1).numpy())
+
+
+def test_dropout_statistics_and_backward():
+    from convnets_amd import layers
+    torch.manual_seed(5)
+    d = layers.Dropout(p=0.3).cuda().train()
+    x = torch.randn(512, 4096, device='cuda').requires_grad_(True)
+    y = d(x)
+    y.backward(torch.ones_like(y))
+    torch.cuda.synchronize()
+    keep = (y != 0)
+    rate = float(keep.float().mean())
+    assert abs(rate - 0.7) < 3e-3, rate                       # 2M samples: sigma = 3e-4
+    assert torch.equal(y[keep], (x.detach() / 0.7)[keep])
+    assert torch.equal(x.grad, keep.float() / 0.7)
+    y2 = d(x)                                                 # a new call draws a new pattern
+    assert not torch.equal(y2 != 0, keep)
+    torch.manual_seed(5)
+    d.eval()
+    assert d(x) is x
