@@ -69,9 +69,9 @@ SIGNATURES = {
     'cnk_gap_fwd': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_gap_bwd': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_nchw_to_nhwc': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_int, _vp]),
-    'cnk_linear_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    'cnk_linear_dgrad': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    'cnk_linear_wgrad_workspace_bytes': (_sz, [_i32, _i32]),
+    'cnk_linear_workspace_bytes': (_sz, [ctypes.c_int, _i32, _i32, _i32]),
+    'cnk_linear_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    'cnk_linear_dgrad': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     'cnk_linear_wgrad': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _vp, _sz, _vp]),
     'cnk_softmax_ce_sum': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     'cnk_dropout_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_uint64, ctypes.c_uint64, _vp]),

@@ -14,9 +14,10 @@ int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const fl
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
-int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, hipStream_t s);
-int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, hipStream_t s);
-int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, hipStream_t s);
+size_t linear_workspace(int pass, int B, int K, int N);
+int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, float* ws, size_t ws_bytes, hipStream_t s);
+int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, float* ws, size_t ws_bytes, hipStream_t s);
+int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax, float* row_loss_ws, int B, int N, hipStream_t s);
 int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
 int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s);
@@ -397,25 +398,34 @@ int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     return adam_dispatch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
 }
 
-int cnk_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t K, int32_t N, void* stream) {
+size_t cnk_linear_workspace_bytes(int pass, int32_t B, int32_t K, int32_t N) {
+    if (B <= 0 || K <= 0 || N <= 0 || pass < 0 || pass > 2) return 0;
+    size_t n = linear_workspace(pass, B, K, N);
+    if (pass == CNK_PASS_WGRAD) {
+        size_t c = colsum_workspace(B, N);
+        if (c > n) n = c;
+    }
+    return n;
+}
+
+int cnk_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t K, int32_t N, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(x && w && y && B > 0 && K > 0 && N > 0, "cnk_linear_fwd: bad arguments");
-    return linear_fwd(x, w, bias, y, B, K, N, S(stream));
+    CNK_CHECK_ARG(workspace_bytes >= linear_workspace(0, B, K, N) && (workspace || !linear_workspace(0, B, K, N)), "cnk_linear_fwd: workspace too small");
+    return linear_fwd(x, w, bias, y, B, K, N, (float*)workspace, workspace_bytes, S(stream));
 }
 
-int cnk_linear_dgrad(const float* dy, const float* w, float* dx, int32_t B, int32_t K, int32_t N, void* stream) {
+int cnk_linear_dgrad(const float* dy, const float* w, float* dx, int32_t B, int32_t K, int32_t N, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(dy && w && dx && B > 0 && K > 0 && N > 0, "cnk_linear_dgrad: bad arguments");
-    return linear_dgrad(dy, w, dx, B, K, N, S(stream));
+    CNK_CHECK_ARG(workspace_bytes >= linear_workspace(1, B, K, N) && (workspace || !linear_workspace(1, B, K, N)), "cnk_linear_dgrad: workspace too small");
+    return linear_dgrad(dy, w, dx, B, K, N, (float*)workspace, workspace_bytes, S(stream));
 }
-
-size_t cnk_linear_wgrad_workspace_bytes(int32_t B, int32_t N) { return colsum_workspace(B, N); }
 
 int cnk_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int accumulate, int32_t B, int32_t K, int32_t N, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(dy && x && dw && B > 0 && K > 0 && N > 0, "cnk_linear_wgrad: bad arguments");
-    if (int rc = linear_wgrad(dy, x, dw, B, K, N, accumulate, S(stream))) return rc;
-    if (dbias) {
-        CNK_CHECK_ARG(workspace && workspace_bytes >= colsum_workspace(B, N), "cnk_linear_wgrad: workspace too small");
-        return colsum(dy, dbias, B, N, CNK_F32, accumulate, workspace, workspace_bytes, S(stream));
-    }
+    size_t need = cnk_linear_workspace_bytes(CNK_PASS_WGRAD, B, K, N);
+    CNK_CHECK_ARG(workspace_bytes >= (dbias ? need : linear_workspace(2, B, K, N)) && (workspace || !need), "cnk_linear_wgrad: workspace too small");
+    if (int rc = linear_wgrad(dy, x, dw, B, K, N, accumulate, (float*)workspace, workspace_bytes, S(stream))) return rc;
+    if (dbias) return colsum(dy, dbias, B, N, CNK_F32, accumulate, workspace, workspace_bytes, S(stream));
     return 0;
 }
 

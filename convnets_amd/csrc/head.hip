@@ -22,37 +22,70 @@ struct GemmParams {
     int M, N, K, ldc;
     int64_t sam, sak, sbn, sbk;
     int accumulate;
+    int ksplit;             // K range per blockIdx.z (multiple of GK); partial results go to slabs
+    float* slab;            // [gridDim.z][M][N] when gridDim.z > 1
 };
 
 constexpr int GT = 64, GK = 32, GP = 68;
 
-template <bool KCONTIG>
+// VEC4: 16-byte loads along the contiguous index (host checks stride and base alignment)
+template <bool KCONTIG, bool VEC4>
 __device__ __forceinline__ void load_tile(float* __restrict__ T, const float* __restrict__ src, int row0, int nrows,
-                                          int k0, int K, int64_t srow, int64_t sk, int tid) {
+                                          int k0, int k1, int64_t srow, int64_t sk, int tid) {
+    if constexpr (VEC4) {
 #pragma unroll
-    for (int i = 0; i < GT * GK / 256; ++i) {
-        const int idx = tid + 256 * i;
-        const int r = KCONTIG ? idx / GK : idx % GT;
-        const int k = KCONTIG ? idx % GK : idx / GT;
-        float v = 0.f;
-        if (row0 + r < nrows && k0 + k < K) v = src[(int64_t)(row0 + r) * srow + (int64_t)(k0 + k) * sk];
-        T[k * GP + r] = v;
+        for (int i = 0; i < GT * GK / 1024; ++i) {
+            const int idx = tid + 256 * i;                      // one float4 each
+            if constexpr (KCONTIG) {
+                const int r = idx / (GK / 4), k = (idx % (GK / 4)) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row0 + r < nrows) {
+                    const float* p = src + (int64_t)(row0 + r) * srow + (k0 + k);
+                    if (k0 + k + 4 <= k1) v = *(const f32x4*)p;
+                    else
+                        for (int e = 0; e < 4; ++e) if (k0 + k + e < k1) v[e] = p[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(k + e) * GP + r] = v[e];
+            } else {
+                const int k = idx / (GT / 4), r = (idx % (GT / 4)) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k0 + k < k1) {
+                    const float* p = src + (int64_t)(k0 + k) * sk + (row0 + r);
+                    if (row0 + r + 4 <= nrows) v = *(const f32x4*)p;
+                    else
+                        for (int e = 0; e < 4; ++e) if (row0 + r + e < nrows) v[e] = p[e];
+                }
+                *(f32x4*)(T + k * GP + r) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < GT * GK / 256; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = KCONTIG ? idx / GK : idx % GT;
+            const int k = KCONTIG ? idx % GK : idx / GT;
+            float v = 0.f;
+            if (row0 + r < nrows && k0 + k < k1) v = src[(int64_t)(row0 + r) * srow + (int64_t)(k0 + k) * sk];
+            T[k * GP + r] = v;
+        }
     }
 }
 
-template <bool AK, bool BK>
+template <bool AK, bool BK, bool VEC4>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-    __shared__ float As[GK * GP];
-    __shared__ float Bs[GK * GP];
+    __shared__ __attribute__((aligned(16))) float As[GK * GP];
+    __shared__ __attribute__((aligned(16))) float Bs[GK * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kb = blockIdx.z * p.ksplit, ke = min(p.K, kb + p.ksplit);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < p.K; k0 += GK) {
-        load_tile<AK>(As, p.a, m0, p.M, k0, p.K, p.sam, p.sak, tid);
-        load_tile<BK>(Bs, p.b, n0, p.N, k0, p.K, p.sbn, p.sbk, tid);
+    for (int k0 = kb; k0 < ke; k0 += GK) {
+        load_tile<AK, VEC4>(As, p.a, m0, p.M, k0, ke, p.sam, p.sak, tid);
+        load_tile<BK, VEC4>(Bs, p.b, n0, p.N, k0, ke, p.sbn, p.sbk, tid);
         __syncthreads();
 #pragma unroll
         for (int ss = 0; ss < GK / 2; ++ss) {
@@ -65,6 +98,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     // C layout of the 32x32 block: column = lane%32, rows (r&3) + 8*(r>>2) + 4*(lane/32)
     const int n = n0 + wn * 32 + l31;
     if (n >= p.N) return;
+    if (gridDim.z > 1) {                                  // split K: plain stores into this split's slab
+        float* sl = p.slab + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < p.M) sl[(int64_t)m * p.N + n] = acc[r];
+        }
+        return;
+    }
     const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -74,6 +116,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             const float v = acc[r] + bias;
             *o = p.accumulate ? *o + v : v;
         }
+    }
+}
+
+// C (+)= sum of the split-K slabs in fixed order (+ bias): deterministic, unlike float atomics
+__global__ __launch_bounds__(256) void gemm_slab_sum_kernel(const float* __restrict__ slab, int splits, float* __restrict__ c,
+                                                            const float* __restrict__ bias, int M, int N, int ldc,
+                                                            int accumulate) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+        float a = 0.f;
+        for (int sp = 0; sp < splits; ++sp) a += slab[(size_t)sp * total + i];
+        if (bias) a += bias[n];
+        float* o = c + (int64_t)m * ldc + n;
+        *o = accumulate ? *o + a : a;
     }
 }
 
@@ -177,33 +234,80 @@ inline int grid1d(int64_t n) {
     return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
 }
 
-int launch_gemm(const GemmParams& p, bool ak, bool bk, hipStream_t s) {
-    dim3 grid(ceil_div(p.N, GT), ceil_div(p.M, GT));
-    if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
-    else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
-    else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
+// Split K so that skinny problems (batch rows x huge weight matrix: the VGG / AlexNet heads) still put
+// ~512 workgroups on the chip; partial tiles go to slabs in the workspace and are summed in fixed order.
+int gemm_splits(int M, int N, int K) {
+    int tiles = ceil_div(M, GT) * ceil_div(N, GT);
+    if (tiles >= 256) return 1;
+    int want = 512 / tiles;
+    int maxk = K / (4 * GK);                               // at least four K steps per split
+    int sp = want < maxk ? want : maxk;
+    return sp < 1 ? 1 : sp;
+}
+
+size_t gemm_workspace(int M, int N, int K) {
+    int sp = gemm_splits(M, N, K);
+    return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+}
+
+template <bool AK, bool BK> int launch_gemm_v(GemmParams& p, bool vec4, dim3 grid, hipStream_t s) {
+    if (vec4) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, false>), grid, dim3(256), 0, s, p);
+    return 0;
+}
+
+int launch_gemm(GemmParams p, bool ak, bool bk, float* ws, size_t ws_bytes, hipStream_t s) {
+    int sp = gemm_splits(p.M, p.N, p.K);
+    if (sp > 1 && (!ws || ws_bytes < (size_t)sp * p.M * p.N * sizeof(float))) sp = 1;
+    p.ksplit = ceil_div(ceil_div(p.K, sp), GK) * GK;
+    sp = ceil_div(p.K, p.ksplit);
+    p.slab = ws;
+    // 16-byte loads need the contiguous index to start 16-byte aligned in every row / column
+    auto ok = [](const float* base, int64_t other_stride) {
+        return ((uintptr_t)base % 16 == 0) && (other_stride % 4 == 0);
+    };
+    const bool vec4 = ok(p.a, ak ? p.sam : p.sak) && ok(p.b, bk ? p.sbn : p.sbk);
+    dim3 grid(ceil_div(p.N, GT), ceil_div(p.M, GT), sp);
+    if (ak && bk) launch_gemm_v<true, true>(p, vec4, grid, s);
+    else if (ak && !bk) launch_gemm_v<true, false>(p, vec4, grid, s);
+    else if (!ak && bk) launch_gemm_v<false, true>(p, vec4, grid, s);
+    else launch_gemm_v<false, false>(p, vec4, grid, s);
     CNK_CHECK_LAUNCH("gemm_f32");
+    if (sp > 1) {
+        int64_t total = (int64_t)p.M * p.N;
+        hipLaunchKernelGGL(gemm_slab_sum_kernel, dim3(grid1d(total)), dim3(256), 0, s, ws, sp, p.c, p.bias, p.M, p.N,
+                           p.ldc, p.accumulate);
+        CNK_CHECK_LAUNCH("gemm_slab_sum");
+    }
     return 0;
 }
 
 }  // namespace
 
-int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, hipStream_t s) {
-    GemmParams p = {x, w, bias, y, B, N, K, N, K, 1, K, 1, 0};
-    return launch_gemm(p, true, true, s);
+size_t linear_workspace(int pass, int B, int K, int N) {
+    if (pass == 0) return gemm_workspace(B, N, K);
+    if (pass == 1) return gemm_workspace(B, K, N);
+    return gemm_workspace(N, K, B);
 }
 
-int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, hipStream_t s) {
+int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, float* ws,
+               size_t ws_bytes, hipStream_t s) {
+    GemmParams p = {x, w, bias, y, B, N, K, N, K, 1, K, 1, 0, 0, nullptr};
+    return launch_gemm(p, true, true, ws, ws_bytes, s);
+}
+
+int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, float* ws, size_t ws_bytes,
+                 hipStream_t s) {
     // dx[b][k'] = sum_n dy[b][n] * w[n][k']
-    GemmParams p = {dy, w, nullptr, dx, B, K, N, K, N, 1, 1, K, 0};
-    return launch_gemm(p, true, false, s);
+    GemmParams p = {dy, w, nullptr, dx, B, K, N, K, N, 1, 1, K, 0, 0, nullptr};
+    return launch_gemm(p, true, false, ws, ws_bytes, s);
 }
 
-int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, hipStream_t s) {
+int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, float* ws,
+                 size_t ws_bytes, hipStream_t s) {
     // dw[n][k'] = sum_b dy[b][n] * x[b][k']
-    GemmParams p = {dy, x, nullptr, dw, N, K, B, K, 1, N, 1, K, accumulate};
-    return launch_gemm(p, false, false, s);
+    GemmParams p = {dy, x, nullptr, dw, N, K, B, K, 1, N, 1, K, accumulate, 0, nullptr};
+    return launch_gemm(p, false, false, ws, ws_bytes, s);
 }
 
 int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax,

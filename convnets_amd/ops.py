@@ -665,7 +665,8 @@ class LinearFn(torch.autograd.Function):
         if w.shape[1] != K:
             raise ValueError('linear: x has %d features, weight expects %d' % (K, w.shape[1]))
         y = torch.empty((B, N), dtype=torch.float32, device=x.device)
-        check(lib.cnk_linear_fwd(_p(x), _p(w), _p(bias), _p(y), B, K, N, _stream()))
+        ws = workspace(lib.cnk_linear_workspace_bytes(PASS_FWD, B, K, N), x.device)
+        check(lib.cnk_linear_fwd(_p(x), _p(w), _p(bias), _p(y), B, K, N, _p(ws), ws.numel(), _stream()))
         ctx.save_for_backward(x, w)
         ctx.params = (weight, bias)
         return y
@@ -681,7 +682,8 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((B, K), dtype=torch.float32, device=x.device)
-            check(lib.cnk_linear_dgrad(_p(dy), _p(w), _p(dx), B, K, N, _stream()))
+            ws = workspace(lib.cnk_linear_workspace_bytes(PASS_DGRAD, B, K, N), x.device)
+            check(lib.cnk_linear_dgrad(_p(dy), _p(w), _p(dx), B, K, N, _p(ws), ws.numel(), _stream()))
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
             gw = _arena_grad(weight) if weight.is_contiguous() else None
             gb = _arena_grad(bias) if bias is not None else None
@@ -691,7 +693,7 @@ class LinearFn(torch.autograd.Function):
             else:
                 dw_buf = dw = torch.empty_like(w)
                 db_buf = db = torch.empty(N, dtype=torch.float32, device=x.device) if bias is not None else None
-            ws = workspace(lib.cnk_linear_wgrad_workspace_bytes(B, N), x.device)
+            ws = workspace(lib.cnk_linear_workspace_bytes(PASS_WGRAD, B, K, N), x.device)
             check(lib.cnk_linear_wgrad(_p(dy), _p(x), _p(dw_buf), _p(db_buf), int(direct), B, K, N,
                                        _p(ws), ws.numel(), _stream()))
             if direct:

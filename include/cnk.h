@@ -206,12 +206,14 @@ int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 /* ---- classifier head -- fp32, row-major, no workspace ---------------------------
  * nn.Linear (resnet.py:106, vggnet.py:83-92): y[B][N] = x[B][K] W[N][K]^T + bias (bias may be NULL);
  * dx[B][K] = dy[B][N] W[N][K]; dW[N][K] (+)= dy^T x, dbias[N] (+)= column sums of dy (dbias may be
- * NULL; needs workspace cnk_linear_wgrad_workspace_bytes(B, N)). */
+ * NULL).  Skinny problems (batch rows x a large weight matrix) are split along the reduction into
+ * fp32 slabs summed in fixed order: workspace = cnk_linear_workspace_bytes(pass, B, K, N), pass as
+ * CNK_PASS_FWD / _DGRAD / _WGRAD (may be 0). */
+size_t cnk_linear_workspace_bytes(int pass, int32_t B, int32_t K, int32_t N);
 int cnk_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t K,
-                   int32_t N, void* stream);
+                   int32_t N, void* workspace, size_t workspace_bytes, void* stream);
 int cnk_linear_dgrad(const float* dy, const float* w, float* dx, int32_t B, int32_t K, int32_t N,
-                     void* stream);
-size_t cnk_linear_wgrad_workspace_bytes(int32_t B, int32_t N);
+                     void* workspace, size_t workspace_bytes, void* stream);
 int cnk_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, int accumulate, int32_t B,
                      int32_t K, int32_t N, void* workspace, size_t workspace_bytes, void* stream);
 
