@@ -173,6 +173,54 @@ class MultiClassBaseModel(nn.Module):
         n = len(dataloader.dataset)
         return epoch_loss.item() / n, epoch_score.item() / n
 
+    # ---- inference measurement (basemodel.py:579-722) ---------------------------------------------
+    def inference_time(self, total_times, num_instances):
+        """basemodel.py:579-599, same arithmetic: `total_times` are per-batch device times in
+        MILLISECONDS (cuda.Event.elapsed_time), so the returned `images_per_sec` = instances / sum of
+        milliseconds -- i.e. THOUSANDS of images per second, the unit of data/results.xlsx's fps
+        column."""
+        total_times = np.array(total_times)
+        entire_time = np.sum(total_times)
+        mean_time = np.mean(total_times / self.setting.batch_size)
+        std_time = np.std(total_times / self.setting.batch_size)
+        return entire_time, mean_time, std_time, num_instances / entire_time
+
+    @torch.no_grad()
+    def test(self, dataloader, repetitions=50):
+        """The measurement core of the reference's test() (basemodel.py:601-722): eval mode,
+        `repetitions` warm-up forwards on a random batch, then every batch timed with device events
+        around forward + arg-max.  Returns (scores, total_times, fps) like the reference: accuracy per
+        subset of test_sample_size parts, per-batch milliseconds, and inference_time()'s fps.  The
+        sklearn classification report / confusion matrix are out of scope."""
+        self.eval()
+        dev = self.setting.device
+        bs, (ch, h, w) = self.setting.batch_size, self.setting.input_size
+        rand_input = dev.move(torch.randn(bs, ch, h, w, dtype=torch.float))
+        for _ in range(repetitions):
+            self(rand_input)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        total_times, preds, targs = [], [], []
+        for batch in dataloader:
+            inputs, targets = dev.move(batch)
+            start.record()
+            outputs = self(inputs)
+            predictions = torch.max(outputs, dim=1)[1]
+            end.record()
+            torch.cuda.synchronize()
+            total_times.append(start.elapsed_time(end))
+            preds.append(predictions.cpu().numpy())
+            targs.append(targets.cpu().numpy())
+            if self.setting.sanity_check:
+                break
+        y_preds, y_targets = np.concatenate(preds), np.concatenate(targs)
+        n = len(dataloader.dataset)
+        parts = getattr(self.setting, 'test_sample_size', None) or 1
+        part = max(int(n / parts), 1)
+        scores = [float(np.mean(y_targets[i:i + part] == y_preds[i:i + part]))
+                  for i in range(0, len(y_targets), part)]
+        _, _, _, fps = self.inference_time(total_times, n)
+        return scores, total_times, fps
+
     # ---- shape tracker (basemodel.py:725-816) ---------------------------------------------------
     def save_conv_outshape(self, layer):
         kh, kw = _pair(layer.kernel_size)

@@ -10,7 +10,7 @@
 
 // ---- kernel families (other translation units) ---------------------------------------------------
 bool igemm_supported(const cnk_conv_desc* d, int pass);
-int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, hipStream_t s);
+int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
@@ -253,11 +253,26 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
-    if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd(d, x, w_fwd, bias, y, bn_partial, S(stream));
+    if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd(d, x, w_fwd, bias, y, bn_partial, nullptr, 0, S(stream));
     CNK_CHECK_ARG(!bn_partial, "cnk_conv2d_fwd: this conv shape cannot emit BN partials (cnk_conv2d_fwd_bn_partial_slices == 0)");
     if (rowpatch_supported(d)) return rowpatch_fwd(d, x, w_fwd, bias, y, S(stream));
     if (smallc_supported(d)) return smallc_fwd(d, x, w_fwd, bias, y, S(stream));
     return direct_fwd(d, x, w_fwd, bias, y, S(stream));
+}
+
+int cnk_conv2d_fwd_act_supported(const cnk_conv_desc* d) {
+    return check_desc(d, "cnk_conv2d_fwd_act_supported") == 0 && igemm_supported(d, CNK_PASS_FWD) &&
+           d->Cout % (d->dtype == CNK_BF16 ? 8 : 4) == 0;
+}
+
+int cnk_conv2d_fwd_act(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, const void* residual, int relu, void* y, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_fwd_act")) return rc;
+    CNK_CHECK_ARG(x && w_fwd && y, "cnk_conv2d_fwd_act: null pointer");
+    CNK_CHECK_ARG(cnk_conv2d_fwd_act_supported(d), "cnk_conv2d_fwd_act: this conv shape has no fused-activation forward (cnk_conv2d_fwd_act_supported == 0)");
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
+    return igemm_fwd(d, x, w_fwd, bias, y, nullptr, residual, relu, S(stream));
 }
 
 int cnk_conv2d_dgrad_accepts_mask(const cnk_conv_desc* d) {

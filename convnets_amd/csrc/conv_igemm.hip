@@ -41,6 +41,7 @@ struct GatherParams {
     const unsigned char* bnf_mask;
     float* bnf_partial;      // [slices][Nout][2]
     int bnf_relu, bnf_tile0; // tile0: first slice of this launch (stride-parity classes)
+    int relu;                // inference epilogue: dst = max(conv + bias [+ addend], 0)
     int N, IH, IW, C;
     int OH, OW;
     int FH, FW, Nout;
@@ -117,6 +118,10 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 if (p.bias) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += p.bias[tile_n * BN + col + e];
+                }
+                if (p.relu && !p.addend) {           // with an addend the ReLU follows the add (below)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
                 if constexpr (ES == 2) {
                     bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
@@ -202,6 +207,10 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                     // out by the BN backward and read back
 #pragma unroll
                     for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) + (((am[u] >> e) & 1u) ? av[u].get(e) : 0.f));
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < PER16; ++e) v.set(e, v.get(e) > 0.f ? v.get(e) : 0.f);
+                    }
                 }
                 if (bnf) {
                     // dx' = dx * ReLU-mask of the producing BN layer; s8 += dx', q8 += dx'*(x - mean)
@@ -902,11 +911,12 @@ int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
 }
 
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
-              float* stats, hipStream_t s) {
+              float* stats, const void* residual, int relu, hipStream_t s) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     GatherParams p = {};
     p.src = x; p.wpk = w_fwd; p.dst = y; p.bias = bias; p.stats = stats;
+    p.addend = residual; p.relu = relu;
     p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cin;
     p.OH = Ho; p.OW = Wo; p.FH = Ho; p.FW = Wo; p.Nout = d->Cout;
     p.sm_h = d->stride_h; p.sm_w = d->stride_w;

@@ -66,6 +66,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                                          bool(relu), partial, link, rec)
             if rec is not None and rec.x is not None:
                 y._cnk_bn = rec
+            self._stats_epoch = getattr(self, '_stats_epoch', 0) + 1     # running statistics changed
             if self._deferred_counter is not None:
                 self._deferred_counter[0] += 1        # flushed for all BN layers at once by the model
             else:
@@ -159,6 +160,15 @@ class ConvBlock(nn.Sequential):
                 y, partial = conv(x, want_bn_partial=True, link=in_link)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
                           link=res_link)
+            if not torch.is_grad_enabled():
+                # inference: BN folded into the conv, ReLU / residual add in its epilogue (one kernel)
+                fold = self.__dict__.setdefault('_fold', ops.FoldedConv())
+                stamp = (ops.weights_epoch(), getattr(bn, '_stats_epoch', 0), id(conv.weight), conv.weight._version,
+                         bn.running_mean._version, bn.running_var._version, bn.weight._version, bn.bias._version)
+                y = fold.run(x, conv.weight, conv.bias, bn, _pair(conv.stride), _pair(conv.padding), residual,
+                             act or relu_after_add, stamp)
+                if y is not None:
+                    return y
             return bn(conv(x), residual=residual, relu=act or relu_after_add)
         y = conv(x, link=in_link)
         if residual is not None:

@@ -769,3 +769,54 @@ class SoftmaxCrossEntropySumFn(torch.autograd.Function):
         if dloss is None or dlogits is None:
             return None, None
         return dlogits * dloss, None
+
+
+# ---- inference: BatchNorm folded into the conv, activation in the conv epilogue -----
+class FoldedConv:
+    """Eval-mode conv2d_block (basemodel.py:999-1015 under model.eval()): the BN affine map of the
+    running statistics is folded into the conv -- w' = w * gamma/sqrt(var+eps) per output channel,
+    bias' = beta - mean*scale (+ conv bias*scale) -- and ReLU / the residual add run in the conv
+    epilogue (cnk_conv2d_fwd_act).  The folded image is cached until the weights or the running
+    statistics change (`stamp`)."""
+
+    def __init__(self):
+        self.stamp = None
+        self.w_img = self.bias = None
+
+    def run(self, x, conv_weight, conv_bias, bn, stride, padding, residual, relu, stamp):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        desc = make_desc(x.shape, conv_weight.shape, stride, padding, _dtype_code(x))
+        if not lib.cnk_conv2d_fwd_act_supported(ctypes.byref(desc)):
+            return None
+        key = (stamp, desc.dtype, x.device)
+        if self.stamp != key:
+            with torch.no_grad():
+                w = conv_weight.detach().float()
+                if bn is not None:
+                    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+                    shift = bn.bias.detach() - bn.running_mean * scale
+                    if conv_bias is not None:
+                        shift = shift + conv_bias.detach() * scale
+                    w = w * scale.view(-1, 1, 1, 1)
+                else:
+                    shift = conv_bias.detach().float() if conv_bias is not None else None
+                w = w.contiguous()
+                self.w_img = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(desc), PASS_FWD),
+                                         dtype=torch.uint8, device=x.device)
+                check(lib.cnk_conv2d_pack_weights(ctypes.byref(desc), _p(w), _p(self.w_img), None, _stream()))
+                self.bias = shift.contiguous() if shift is not None else None
+            self.stamp = key
+        if residual is not None:
+            residual = _nhwc(residual)
+            if residual.dtype != x.dtype:
+                raise ValueError('conv epilogue: residual dtype must match the activations')
+        Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
+        lib.cnk_conv2d_out_hw(ctypes.byref(desc), ctypes.byref(Ho), ctypes.byref(Wo))
+        y = torch.empty((desc.N, desc.Cout, Ho.value, Wo.value), dtype=x.dtype, device=x.device, memory_format=CL)
+        if residual is not None and residual.shape != y.shape:
+            raise ValueError('conv epilogue: residual shape %s != output shape %s' % (tuple(residual.shape), tuple(y.shape)))
+        check(lib.cnk_conv2d_fwd_act(ctypes.byref(desc), _p(x), _p(self.w_img), _p(self.bias), _p(residual),
+                                     int(relu), _p(y), _stream()))
+        return y

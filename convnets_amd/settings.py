@@ -29,7 +29,8 @@ class Settings:
     DEF = dict(batch_size=256, batch_norm=True, epochs=50, learning_rate=0.01, lr_factor=0.1,
                lr_patience=10, weight_decay=1e-4, dropout_rate=0.5, loss_optim=False,
                grad_clip_norm=False, gc_max_norm=1, grad_clip_value=False, gc_value=1,
-               init_params=True, sanity_check=False, debug=False, mixed_precision=True, seed=21)
+               init_params=True, sanity_check=False, debug=False, mixed_precision=True, seed=21,
+               test_sample_size=90)
 
     def __init__(self, kind, input_size, num_classes, device=None, **kwargs):
         self.kind = kind

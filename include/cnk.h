@@ -90,6 +90,16 @@ int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d);
 int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
                    void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Inference forward with the layer's whole epilogue in the conv kernel:
+ *     y = act( conv(x, w) + bias [+ residual] ),  act = ReLU when relu != 0.
+ * With BatchNorm folded into w and bias (w' = w * gamma/sqrt(var+eps), bias' = beta - mean*scale) this is
+ * conv2d_block in eval mode (valid_model / test(), basemodel.py:304-346, 601-722) and, with the
+ * residual operand, the tail of a ResNet block (resnet.py:151-154,191-194) -- one kernel, no BN pass.
+ * residual (may be NULL) is shaped like y.  Implicit-GEMM shapes only: query _supported first. */
+int cnk_conv2d_fwd_act_supported(const cnk_conv_desc* d);
+int cnk_conv2d_fwd_act(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                       const void* residual, int relu, void* y, void* stream);
+
 /* dx = conv2d_transpose(dy, w) [+ addend]: autograd's input gradient of the call above
  * (loss.backward(), basemodel.py:258/278).  `addend` (may be NULL; shaped like dx) is the
  * gradient arriving at the same tensor through another branch -- the identity / projection

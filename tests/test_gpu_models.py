@@ -328,3 +328,29 @@ def test_batched_weight_pack_matches_per_conv_pack():
     sd = model.state_dict()
     nbt = [int(v) for k, v in sd.items() if k.endswith('num_batches_tracked')]
     assert nbt and all(v == 4 for v in nbt)
+
+
+def test_reference_test_measurement():
+    """test() (basemodel.py:601-722): eval mode, warm-up, per-batch device timing, the reference's
+    fps arithmetic, subset accuracies; predictions equal those of a plain eval forward."""
+    import convnets_amd as ca
+    torch.manual_seed(21)
+    s = ca.Settings(kind=26, input_size=(3, 32, 32), num_classes=10, batch_size=32, dropout_rate=0,
+                    mixed_precision=True, test_sample_size=3)
+    model = ca.MODELS['resnet'](s).cuda()
+    model.init_optimizer()
+    g = torch.Generator().manual_seed(1)
+    xs, ys = torch.randn(96, 3, 32, 32, generator=g), torch.randint(0, 10, (96,), generator=g)
+    model.train_batch((xs[:32], ys[:32]))           # non-trivial running statistics
+
+    class Loader(list):
+        dataset = range(96)
+    loader = Loader([(xs[i:i + 32], ys[i:i + 32]) for i in range(0, 96, 32)])
+    scores, times, fps = model.test(loader, repetitions=3)
+    assert len(times) == 3 and all(t > 0 for t in times) and len(scores) == 3
+    assert abs(fps - 96 / sum(times)) < 1e-9
+    model.eval()
+    with torch.no_grad():
+        pred = torch.cat([model(xb.cuda()).argmax(dim=1).cpu() for xb, _ in loader])
+    acc = [float((pred[i:i + 32] == ys[i:i + 32]).float().mean()) for i in range(0, 96, 32)]
+    assert np.allclose(scores, acc)

@@ -470,3 +470,49 @@ def test_dropout_statistics_and_backward():
     torch.manual_seed(5)
     d.eval()
     assert d(x) is x
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [(64, 64, 3, 1, 1, True, False), (64, 128, 3, 2, 1, True, False),
+                                 (128, 256, 1, 1, 0, True, True), (256, 64, 1, 2, 0, False, False)],
+                         ids=['k3s1', 'k3s2', 'k1-res', 'k1s2-noact'])
+def test_eval_conv_block_folds_bn_into_conv(cfg, dtype):
+    """Eval-mode conv2d_block (+ the residual tail of a ResNet block): BN folded into the conv, ReLU /
+    add in the conv epilogue (cnk_conv2d_fwd_act) against the unfused definition in fp64."""
+    from convnets_amd import layers
+    Cin, Cout, k, s, p, act, with_res = cfg
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    blk = layers.ConvBlock(layers.Conv2d(Cin, Cout, kernel_size=k, stride=s, padding=p, bias=False),
+                           layers.BatchNorm2d(Cout), *([layers.ReLU(inplace=True)] if act else [])).cuda()
+    with torch.no_grad():
+        blk[0].weight.copy_(torch.randn(Cout, Cin, k, k, generator=g) * 0.05)
+        blk[1].weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        blk[1].bias.copy_(torch.randn(Cout, generator=g) * 0.2)
+        blk[1].running_mean.copy_(torch.randn(Cout, generator=g) * 0.3)
+        blk[1].running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    blk.eval()
+    x = torch.randn(5, Cin, 14, 14, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    Ho = (14 + 2 * p - k) // s + 1
+    res = torch.randn(5, Cout, Ho, Ho, generator=g) if with_res else None
+    if res is not None and dtype == torch.bfloat16:
+        res = res.bfloat16().float()
+    with torch.no_grad():
+        y = blk(dev(x.numpy(), dtype), residual=None if res is None else dev(res.numpy(), dtype), relu_after_add=with_res)
+        assert blk.__dict__.get('_fold') is not None and blk._fold.stamp is not None, 'folded path did not run'
+        z = F.conv2d(x.double(), blk[0].weight.detach().double().cpu(), None, s, p)
+        z = F.batch_norm(z, blk[1].running_mean.double().cpu(), blk[1].running_var.double().cpu(),
+                         blk[1].weight.detach().double().cpu(), blk[1].bias.detach().double().cpu(), False, 0.1, 1e-5)
+        if res is not None:
+            z = z + res.double()
+        if act or with_res:
+            z = torch.relu(z)
+    assert rel_l2(host(y), z.numpy()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # a training forward moves the running statistics: the folded image must be rebuilt
+    blk.train()
+    blk(dev(x.numpy(), dtype), residual=None if res is None else dev(res.numpy(), dtype), relu_after_add=with_res)
+    blk.eval()
+    with torch.no_grad():
+        y2 = blk(dev(x.numpy(), dtype), residual=None if res is None else dev(res.numpy(), dtype), relu_after_add=with_res)
+    assert rel_l2(host(y2), host(y)) > 1e-4
