@@ -17,7 +17,7 @@
 #include "common.h"
 
 #ifndef CNK_ABLATE
-#define CNK_ABLATE 0      // debug builds only (tools/ablate.sh): 1 no MFMA phase, 2 no global loads, 4 no LDS reads
+#define CNK_ABLATE 0      // debug builds only (tools/ablate.sh): 1 no MFMA phase, 2 no global loads, 4 no LDS reads, 16 no tap masks
 #endif
 namespace {
 
@@ -600,8 +600,12 @@ __global__ __launch_bounds__(256, 3) void igemm_halo3x3_kernel(const GatherParam
 #else
                     u32x4 v = *(const u32x4*)(Ps + j * 128 + swz(j, 2 * s + lh));
 #endif
+#if (CNK_ABLATE & 16)
+                    fa[i] = v;
+#else
                     const bool ok = (vm[i] >> t) & 1u;
                     fa[i] = ok ? v : u32x4{0, 0, 0, 0};
+#endif
                 }
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn) {
