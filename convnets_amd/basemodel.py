@@ -256,8 +256,17 @@ class MultiClassBaseModel(nn.Module):
         return layer
 
     def conv2d_depthwise(self, in_channels=None, num_filters=None, set_output=True, **kwargs):
-        raise NotImplementedError('conv2d_depthwise (basemodel.py:981-997) is outside the hot path: '
-                                  'LeNet/AlexNet/VGG/ResNet use groups=1 (SURVEY.md section 8f, n4)')
+        """basemodel.py:981-997: nn.Conv2d(in, filters, groups=in): the depthwise kernels need
+        filters == in (channel multiplier 1, as every caller in the reference uses it)."""
+        if in_channels is None:
+            in_channels = self.in_channels
+        if num_filters is None:
+            num_filters = self.in_channels
+        layer = layers.Conv2d(in_channels, num_filters, groups=in_channels, **kwargs,
+                              bias=not self.setting.batch_norm)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
 
     def conv2d_block(self, in_channels=None, num_filters=None, set_output=True, activation=True,
                      **kwargs):

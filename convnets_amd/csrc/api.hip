@@ -14,6 +14,11 @@ int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const fl
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
+bool dwconv_supported(const cnk_conv_desc* d);
+int dwconv_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y, hipStream_t s);
+int dwconv_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, void* dx, hipStream_t s);
+size_t dwconv_wgrad_workspace(const cnk_conv_desc* d);
+int dwconv_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, float* ws, hipStream_t s);
 size_t linear_workspace(int pass, int B, int K, int N);
 int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, float* ws, size_t ws_bytes, hipStream_t s);
 int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, float* ws, size_t ws_bytes, hipStream_t s);
@@ -411,6 +416,50 @@ int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     CNK_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "cnk_adam_step: bad arguments");
     CNK_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "cnk_adam_step: arenas must be 16-byte aligned");
     return adam_dispatch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
+
+int cnk_dwconv2d_supported(const cnk_conv_desc* d) {
+    return check_desc(d, "cnk_dwconv2d_supported") == 0 && dwconv_supported(d);
+}
+
+static size_t dw_ws(const cnk_conv_desc* d) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    size_t a = dwconv_wgrad_workspace(d), c = colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout);
+    return a > c ? a : c;
+}
+
+size_t cnk_dwconv2d_workspace_bytes(const cnk_conv_desc* d) {
+    if (check_desc(d, "cnk_dwconv2d_workspace_bytes") || !dwconv_supported(d)) return 0;
+    return dw_ws(d);
+}
+
+int cnk_dwconv2d_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* stream) {
+    if (int rc = check_desc(d, "cnk_dwconv2d_fwd")) return rc;
+    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_fwd: needs Cin == Cout, C %% 8 (bf16) / 4 (fp32) == 0, kh*kw <= 25");
+    CNK_CHECK_ARG(x && w && y, "cnk_dwconv2d_fwd: null pointer");
+    return dwconv_fwd(d, x, w, bias, y, S(stream));
+}
+
+int cnk_dwconv2d_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, void* dx, void* stream) {
+    if (int rc = check_desc(d, "cnk_dwconv2d_dgrad")) return rc;
+    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_dgrad: needs Cin == Cout, C %% 8 (bf16) / 4 (fp32) == 0, kh*kw <= 25");
+    CNK_CHECK_ARG(dy && w && dx, "cnk_dwconv2d_dgrad: null pointer");
+    return dwconv_dgrad(d, dy, w, dx, S(stream));
+}
+
+int cnk_dwconv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d, "cnk_dwconv2d_wgrad")) return rc;
+    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_wgrad: needs Cin == Cout, C %% 8 (bf16) / 4 (fp32) == 0, kh*kw <= 25");
+    CNK_CHECK_ARG(dy && x && dw, "cnk_dwconv2d_wgrad: null pointer");
+    CNK_CHECK_ARG(workspace && workspace_bytes >= dw_ws(d), "cnk_dwconv2d_wgrad: workspace too small");
+    if (int rc = dwconv_wgrad(d, dy, x, dw, accumulate, (float*)workspace, S(stream))) return rc;
+    if (dbias) {
+        int Ho, Wo;
+        cnk_conv2d_out_hw(d, &Ho, &Wo);
+        return colsum(dy, dbias, (int64_t)d->N * Ho * Wo, d->Cout, d->dtype, accumulate, workspace, workspace_bytes, S(stream));
+    }
+    return 0;
 }
 
 size_t cnk_linear_workspace_bytes(int pass, int32_t B, int32_t K, int32_t N) {

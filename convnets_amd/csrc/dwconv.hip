@@ -1,0 +1,341 @@
+// Depthwise convolution (groups == Cin == Cout, channel multiplier 1) on NHWC activations:
+// conv2d_depthwise of the reference's layer factory (src/basemodel.py:981-997), the spatial half of
+// MobileNet-v1's Conv2dBlockDW (src/mobilenet_v1.py:92-125).  SURVEY.md 8f n4.
+//
+// There is no reduction over channels, so this is HBM-bound vector work, not a GEMM: a thread owns
+// one 16-byte channel vector (8 bf16 / 4 fp32 channels) with its taps' weights in registers and
+// walks a strip of pixels; lanes run along C, so every load and store is a coalesced row segment.
+//   forward   y[m][c]   = sum_t x[pix(m,t)][c] * w[c][t]  (+ bias[c])
+//   dgrad     dx[p][c]  = sum_t dy[opix(p,t)][c] * w[c][t]      (positions that divide by the stride)
+//   wgrad     dw[c][t]  = sum_m dy[m][c] * x[pix(m,t)][c]       per-slice partials, fixed-order sum
+// Weights are read from the fp32 master tensor [C][1][kh][kw] directly (no packed image).
+#include "common.h"
+
+namespace {
+
+constexpr int DW_MAX_TAPS = 25;
+
+struct DwParams {
+    const void* a;        // fwd: x      dgrad: dy     wgrad: dy
+    const void* b;        // fwd: -      dgrad: -      wgrad: x
+    const float* w;       // [C][taps]
+    const float* bias;
+    void* out;            // fwd: y      dgrad: dx
+    float* partial;       // wgrad: [slices][taps][C]
+    int N, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw;
+    int cols, cpb, rpb;   // vector columns, columns / rows per block
+    int64_t M;            // pixels walked (fwd/wgrad: N*Ho*Wo, dgrad: N*H*W)
+    int64_t slice;        // pixels per block
+    FastDiv fd_hw, fd_w;  // decomposition of the walked pixel index
+};
+
+template <typename T, int VEC> struct RawV {
+    using V = decltype(Vec16<T>::v);
+    V v;
+    __device__ __forceinline__ void load(const T* p) { v = *(const V*)p; }
+    __device__ __forceinline__ void store(T* p) const { *(V*)p = v; }
+    __device__ __forceinline__ float get(int i) const { return to_f32(v[i]); }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = from_f32<T>(f); }
+};
+
+// TAPS > 0: compile-time tap count with the weights in registers (3x3: 9); TAPS == 0: run-time
+template <typename T, int TAPS, bool DGRAD>
+__global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
+    constexpr int VEC = ElemTraits<T>::PER16;
+    const int tid = threadIdx.x, tcol = tid % p.cpb, trow = tid / p.cpb;
+    const int vcol = blockIdx.y * p.cpb + tcol;
+    if (trow >= p.rpb || vcol >= p.cols) return;
+    const int c0 = vcol * VEC;
+    const int ntaps = TAPS > 0 ? TAPS : p.kh * p.kw;
+    float wr[TAPS > 0 ? TAPS : 1][VEC];
+    if constexpr (TAPS > 0) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) wr[t][e] = p.w[(size_t)(c0 + e) * TAPS + t];
+    }
+    float bs[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) bs[e] = (!DGRAD && p.bias) ? p.bias[c0 + e] : 0.f;
+    const T* src = (const T*)p.a;
+    T* dst = (T*)p.out;
+    const int64_t m0 = (int64_t)blockIdx.x * p.slice;
+    const int64_t m1 = m0 + p.slice < p.M ? m0 + p.slice : p.M;
+    const int SH = DGRAD ? p.Ho : p.H, SW = DGRAD ? p.Wo : p.W;     // source grid
+    for (int64_t m = m0 + trow; m < m1; m += p.rpb) {
+        const uint32_t img = fd_div((uint32_t)m, p.fd_hw), rem = (uint32_t)m - img * p.fd_hw.d;
+        const int oh = (int)fd_div(rem, p.fd_w), ow = (int)(rem - (uint32_t)oh * p.fd_w.d);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = bs[e];
+        auto tap = [&](int t, int r, int q) {
+            int ih, iw;
+            bool ok;
+            if constexpr (DGRAD) {
+                const int th = oh + p.ph - r, tw = ow + p.pw - q;
+                ok = th >= 0 && tw >= 0 && th % p.sh == 0 && tw % p.sw == 0;
+                ih = th / p.sh; iw = tw / p.sw;
+            } else {
+                ih = oh * p.sh - p.ph + r; iw = ow * p.sw - p.pw + q;
+                ok = true;
+            }
+            if (ok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW) {
+                RawV<T, VEC> v;
+                v.load(src + ((size_t)(img * SH + ih) * SW + iw) * p.C + c0);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float wv = TAPS > 0 ? wr[TAPS > 0 ? t : 0][e] : p.w[(size_t)(c0 + e) * ntaps + t];
+                    acc[e] += v.get(e) * wv;
+                }
+            }
+        };
+        if constexpr (TAPS == 9) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) tap(t, t / 3, t % 3);
+        } else {
+            for (int r = 0, t = 0; r < p.kh; ++r)
+                for (int q = 0; q < p.kw; ++q, ++t) tap(t, r, q);
+        }
+        RawV<T, VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+        o.store(dst + (size_t)m * p.C + c0);
+    }
+}
+
+// wgrad partials: thread (column, row-thread) accumulates dy*x for its pixels and taps, rows of a
+// block are summed through LDS in fixed order -> partial[blockIdx.x][t][c]
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwParams p) {
+    constexpr int VEC = ElemTraits<T>::PER16;
+    extern __shared__ float sh[];                       // [256][VEC]
+    const int tid = threadIdx.x, tcol = tid % p.cpb, trow = tid / p.cpb;
+    const int vcol = blockIdx.y * p.cpb + tcol;
+    const bool active = trow < p.rpb && vcol < p.cols;
+    const int c0 = vcol * VEC;
+    float acc[TAPS][VEC];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    const T* dy = (const T*)p.a;
+    const T* x = (const T*)p.b;
+    const int64_t m0 = (int64_t)blockIdx.x * p.slice;
+    const int64_t m1 = m0 + p.slice < p.M ? m0 + p.slice : p.M;
+    if (active) {
+        for (int64_t m = m0 + trow; m < m1; m += p.rpb) {
+            const uint32_t img = fd_div((uint32_t)m, p.fd_hw), rem = (uint32_t)m - img * p.fd_hw.d;
+            const int oh = (int)fd_div(rem, p.fd_w), ow = (int)(rem - (uint32_t)oh * p.fd_w.d);
+            RawV<T, VEC> d;
+            d.load(dy + (size_t)m * p.C + c0);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int r = t / p.kw, q = t - r * p.kw;
+                const int ih = oh * p.sh - p.ph + r, iw = ow * p.sw - p.pw + q;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+                    RawV<T, VEC> v;
+                    v.load(x + ((size_t)(img * p.H + ih) * p.W + iw) * p.C + c0);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[t][e] += d.get(e) * v.get(e);
+                }
+            }
+        }
+    }
+    int span = 1;
+    while (span < p.rpb) span <<= 1;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh[tid * VEC + e] = acc[t][e];
+        __syncthreads();
+        for (int st = span >> 1; st >= 1; st >>= 1) {
+            if (trow < st && trow + st < p.rpb && vcol < p.cols) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sh[tid * VEC + e] += sh[(tid + st * p.cpb) * VEC + e];
+            }
+            __syncthreads();
+        }
+        if (trow == 0 && vcol < p.cols) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                p.partial[((size_t)blockIdx.x * TAPS + t) * p.C + c0 + e] = sh[tid * VEC + e];
+        }
+        __syncthreads();
+    }
+}
+
+// generic tap count: one launch per tap with TAPS == 1 semantics is avoided by looping taps here
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_generic_kernel(const DwParams p) {
+    constexpr int VEC = ElemTraits<T>::PER16;
+    extern __shared__ float sh[];
+    const int tid = threadIdx.x, tcol = tid % p.cpb, trow = tid / p.cpb;
+    const int vcol = blockIdx.y * p.cpb + tcol;
+    const bool active = trow < p.rpb && vcol < p.cols;
+    const int c0 = vcol * VEC, ntaps = p.kh * p.kw;
+    const T* dy = (const T*)p.a;
+    const T* x = (const T*)p.b;
+    const int64_t m0 = (int64_t)blockIdx.x * p.slice;
+    const int64_t m1 = m0 + p.slice < p.M ? m0 + p.slice : p.M;
+    int span = 1;
+    while (span < p.rpb) span <<= 1;
+    for (int t = 0; t < ntaps; ++t) {
+        const int r = t / p.kw, q = t - r * p.kw;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        if (active) {
+            for (int64_t m = m0 + trow; m < m1; m += p.rpb) {
+                const uint32_t img = fd_div((uint32_t)m, p.fd_hw), rem = (uint32_t)m - img * p.fd_hw.d;
+                const int oh = (int)fd_div(rem, p.fd_w), ow = (int)(rem - (uint32_t)oh * p.fd_w.d);
+                const int ih = oh * p.sh - p.ph + r, iw = ow * p.sw - p.pw + q;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+                    RawV<T, VEC> d, v;
+                    d.load(dy + (size_t)m * p.C + c0);
+                    v.load(x + ((size_t)(img * p.H + ih) * p.W + iw) * p.C + c0);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += d.get(e) * v.get(e);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh[tid * VEC + e] = acc[e];
+        __syncthreads();
+        for (int st = span >> 1; st >= 1; st >>= 1) {
+            if (trow < st && trow + st < p.rpb && vcol < p.cols) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sh[tid * VEC + e] += sh[(tid + st * p.cpb) * VEC + e];
+            }
+            __syncthreads();
+        }
+        if (trow == 0 && vcol < p.cols) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                p.partial[((size_t)blockIdx.x * ntaps + t) * p.C + c0 + e] = sh[tid * VEC + e];
+        }
+        __syncthreads();
+    }
+}
+
+// dw[c][t] (+)= sum_slices partial[s][t][c], fixed order
+__global__ __launch_bounds__(256) void dwconv_wgrad_sum_kernel(const float* __restrict__ partial, int slices, int taps, int C,
+                                                               float* __restrict__ dw, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over taps*C, c fastest (coalesced reads)
+    if (i >= taps * C) return;
+    const int t = i / C, c = i - t * C;
+    float a0 = 0.f, a1 = 0.f;
+    int s = 0;
+    for (; s + 1 < slices; s += 2) {
+        a0 += partial[((size_t)s * taps + t) * C + c];
+        a1 += partial[((size_t)(s + 1) * taps + t) * C + c];
+    }
+    if (s < slices) a0 += partial[((size_t)s * taps + t) * C + c];
+    float* o = dw + (size_t)c * taps + t;
+    *o = accumulate ? *o + (a0 + a1) : (a0 + a1);
+}
+
+int dw_vec(int dtype) { return dtype == CNK_BF16 ? 8 : 4; }
+
+void dw_geom(DwParams& p, int64_t M, int C, int vec, int target_blocks) {
+    p.cols = C / vec;
+    p.cpb = p.cols < 32 ? p.cols : 32;
+    p.rpb = 256 / p.cpb;
+    int colgroups = ceil_div(p.cols, p.cpb);
+    int64_t want = target_blocks / colgroups;
+    if (want < 1) want = 1;
+    int64_t sl = ceil_div64(M, want);
+    int64_t per = ceil_div64(sl, p.rpb);
+    if (per < 4) per = 4;
+    p.slice = per * p.rpb;
+    p.M = M;
+}
+
+}  // namespace
+
+bool dwconv_supported(const cnk_conv_desc* d) {
+    return d->Cin == d->Cout && d->Cin % dw_vec(d->dtype) == 0 && d->kh * d->kw <= DW_MAX_TAPS;
+}
+
+static DwParams dw_params(const cnk_conv_desc* d) {
+    DwParams p = {};
+    cnk_conv2d_out_hw(d, &p.Ho, &p.Wo);
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.kh = d->kh; p.kw = d->kw;
+    p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+    return p;
+}
+
+int dwconv_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y, hipStream_t s) {
+    DwParams p = dw_params(d);
+    p.a = x; p.w = w; p.bias = bias; p.out = y;
+    dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, dw_vec(d->dtype), 4096);
+    if (p.M == 0) return 0;
+    p.fd_hw = make_fastdiv(p.Ho * p.Wo);
+    p.fd_w = make_fastdiv(p.Wo);
+    dim3 grid((unsigned)ceil_div64(p.M, p.slice), ceil_div(p.cols, p.cpb));
+    const bool k3 = d->kh == 3 && d->kw == 3;
+    if (d->dtype == CNK_BF16) {
+        if (k3) hipLaunchKernelGGL((dwconv_kernel<bf16, 9, false>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_kernel<bf16, 0, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (k3) hipLaunchKernelGGL((dwconv_kernel<float, 9, false>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_kernel<float, 0, false>), grid, dim3(256), 0, s, p);
+    }
+    CNK_CHECK_LAUNCH("dwconv_fwd");
+    return 0;
+}
+
+int dwconv_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, void* dx, hipStream_t s) {
+    DwParams p = dw_params(d);
+    p.a = dy; p.w = w; p.out = dx;
+    dw_geom(p, (int64_t)d->N * d->H * d->W, d->Cin, dw_vec(d->dtype), 4096);
+    if (p.M == 0) return 0;
+    p.fd_hw = make_fastdiv(d->H * d->W);
+    p.fd_w = make_fastdiv(d->W);
+    dim3 grid((unsigned)ceil_div64(p.M, p.slice), ceil_div(p.cols, p.cpb));
+    const bool k3 = d->kh == 3 && d->kw == 3;
+    if (d->dtype == CNK_BF16) {
+        if (k3) hipLaunchKernelGGL((dwconv_kernel<bf16, 9, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_kernel<bf16, 0, true>), grid, dim3(256), 0, s, p);
+    } else {
+        if (k3) hipLaunchKernelGGL((dwconv_kernel<float, 9, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dwconv_kernel<float, 0, true>), grid, dim3(256), 0, s, p);
+    }
+    CNK_CHECK_LAUNCH("dwconv_dgrad");
+    return 0;
+}
+
+static int dw_wgrad_blocks() { return 1024; }
+
+size_t dwconv_wgrad_workspace(const cnk_conv_desc* d) {
+    DwParams p = dw_params(d);
+    dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, dw_vec(d->dtype), dw_wgrad_blocks());
+    size_t slices = (size_t)ceil_div64(p.M > 0 ? p.M : 1, p.slice);
+    return slices * d->kh * d->kw * d->Cin * sizeof(float);
+}
+
+int dwconv_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, float* ws,
+                 hipStream_t s) {
+    DwParams p = dw_params(d);
+    p.a = dy; p.b = x; p.partial = ws;
+    const int vec = dw_vec(d->dtype), taps = d->kh * d->kw;
+    dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, vec, dw_wgrad_blocks());
+    if (p.M == 0) return 0;
+    p.fd_hw = make_fastdiv(p.Ho * p.Wo);
+    p.fd_w = make_fastdiv(p.Wo);
+    const int slices = (int)ceil_div64(p.M, p.slice);
+    dim3 grid(slices, ceil_div(p.cols, p.cpb));
+    const size_t lds = 256 * vec * sizeof(float);
+    const bool k3 = d->kh == 3 && d->kw == 3;
+    if (d->dtype == CNK_BF16) {
+        if (k3) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16, 9>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((dwconv_wgrad_generic_kernel<bf16>), grid, dim3(256), lds, s, p);
+    } else {
+        if (k3) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, 9>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((dwconv_wgrad_generic_kernel<float>), grid, dim3(256), lds, s, p);
+    }
+    CNK_CHECK_LAUNCH("dwconv_wgrad");
+    hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3(ceil_div(taps * d->Cin, 256)), dim3(256), 0, s, ws, slices, taps,
+                       d->Cin, dw, accumulate);
+    CNK_CHECK_LAUNCH("dwconv_wgrad_sum");
+    return 0;
+}

@@ -18,15 +18,16 @@ def _pair(v):
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d with the MI355X implicit-GEMM forward/dgrad/wgrad (groups=1, dilation=1, zeros
-    padding -- everything the hot path's models use; anything else is refused loudly)."""
+    """nn.Conv2d with the MI355X implicit-GEMM forward/dgrad/wgrad (groups=1) or the depthwise
+    kernels (groups == channels); dilation=1, zeros padding -- anything else is refused loudly."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if self.groups != 1 or _pair(self.dilation) != (1, 1) or self.padding_mode != 'zeros' \
-                or isinstance(self.padding, str):
-            raise NotImplementedError('convnets_amd.Conv2d: groups/dilation/padding_mode outside the '
-                                      'hot path (groups=1, dilation=1, zeros) are not implemented')
+        self._depthwise = self.groups > 1 and self.groups == self.in_channels == self.out_channels
+        if (self.groups != 1 and not self._depthwise) or _pair(self.dilation) != (1, 1) \
+                or self.padding_mode != 'zeros' or isinstance(self.padding, str):
+            raise NotImplementedError('convnets_amd.Conv2d: only groups=1 or depthwise (groups == in == out '
+                                      'channels), dilation=1, zeros padding are implemented')
         self._packed = ops.PackedWeights()
 
     def __deepcopy__(self, memo):
@@ -40,6 +41,9 @@ class Conv2d(nn.Conv2d):
         return new
 
     def forward(self, x, want_bn_partial=False, link=None):
+        if self._depthwise:                      # conv2d_depthwise (basemodel.py:981-997)
+            y = ops.DepthwiseConv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
+            return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
         # x._cnk_bn: set when x is the output of a training-mode BatchNorm2d of this package (ops.BnRecord)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
                                   self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None))
@@ -189,3 +193,41 @@ class Conv2dBlock(ConvBlock):
             self.add_module('bn', BatchNorm2d(num_features=num_filters))
         if activation:
             self.add_module('relu', ReLU(inplace=True))
+
+
+class Conv2dBlockDW(nn.Sequential):
+    """MobileNet-v1's depthwise-separable block (src/mobilenet_v1.py:92-125), same child names
+    (conv_dw, bn_dw, relu_dw, conv_pw, bn_pw, relu_pw => same state_dict keys): depthwise 3x3 ->
+    [BN] -> [ReLU] -> pointwise 1x1 -> [BN] -> [ReLU], each BN+ReLU pair one fused kernel pass and the
+    pointwise conv's dgrad epilogue carrying the depthwise BN's backward reduction."""
+
+    def __init__(self, network, in_channels=None, num_filters=None, set_output=True, activation=True,
+                 **kwargs):
+        super().__init__()
+        self.add_module('conv_dw', network.conv2d_depthwise(in_channels, in_channels, set_output, **kwargs))
+        if network.setting.batch_norm:
+            if in_channels is None:
+                in_channels = network.in_channels
+            self.add_module('bn_dw', BatchNorm2d(num_features=in_channels))
+        if activation:
+            self.add_module('relu_dw', ReLU(inplace=True))
+        self.add_module('conv_pw', network.conv2d(in_channels, num_filters, set_output, kernel_size=1))
+        if network.setting.batch_norm:
+            self.add_module('bn_pw', BatchNorm2d(num_features=num_filters))
+        if activation:
+            self.add_module('relu_pw', ReLU(inplace=True))
+
+    def forward(self, x):
+        act = hasattr(self, 'relu_dw')
+        y = self.conv_dw(x)
+        if hasattr(self, 'bn_dw'):
+            y = self.bn_dw(y, relu=act)
+        elif act:
+            y = ops.ReLUFn.apply(y)
+        if hasattr(self, 'bn_pw'):
+            if self.bn_pw.training:
+                y, partial = self.conv_pw(y, want_bn_partial=True)
+                return self.bn_pw(y, relu=act, partial=partial)
+            return self.bn_pw(self.conv_pw(y), relu=act)
+        y = self.conv_pw(y)
+        return ops.ReLUFn.apply(y) if act else y

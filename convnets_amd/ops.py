@@ -820,3 +820,58 @@ class FoldedConv:
         check(lib.cnk_conv2d_fwd_act(ctypes.byref(desc), _p(x), _p(self.w_img), _p(self.bias), _p(residual),
                                      int(relu), _p(y), _stream()))
         return y
+
+
+# ---- depthwise convolution ---------------------------------------------------------
+class DepthwiseConv2dFn(torch.autograd.Function):
+    """nn.Conv2d(C, C, groups=C) -- conv2d_depthwise (basemodel.py:981-997) -- on csrc/dwconv.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        C = x.shape[1]
+        if w.shape[0] != C or w.shape[1] != 1:
+            raise ValueError('depthwise conv: weight %s does not match %d input channels' % (tuple(w.shape), C))
+        desc = make_desc(x.shape, (C, C, w.shape[2], w.shape[3]), stride, padding, _dtype_code(x))
+        if not lib.cnk_dwconv2d_supported(ctypes.byref(desc)):
+            raise NotImplementedError('depthwise conv: C must be a multiple of %d and kh*kw <= 25 (got C=%d, %dx%d)'
+                                      % (8 if x.dtype == torch.bfloat16 else 4, C, w.shape[2], w.shape[3]))
+        Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
+        lib.cnk_conv2d_out_hw(ctypes.byref(desc), ctypes.byref(Ho), ctypes.byref(Wo))
+        y = torch.empty((desc.N, C, Ho.value, Wo.value), dtype=x.dtype, device=x.device, memory_format=CL)
+        check(lib.cnk_dwconv2d_fwd(ctypes.byref(desc), _p(x), _p(w), _p(bias), _p(y), _stream()))
+        ctx.save_for_backward(x, w)
+        ctx.desc, ctx.params = desc, (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        weight, bias = ctx.params
+        desc = ctx.desc
+        dy = _nhwc(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=CL)
+            check(lib.cnk_dwconv2d_dgrad(ctypes.byref(desc), _p(dy), _p(w), _p(dx), _stream()))
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            gw = _arena_grad(weight) if weight.is_contiguous() else None
+            gb = _arena_grad(bias) if bias is not None else None
+            direct = gw is not None and (bias is None or gb is not None)
+            if direct:
+                dw_buf, db_buf = gw, gb
+            else:
+                dw_buf = dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+                db_buf = db = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if bias is not None else None
+            ws = workspace(lib.cnk_dwconv2d_workspace_bytes(ctypes.byref(desc)), x.device)
+            check(lib.cnk_dwconv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf), int(direct),
+                                         _p(ws), ws.numel(), _stream()))
+            if direct:
+                _grad_written(weight)
+                if bias is not None:
+                    _grad_written(bias)
+        return dx, dw, db, None, None

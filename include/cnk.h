@@ -213,6 +213,20 @@ int cnk_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int32_t N, int32_t C, in
 int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
+/* ---- depthwise convolution ------------------------------------------------------
+ * conv2d_depthwise of the layer factory (basemodel.py:981-997): nn.Conv2d(C, C, groups=C, ...), the
+ * spatial half of MobileNet-v1's Conv2dBlockDW (mobilenet_v1.py:92-125).  Same descriptor with
+ * Cin == Cout == C (C % 8 == 0 for bf16, % 4 for fp32; kh*kw <= 25); x/y/dy/dx NHWC in `dtype`;
+ * w is the fp32 MASTER weight [C][1][kh][kw] (no packed image); dw fp32 in the same layout.
+ * wgrad workspace: cnk_dwconv2d_workspace_bytes(d); dbias (may be NULL) = column sums of dy. */
+int cnk_dwconv2d_supported(const cnk_conv_desc* d);
+size_t cnk_dwconv2d_workspace_bytes(const cnk_conv_desc* d);
+int cnk_dwconv2d_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
+                     void* stream);
+int cnk_dwconv2d_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, void* dx, void* stream);
+int cnk_dwconv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                       int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- classifier head -- fp32, row-major, no workspace ---------------------------
  * nn.Linear (resnet.py:106, vggnet.py:83-92): y[B][N] = x[B][K] W[N][K]^T + bias (bias may be NULL);
  * dx[B][K] = dy[B][N] W[N][K]; dW[N][K] (+)= dy^T x, dbias[N] (+)= column sums of dy (dbias may be

@@ -60,8 +60,9 @@ def emulate_bf16(model, round_weights=lambda conv: conv.in_channels % 64 == 0 an
     for m in model.modules():
         if isinstance(m, nn.Conv2d):
             def fwd(x, m=m):
-                w = RoundFwd.apply(m.weight) if round_weights(m) else m.weight
-                return RoundBoth.apply(F.conv2d(x, w, m.bias, m.stride, m.padding))
+                # depthwise kernels read the fp32 master weights directly: never rounded
+                w = RoundFwd.apply(m.weight) if (m.groups == 1 and round_weights(m)) else m.weight
+                return RoundBoth.apply(F.conv2d(x, w, m.bias, m.stride, m.padding, m.dilation, m.groups))
             m.forward = fwd
         elif isinstance(m, nn.BatchNorm2d) and m not in no_round_bn:
             # a BN followed by ReLU is rounded after the ReLU by the HIP kernel; rounding commutes

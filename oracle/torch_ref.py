@@ -110,6 +110,16 @@ class RefBaseModel(nn.Module):
             self.save_conv_outshape(layer)
         return layer
 
+    def conv2d_depthwise(self, in_channels=None, num_filters=None, set_output=True, **kwargs):   # :981-997
+        if in_channels is None:
+            in_channels = self.in_channels
+        if num_filters is None:
+            num_filters = self.in_channels
+        layer = nn.Conv2d(in_channels, num_filters, groups=in_channels, **kwargs, bias=not self.setting.batch_norm)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
+
     def conv2d_block(self, in_channels=None, num_filters=None, set_output=True, activation=True,
                      **kwargs):                                                        # :999-1015
         layers = [self.conv2d(in_channels, num_filters, set_output, **kwargs)]
@@ -324,5 +334,48 @@ def synthetic_batch(batch_size, input_size, num_classes, seed=21):
     return x, y
 
 
+class RefConv2dBlock(nn.Sequential):                               # basemodel.py:1045-1067
+    def __init__(self, network, in_channels=None, num_filters=None, set_output=True, activation=True, **kwargs):
+        super().__init__()
+        self.add_module('conv', network.conv2d(in_channels, num_filters, set_output, **kwargs))
+        if network.setting.batch_norm:
+            self.add_module('bn', nn.BatchNorm2d(num_features=num_filters))
+        if activation:
+            self.add_module('relu', nn.ReLU(inplace=True))
+
+
+class RefConv2dBlockDW(nn.Sequential):                             # mobilenet_v1.py:92-125
+    def __init__(self, network, in_channels=None, num_filters=None, set_output=True, activation=True, **kwargs):
+        super().__init__()
+        self.add_module('conv_dw', network.conv2d_depthwise(in_channels, in_channels, set_output, **kwargs))
+        if network.setting.batch_norm:
+            if in_channels is None:
+                in_channels = network.in_channels
+            self.add_module('bn_dw', nn.BatchNorm2d(num_features=in_channels))
+        if activation:
+            self.add_module('relu_dw', nn.ReLU(inplace=True))
+        self.add_module('conv_pw', network.conv2d(in_channels, num_filters, set_output, kernel_size=1))
+        if network.setting.batch_norm:
+            self.add_module('bn_pw', nn.BatchNorm2d(num_features=num_filters))
+        if activation:
+            self.add_module('relu_pw', nn.ReLU(inplace=True))
+
+
+class RefMobileNetV1(RefBaseModel):                                # mobilenet_v1.py:16-90
+    def __init__(self, setting):
+        super().__init__(setting)
+        cfg = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1), (512, 1), (512, 1),
+               (512, 1), (512, 1), (1024, 2), (1024, 1)]
+        mods = [RefConv2dBlock(self, num_filters=32, kernel_size=3, stride=2, padding=1)]
+        for filters, stride in cfg:
+            mods.append(RefConv2dBlockDW(self, num_filters=filters, kernel_size=3, stride=stride, padding=1))
+        mods.append(self.adapt_avgpool2d(output_size=1))
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
-          'alexnet': RefAlexNet}
+          'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1}

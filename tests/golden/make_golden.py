@@ -38,6 +38,7 @@ def import_reference():
     if REF not in sys.path:
         sys.path.insert(0, REF)
     import basemodel
+    import mobilenet_v1
     import resnet
     import settings
     import vggnet
@@ -48,6 +49,7 @@ def import_reference():
             super().__init__(*a, **k)
 
     basemodel.ReduceLROnPlateau = _RLPCompat
+    basemodel.mobilenet_v1 = mobilenet_v1          # carried along for make_models / make_dwblocks
     return settings, basemodel, resnet, vggnet
 
 
@@ -223,7 +225,8 @@ def make_models(settings, basemodel, resnet, vggnet):
     cases = [('resnet26', resnet.ResNet, 26, (3, 32, 32), True, 16),
              ('resnet18', resnet.ResNet, 18, (3, 32, 32), True, 16),
              ('vgg11', vggnet.VGGNet, 11, (3, 32, 32), True, 16),
-             ('convnet', basemodel.ConvNet, 0, (1, 28, 28), False, 8)]
+             ('convnet', basemodel.ConvNet, 0, (1, 28, 28), False, 8),
+             ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)
@@ -274,9 +277,50 @@ def make_models(settings, basemodel, resnet, vggnet):
     print('models.npz', len(out), 'arrays')
 
 
+def make_dwblocks(settings, basemodel):
+    """Depthwise-separable blocks built by the reference's own factory (mobilenet_v1.Conv2dBlockDW on a
+    MultiClassBaseModel): forward output, input gradient, every parameter gradient, running statistics."""
+    out = meta()
+    DW = basemodel.mobilenet_v1.Conv2dBlockDW
+    for name, C, F_, H, stride, bn in [('dw64s1', 64, 128, 14, 1, True), ('dw128s2', 128, 256, 13, 2, True),
+                                       ('dw32nobn', 32, 64, 9, 1, False)]:
+        s = settings.Settings(kind=0, input_size=(C, H, H), num_classes=10, batch_size=4, batch_norm=bn,
+                              mixed_precision=False, dropout_rate=0, seed=21)
+        net = basemodel.MultiClassBaseModel(s)
+        torch.manual_seed(21)
+        blk = DW(net, num_filters=F_, kernel_size=3, stride=stride, padding=1)
+        net.block = blk
+        net.init_params()
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                if isinstance(m, nn.Conv2d) and m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+        x = torch.randn(4, C, H, H, generator=g).requires_grad_(True)
+        blk.train()
+        y = blk(x)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        out[f'{name}/cfg'] = np.array([C, F_, H, stride, int(bn)])
+        out[f'{name}/x'], out[f'{name}/y'], out[f'{name}/dy'], out[f'{name}/dx'] = \
+            x.detach().numpy(), y.detach().numpy(), dy.numpy(), x.grad.numpy()
+        for k, p in blk.named_parameters():
+            out[f'{name}/param/{k}'] = p.detach().numpy()
+            out[f'{name}/grad/{k}'] = p.grad.numpy()
+        for k, b in blk.named_buffers():
+            if 'running' in k:
+                out[f'{name}/buf/{k}'] = b.numpy()
+    np.savez_compressed(os.path.join(HERE, 'dwblocks.npz'), **out)
+    print('dwblocks.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     settings, basemodel, resnet, vggnet = import_reference()
     make_ops(settings, basemodel)
     make_resblocks(settings, resnet)
     make_models(settings, basemodel, resnet, vggnet)
+    make_dwblocks(settings, basemodel)

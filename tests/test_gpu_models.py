@@ -59,7 +59,8 @@ def test_residual_block_golden(name, mixed):
 
 
 MODEL_CASES = [('resnet26', 'resnet', 26, (3, 32, 32), True), ('resnet18', 'resnet', 18, (3, 32, 32), True),
-               ('vgg11', 'vgg', 11, (3, 32, 32), True), ('convnet', 'convnet', 0, (1, 28, 28), False)]
+               ('vgg11', 'vgg', 11, (3, 32, 32), True), ('convnet', 'convnet', 0, (1, 28, 28), False),
+               ('mobilenet', 'mobilenet', 1, (3, 32, 32), True)]
 
 
 @pytest.mark.parametrize('mixed', [False, True], ids=['f32', 'bf16'])
@@ -87,7 +88,9 @@ def test_model_one_step_golden(name, family, kind, in_size, bn, mixed):
         model(x.cuda())
         model.train()
     out = model(x.cuda())
-    t_out = 2e-4 if not mixed else 2.5e-1   # bf16 vs fp32 is loose by nature; see the emulation test
+    # bf16 vs fp32 is loose by nature (see the emulation test); MobileNet's 27 BN layers at 32x32 / batch 16
+    # end in 1x1 maps normalised over 16 samples, which amplifies bf16 rounding most
+    t_out = 2e-4 if not mixed else (5e-1 if name == 'mobilenet' else 2.5e-1)
     assert rel_l2(host(out), g('logits')) < t_out
     for b in model.buffers():                   # undo the extra forward's running-stat update
         pass
@@ -183,7 +186,7 @@ def _fwd_bwd_cpu(model, x, y):
     return out.detach(), float(loss.detach()), torch.cat([p.grad.reshape(-1).double() for p in model.parameters()])
 
 
-@pytest.mark.parametrize('name,family,kind,in_size,bn', MODEL_CASES[:3])
+@pytest.mark.parametrize('name,family,kind,in_size,bn', MODEL_CASES[:3] + MODEL_CASES[4:5])
 def test_model_bf16_vs_bf16_emulated_oracle(name, family, kind, in_size, bn):
     """Whole-network bf16 check against the oracle instrumented to round to bf16 at the same
     points as the kernels (oracle/bf16_emu.py).  A randomly initialised deep BN network amplifies

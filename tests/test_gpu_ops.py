@@ -516,3 +516,76 @@ def test_eval_conv_block_folds_bn_into_conv(cfg, dtype):
     with torch.no_grad():
         y2 = blk(dev(x.numpy(), dtype), residual=None if res is None else dev(res.numpy(), dtype), relu_after_add=with_res)
     assert rel_l2(host(y2), host(y)) > 1e-4
+
+
+DWB = np.load(os.path.join(G, 'dwblocks.npz'))
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [(64, 3, 1, 1, 14, 14), (128, 3, 2, 1, 13, 11), (32, 5, 1, 2, 9, 9), (8, 3, 2, 0, 7, 8),
+                                 (256, 3, 1, 1, 56, 56)], ids=lambda c: 'C%d-k%d-s%d-p%d-%dx%d' % c)
+@pytest.mark.parametrize('bias', [False, True], ids=['nobias', 'bias'])
+def test_depthwise_conv_vs_torch(cfg, bias, dtype):
+    """conv2d_depthwise (basemodel.py:981-997): forward, dx, dw, dbias against torch fp64 on the host."""
+    from convnets_amd import layers
+    C, k, s, p, H, W = cfg
+    N = 3 if H < 50 else 2
+    g = torch.Generator().manual_seed(C + k + s + H)
+    x, w = torch.randn(N, C, H, W, generator=g), torch.randn(C, 1, k, k, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.1 if bias else None
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    conv = layers.Conv2d(C, C, kernel_size=k, stride=s, padding=p, groups=C, bias=bias).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        if bias:
+            conv.bias.copy_(b)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, s, p, 1, C)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy.double())
+    xt = dev(x.numpy(), dtype).requires_grad_(True)
+    y = conv(xt)
+    y.backward(dev(dy.numpy(), dtype))
+    torch.cuda.synchronize()
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(host(y), yr.detach().numpy()) < t
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < t
+    assert rel_l2(host(conv.weight.grad), wr.grad.numpy()) < (2e-5 if dtype == torch.float32 else 1e-2)
+    if bias:
+        assert rel_l2(host(conv.bias.grad), br.grad.numpy()) < t
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('name', sorted({k.split('/')[0] for k in DWB.files if '/' in k}))
+def test_depthwise_separable_block_golden(name, dtype):
+    """Conv2dBlockDW (mobilenet_v1.py:92-125) built by this package's factory reproduces the reference
+    block's output, gradients and running statistics (tests/golden/dwblocks.npz)."""
+    import convnets_amd as ca
+    from convnets_amd import layers
+    C, F_, H, stride, bn = (int(v) for v in DWB[f'{name}/cfg'])
+    s = ca.Settings(kind=0, input_size=(C, H, H), num_classes=10, batch_size=4, batch_norm=bool(bn),
+                    dropout_rate=0, mixed_precision=dtype == torch.bfloat16)
+    net = ca.MultiClassBaseModel(s)
+    blk = layers.Conv2dBlockDW(net, num_filters=F_, kernel_size=3, stride=stride, padding=1).cuda()
+    with torch.no_grad():
+        for k, p in blk.named_parameters():
+            p.copy_(torch.from_numpy(DWB[f'{name}/param/{k}']))
+    blk.train()
+    xt = dev(DWB[f'{name}/x'], dtype).requires_grad_(True)
+    y = blk(xt)
+    y.backward(dev(DWB[f'{name}/dy'], dtype))
+    torch.cuda.synchronize()
+    # bf16 vs the fp32 reference is loose by nature: two conv->BN->ReLU stages, rounding flips the ReLU mask
+    # of near-zero activations (the tight check is the fp32 one)
+    t = (2e-5, 2e-4) if dtype == torch.float32 else (2e-2, 1e-1)
+    assert rel_l2(host(y), DWB[f'{name}/y']) < t[0]
+    assert rel_l2(host(xt.grad), DWB[f'{name}/dx']) < t[1]
+    for k, p in blk.named_parameters():
+        assert rel_l2(host(p.grad), DWB[f'{name}/grad/{k}']) < t[1], k
+    for k, b in blk.named_buffers():
+        if 'running' in k:
+            assert rel_l2(host(b), DWB[f'{name}/buf/{k}']) < (1e-5 if dtype == torch.float32 else 1e-2), k

@@ -104,10 +104,12 @@ def test_factory_returns_stock_subclasses_and_tracks_shapes():
     nobn = ca.MultiClassBaseModel(ca.Settings(kind=0, input_size=(1, 28, 28), num_classes=10, batch_norm=False, device='cpu'))
     c = nobn.conv2d(num_filters=32, kernel_size=3)
     assert c.bias is not None and (nobn.height, nobn.width) == (26, 26)
-    with pytest.raises(NotImplementedError):
-        net.conv2d_depthwise(num_filters=8, kernel_size=3)
-    with pytest.raises(NotImplementedError):
-        net.conv2d(num_filters=8, kernel_size=3, groups=2)
+    dwc = net.conv2d_depthwise(kernel_size=3, padding=1, set_output=False)       # basemodel.py:981-997
+    assert isinstance(dwc, nn.Conv2d) and dwc.groups == 64 and tuple(dwc.weight.shape) == (64, 1, 3, 3)
+    with pytest.raises(NotImplementedError):                                     # channel multiplier != 1
+        net.conv2d_depthwise(num_filters=128, kernel_size=3)
+    with pytest.raises(NotImplementedError):                                     # general grouped conv
+        net.conv2d(num_filters=64, kernel_size=3, groups=2)
     with pytest.raises(TypeError):
         ca.Settings(kind=0, input_size=(1, 2, 2), num_classes=2, no_such_field=1)
 

@@ -83,7 +83,8 @@ def test_c_oracle_edge_cases():
 
 
 MODEL_CASES = [('resnet26', 'resnet', 26, (3, 32, 32), True), ('resnet18', 'resnet', 18, (3, 32, 32), True),
-               ('vgg11', 'vgg', 11, (3, 32, 32), True), ('convnet', 'convnet', 0, (1, 28, 28), False)]
+               ('vgg11', 'vgg', 11, (3, 32, 32), True), ('convnet', 'convnet', 0, (1, 28, 28), False),
+               ('mobilenet', 'mobilenet', 1, (3, 32, 32), True)]
 
 
 @pytest.mark.parametrize('name,family,kind,in_size,bn', MODEL_CASES)
@@ -120,3 +121,30 @@ def test_baseline_architectures_match_reference(name, family, kind):
     assert list(m.state_dict().keys()) == list(MODELS[f'{name}/sd_keys'])
     assert [str(tuple(v.shape)) for v in m.state_dict().values()] == list(MODELS[f'{name}/sd_shapes'])
     assert sum(p.numel() for p in m.parameters()) == int(MODELS[f'{name}/n_params'])
+
+
+DWB = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dwblocks.npz'))
+
+
+@pytest.mark.parametrize('name', sorted({k.split('/')[0] for k in DWB.files if '/' in k}))
+def test_torch_restatement_depthwise_block_matches_reference(name):
+    """oracle RefConv2dBlockDW (mobilenet_v1.py:92-125) with the reference's parameters reproduces the
+    reference block's output, input gradient, parameter gradients and running statistics bit for bit."""
+    C, F_, H, stride, bn = (int(v) for v in DWB[f'{name}/cfg'])
+    s = tr.RefSettings(0, (C, H, H), 10, batch_size=4, batch_norm=bool(bn), dropout_rate=0)
+    net = tr.RefBaseModel(s)
+    blk = tr.RefConv2dBlockDW(net, num_filters=F_, kernel_size=3, stride=stride, padding=1)
+    with torch.no_grad():
+        for k, p in blk.named_parameters():
+            p.copy_(torch.from_numpy(DWB[f'{name}/param/{k}']))
+    x = torch.from_numpy(DWB[f'{name}/x']).requires_grad_(True)
+    blk.train()
+    y = blk(x)
+    y.backward(torch.from_numpy(DWB[f'{name}/dy']))
+    assert np.array_equal(y.detach().numpy(), DWB[f'{name}/y'])
+    assert np.array_equal(x.grad.numpy(), DWB[f'{name}/dx'])
+    for k, p in blk.named_parameters():
+        assert np.array_equal(p.grad.numpy(), DWB[f'{name}/grad/{k}']), k
+    for k, b in blk.named_buffers():
+        if 'running' in k:
+            assert np.array_equal(b.numpy(), DWB[f'{name}/buf/{k}']), k
