@@ -280,16 +280,16 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     }
 }
 
-template <typename T, int BN, int NBUF, bool GLDS>
-__global__ __launch_bounds__(256, GLDS ? (NBUF == 2 ? 2 : 4) : (NBUF == 2 ? 2 : 3)) void igemm_gather_kernel(const GatherParams p) {
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
     constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
     constexpr int NJ = BN / 64;                      // 32-wide MFMA blocks per wave along n
     constexpr int B_LOADS = BN / 32;                 // 16-B chunks per thread for the B tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* row_dst = (int*)smem;                       // [128] dst pixel per tile row (-1: none)
-    unsigned char* As = smem + BM * sizeof(int);     // [2][128][128 B]
-    unsigned char* Bs = As + NBUF * BM * 128;        // [NBUF][BN][128 B]
+    unsigned char* As = smem + BM * sizeof(int);     // [128][128 B]
+    unsigned char* Bs = As + BM * 128;               // [BN][128 B]
 
     // XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
     // run of tiles so neighbours (same A rows, other n tile; adjacent pixels) share L2 lines.
@@ -348,9 +348,9 @@ __global__ __launch_bounds__(256, GLDS ? (NBUF == 2 ? 2 : 4) : (NBUF == 2 ? 2 : 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int l31 = lane & 31, lh = lane >> 5;
-    auto compute = [&](int buf) {
-        const unsigned char* Ab = As + buf * (BM * 128);
-        const unsigned char* Bb = Bs + buf * (BN * 128);
+    auto compute = [&]() {
+        const unsigned char* Ab = As;
+        const unsigned char* Bb = Bs;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 fa[2], fb[NJ];
@@ -371,128 +371,44 @@ __global__ __launch_bounds__(256, GLDS ? (NBUF == 2 ? 2 : 4) : (NBUF == 2 ? 2 : 
         }
     };
 
-    if constexpr (GLDS) {
-        // LDS-DMA pipeline: global_load_lds_dwordx4 writes 64 lanes x 16 B = 8 rows x 128 B straight
-        // into LDS (no staging VGPRs, no ds_write).  The LDS image is lane-linear, so the XOR
-        // swizzle goes on the SOURCE: lane (row r, physical chunk pc) fetches logical chunk
-        // pc ^ ((r>>1)&7).  Padded / out-of-range rows fetch a 16-byte zero block instead.
-        lds_u8* As3 = (lds_u8*)As;
-        lds_u8* Bs3 = (lds_u8*)Bs;
-        int ld_t = 0, ld_cs = 0;
-        auto issue = [&](int buf) {
-            const int t = ld_t, cb = ld_cs * KSTEP;
-            if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
-            const int dh = p.dh[t], dw = p.dw[t];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = lrow + 32 * i;
-                const int c = chunk ^ ((r >> 1) & 7);
-                const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
-                const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-                const T* gp = ok ? src + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + cb + c * PER16
-                                 : (const T*)cnk_zero16;
-                __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + buf * (BM * 128) + (wave * 8 + 32 * i) * 128), 16, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) {
-                const int r = lrow + 32 * i;
-                const int c = chunk ^ ((r >> 1) & 7);
-                const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.C + cb + c * PER16;
-                __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + buf * (BN * 128) + (wave * 8 + 32 * i) * 128), 16, 0, 0);
-            }
-        };
-        if (NBUF == 2) {
-            if (nk > 0) issue(0);
-            __syncthreads();                         // vmcnt(0) + barrier: tile 0 landed
-            for (int ks = 0; ks < nk; ++ks) {
-                if (ks + 1 < nk) issue((ks + 1) & 1);   // lands while this tile is consumed
-                compute(ks & 1);
-                __syncthreads();
-            }
-        } else {
-            for (int ks = 0; ks < nk; ++ks) {
-                issue(0);
-                __syncthreads();
-                compute(0);
-                __syncthreads();
-            }
-            if (nk == 0) __syncthreads();
-        }
-    } else {
-    // Register-staged pipeline, prefetch distance 1: the global loads of tile ks+1 are issued before
-    // the MFMA phase of tile ks and written to LDS after it.  NBUF = 2: double-buffered LDS, one
-    // barrier per K step (64 KiB -> 2 workgroups/CU).  NBUF = 1: one LDS buffer, two barriers per
-    // step, half the LDS -> 3 workgroups/CU (register-limited), i.e. more loads in flight per CU.
-    u32x4 ra[4], rb[B_LOADS];
-    int ld_t = 0, ld_cs = 0;                         // (tap, channel step) of the next load_step
-    auto load_step = [&]() {
-        const int t = ld_t, c0 = ld_cs * KSTEP + chunk * PER16;
+    // LDS-DMA main loop: global_load_lds_dwordx4 writes 64 lanes x 16 B = 8 rows x 128 B straight
+    // into LDS (no staging VGPRs, no ds_write).  The LDS image is lane-linear, so the XOR swizzle
+    // goes on the SOURCE: lane (row r, physical chunk pc) fetches logical chunk pc ^ ((r>>1)&7).
+    // Padded / out-of-range rows fetch a 16-byte zero block instead.  ONE buffer, two barriers per
+    // K step: 35 KiB of LDS and 116 VGPRs put four workgroups on a CU, and on this latency-bound
+    // loop that beat every double-buffered / register-staged variant tried (2 or 3 workgroups/CU).
+    lds_u8* As3 = (lds_u8*)As;
+    lds_u8* Bs3 = (lds_u8*)Bs;
+    int ld_t = 0, ld_cs = 0;
+    auto issue = [&]() {
+        const int t = ld_t, cb = ld_cs * KSTEP;
         if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
-        int dh = p.dh[t], dw = p.dw[t];
+        const int dh = p.dh[t], dw = p.dw[t];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
-            bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            u32x4 v = {0, 0, 0, 0};
-            if (ok) {
-                size_t off = ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + c0;
-                v = *(const u32x4*)(src + off);
-            }
-            ra[i] = v;
+            const int r = lrow + 32 * i;
+            const int c = chunk ^ ((r >> 1) & 7);
+            const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+            const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            const T* gp = ok ? src + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + cb + c * PER16
+                             : (const T*)cnk_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            int n = tile_n * BN + lrow + 32 * i;
-            size_t off = (size_t)n * wrow + (size_t)t * p.C + c0;
-            rb[i] = *(const u32x4*)(wpk + off);
+            const int r = lrow + 32 * i;
+            const int c = chunk ^ ((r >> 1) & 7);
+            const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.C + cb + c * PER16;
+            __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
         }
     };
-    auto store_step = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = lrow + 32 * i;
-            *(u32x4*)(As + buf * (BM * 128) + r * 128 + swz(r, chunk)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            int r = lrow + 32 * i;
-            *(u32x4*)(Bs + buf * (BN * 128) + r * 128 + swz(r, chunk)) = rb[i];
-        }
-    };
-
-    if (nk > 0) {
-        load_step();
-        store_step(0);
-    }
-    __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
-        const int buf = NBUF == 2 ? (ks & 1) : 0;
-        if (ks + 1 < nk) load_step();
-        const unsigned char* Ab = As + buf * (BM * 128);
-        const unsigned char* Bb = Bs + buf * (BN * 128);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            u32x4 fa[2], fb[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int r = wm * 64 + i * 32 + l31;
-                fa[i] = *(const u32x4*)(Ab + r * 128 + swz(r, 2 * s + lh));
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                int r = wn * (BN / 2) + j * 32 + l31;
-                fb[j] = *(const u32x4*)(Bb + r * 128 + swz(r, 2 * s + lh));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) Mma32<T>::run(acc[i][j], fb[j], fa[i]);   // C^T block
-        }
-        if (NBUF == 1) __syncthreads();              // every wave is done reading the only buffer
-        if (ks + 1 < nk) store_step(NBUF == 2 ? (buf ^ 1) : 0);
-        __syncthreads();
+        issue();
+        __syncthreads();                             // vmcnt(0) + barrier: the tile has landed
+        compute();
+        __syncthreads();                             // every wave is done reading the only buffer
     }
-    }   // register-staged path
+    if (nk == 0) __syncthreads();
 
     igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
@@ -788,39 +704,15 @@ __global__ __launch_bounds__(256, 2) void igemm_halo3x3_pf_kernel(const GatherPa
     igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
 
-template <typename T, int BN, int NBUF, bool GLDS> int launch_gather_v(const GatherParams& p, hipStream_t s) {
-    size_t pipe = NBUF * (BM * 128 + BN * 128);
+template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
+    size_t pipe = BM * 128 + BN * 128;
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
     size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);     // aliases the staged tile
     if (red > epi) epi = red;
     size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
-    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, NBUF, GLDS>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((igemm_gather_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
-}
-
-static int igemm_nbuf() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CNK_IGEMM_NBUF");
-        v = (e && e[0] == '2') ? 2 : 1;      // measured: 1 buffer / 3 WGs per CU wins (latency-bound loop)
-    }
-    return v;
-}
-
-static int igemm_glds() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CNK_IGEMM_GLDS");
-        v = (e && e[0] == '0') ? 0 : 1;       // measured: LDS-DMA + 1 buffer (4 WGs/CU) is fastest
-    }
-    return v;
-}
-
-template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
-    if (igemm_glds())
-        return igemm_nbuf() == 1 ? launch_gather_v<T, BN, 1, true>(p, s) : launch_gather_v<T, BN, 2, true>(p, s);
-    return igemm_nbuf() == 1 ? launch_gather_v<T, BN, 1, false>(p, s) : launch_gather_v<T, BN, 2, false>(p, s);
 }
 
 static bool pick_bn128(int M, int Nout) {

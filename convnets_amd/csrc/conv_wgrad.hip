@@ -256,22 +256,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     }
 }
 
-static int wgrad_nbuf() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CNK_WGRAD_NBUF");
-        v = (e && e[0] == '1') ? 1 : 2;
-    }
-    return v;
-}
-
 template <typename T, int BMW, int BNW> int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int KP = WgCfg<T>::KP;
-    const int nb = wgrad_nbuf();
-    size_t lds = nb * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));
+    size_t lds = 2 * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));   // double-buffered
     int grid = p.splits * p.tiles_co * p.ntaps * p.tiles_ci;
-    if (nb == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2>), dim3(grid), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 1>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2>), dim3(grid), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("wgrad_mfma");
     return 0;
 }
@@ -305,12 +294,7 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
     *ksteps = ceil_div(M, kp);
     // The kernel is resident at 2 workgroups per CU (80 KiB LDS each): 512 slots on 256 CUs.  Fill
     // them exactly once -- tiles*splits just ABOVE a multiple of 512 costs a whole extra round.
-    static int slots = 0;
-    if (!slots) {
-        const char* e = getenv("CNK_WGRAD_SLOTS");
-        slots = e ? atoi(e) : 512;
-        if (slots < 64) slots = 512;
-    }
+    const int slots = 512;
     int want = tiles >= slots ? 1 : slots / tiles;
     int max_by_k = *ksteps / 4 > 0 ? *ksteps / 4 : 1;       // at least 4 K steps per split
     int sp = want < max_by_k ? want : max_by_k;
