@@ -357,3 +357,37 @@ def test_reference_test_measurement():
         pred = torch.cat([model(xb.cuda()).argmax(dim=1).cpu() for xb, _ in loader])
     acc = [float((pred[i:i + 32] == ys[i:i + 32]).float().mean()) for i in range(0, 96, 32)]
     assert np.allclose(scores, acc)
+
+
+@pytest.mark.parametrize('mixed', [False, True], ids=['f32', 'bf16'])
+def test_training_trajectory_tracks_the_oracle(mixed):
+    """Twenty-four optimizer steps on a small learnable problem (4 fixed batches, labels from a linear probe of
+    the inputs): the HIP path's loss must fall like the oracle's torch-CPU loop run on the same data --
+    an end-to-end check that forward, backward, BN statistics, Adam and weight re-packing compose."""
+    import convnets_amd as ca
+    from oracle import torch_ref as tr
+    g = torch.Generator().manual_seed(3)
+    xs = torch.randn(128, 3, 32, 32, generator=g)
+    probe = torch.randn(10, 3 * 32 * 32, generator=g)
+    ys = (xs.reshape(128, -1) @ probe.t()).argmax(dim=1)
+    batches = [(xs[i:i + 32], ys[i:i + 32]) for i in range(0, 128, 32)]
+    kw = dict(batch_size=32, dropout_rate=0, learning_rate=1e-3)
+    torch.manual_seed(21)
+    ref = tr.MODELS['resnet'](tr.RefSettings(18, (3, 32, 32), 10, **kw))
+    ref.init_optimizer()
+    torch.manual_seed(21)
+    model = ca.MODELS['resnet'](ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, mixed_precision=mixed, **kw)).cuda()
+    model.init_optimizer()
+    model.train()
+    lr_, lh_ = [], []
+    for step in range(24):
+        xb, yb = batches[step % 4]
+        lr_.append(tr.ref_training_step(ref, xb, yb)[0])
+        lh_.append(float(model.train_batch((xb, yb))[0]))
+    first_r, last_r = np.mean(lr_[:4]), np.mean(lr_[-4:])
+    first_h, last_h = np.mean(lh_[:4]), np.mean(lh_[-4:])
+    print('oracle %.2f -> %.2f | hip(%s) %.2f -> %.2f' % (first_r, last_r, 'bf16' if mixed else 'f32', first_h, last_h))
+    assert abs(first_h - first_r) < (1e-3 if not mixed else 5e-2) * first_r
+    assert last_r < 0.35 * first_r, 'the problem must be learnable by the oracle'
+    assert last_h < 0.35 * first_h
+    assert abs(last_h - last_r) < (0.15 if not mixed else 0.3) * first_r      # same trajectory, not just "decreasing"
