@@ -87,9 +87,13 @@ class GradReducer:
         s, e, _ = self.buckets[b]
         view = self.flat_grad[s:e]
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.side.wait_event(ev)
+            from . import ops
+            dev = self.flat_grad.device
+            # the bucket's gradients were written on the compute stream and on the wgrad stream
+            for st in [torch.cuda.current_stream(dev), torch.cuda.default_stream(dev)] + ops.side_streams(dev):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
                 w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._works.append((w, None))

@@ -78,13 +78,59 @@ _workspaces = {}
 
 
 def workspace(nbytes, device):
-    """One grow-only scratch buffer per device; all kernels are stream-ordered on the caller's
-    stream, so successive ops can share it (the library itself never allocates)."""
-    ws = _workspaces.get(device)
+    """One grow-only scratch buffer per (device, stream); kernels are stream-ordered on the caller's
+    stream, so successive ops on one stream can share it (the library itself never allocates)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
+
+
+# ---- second HIP stream for the weight gradients -------------------------------------------------------
+# In the backward of a conv, dgrad (needed by the next backward op) and wgrad (needed only by the
+# optimizer / the gradient all-reduce) both depend on dy alone.  Both kernels are latency-bound and end
+# in a partially filled last round of workgroups; issued on two streams they share the chip, each
+# filling the other's idle slots.  The wgrad stream waits on an event recorded after dy is ready; whoever
+# consumes weight gradients (FlatAdam.step, clipping, GradReducer) first calls join_side_streams().
+WGRAD_STREAM = os.environ.get('CNK_WGRAD_STREAM', '1') != '0'
+_side_streams = {}
+
+
+def wgrad_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def side_streams(device):
+    st = _side_streams.get(device)
+    return [st] if st is not None else []
+
+
+_join_queued = [False]
+
+
+def _join_at_end_of_backward():
+    """Once per backward pass: when the autograd engine has run the whole graph, the compute stream
+    waits for the weight-gradient stream, so `.grad` is safe to read on the compute stream as usual."""
+    if _join_queued[0]:
+        return
+    _join_queued[0] = True
+
+    def cb():
+        _join_queued[0] = False
+        join_side_streams()
+    torch.autograd.Variable._execution_engine.queue_callback(cb)
+
+
+def join_side_streams(device=None):
+    """Makes the current stream wait for everything issued on the weight-gradient stream(s)."""
+    for dev, st in _side_streams.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(st)
 
 
 def make_desc(x_shape, weight_shape, stride, padding, dtype_code):
@@ -368,13 +414,27 @@ class Conv2dFn(torch.autograd.Function):
                 db_buf = db = torch.empty((desc.Cout,), dtype=torch.float32, device=w.device) \
                     if ctx.has_bias else None
             nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), PASS_WGRAD)
-            ws = workspace(nws, x.device)
-            check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
-                                       int(direct), _p(ws), ws.numel(), _stream()))
-            if direct:
-                _grad_written(weight)
-                if ctx.has_bias:
-                    _grad_written(bias)
+
+            def run_wgrad():
+                ws = workspace(nws, x.device)
+                check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
+                                           int(direct), _p(ws), ws.numel(), _stream()))
+                if direct:
+                    _grad_written(weight)
+                    if ctx.has_bias:
+                        _grad_written(bias)
+            if WGRAD_STREAM and direct:
+                # in-place arena gradients only: a returned dw tensor would be consumed by autograd on
+                # the main stream without knowing about the side stream
+                side = wgrad_stream(x.device)
+                side.wait_stream(torch.cuda.current_stream(x.device))       # dy, x (and zero_grad) are ready
+                with torch.cuda.stream(side):
+                    run_wgrad()
+                dy.record_stream(side)
+                x.record_stream(side)
+                _join_at_end_of_backward()
+            else:
+                run_wgrad()
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -57,6 +57,7 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none=False):
         # grads stay views of the arena (never None): autograd then accumulates in place
+        ops.join_side_streams(self.flat_g.device)
         self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
@@ -64,6 +65,7 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self):
+        ops.join_side_streams(self.flat_g.device)       # weight gradients written on the wgrad stream
         g = self.param_groups[0]
         self.step_count += 1
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -79,6 +81,7 @@ class FlatAdam:
         """clip_grad_norm_(parameters, max_norm) of basemodel.py:156 over the whole arena in two
         kernels; returns the total norm as a DEVICE scalar (no host sync)."""
         lib = _lib.load()
+        ops.join_side_streams(self.flat_g.device)
         ws = ops.workspace(lib.cnk_grad_clip_workspace_bytes(), self.flat_g.device)
         norm = torch.empty((), dtype=torch.float32, device=self.flat_g.device)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -90,6 +93,7 @@ class FlatAdam:
     @torch.no_grad()
     def clip_grad_value(self, clip_value):
         """clip_grad_value_(parameters, clip_value) of basemodel.py:171 as one kernel."""
+        ops.join_side_streams(self.flat_g.device)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(_lib.load().cnk_grad_clip_value(ctypes.c_void_p(self.flat_g.data_ptr()), self.numel,
                                               float(clip_value), s))
