@@ -371,6 +371,14 @@ class Conv2dFn(torch.autograd.Function):
         desc = ctx.desc
         dy = _nhwc(dy)
         dx = dw = db = None
+        # dy is complete on the compute stream HERE: the weight gradient (issued below on the second
+        # stream) waits for this point only, so it also overlaps this conv's own data gradient
+        dy_ready = None
+        # (bf16 path only: its kernels are latency/HBM-bound and gain from sharing the chip; the fp32
+        # kernels run at 65-70 % of the fp32 MFMA peak and only contend -- AlexNet fp32 lost 4 %)
+        if WGRAD_STREAM and x.is_cuda and x.dtype == torch.bfloat16:
+            dy_ready = torch.cuda.Event()
+            dy_ready.record(torch.cuda.current_stream(x.device))
         if ctx.needs_input_grad[0]:
             def dgrad(addend):
                 amask = None
@@ -423,11 +431,11 @@ class Conv2dFn(torch.autograd.Function):
                     _grad_written(weight)
                     if ctx.has_bias:
                         _grad_written(bias)
-            if WGRAD_STREAM and direct:
+            if dy_ready is not None and direct:
                 # in-place arena gradients only: a returned dw tensor would be consumed by autograd on
                 # the main stream without knowing about the side stream
                 side = wgrad_stream(x.device)
-                side.wait_stream(torch.cuda.current_stream(x.device))       # dy, x (and zero_grad) are ready
+                side.wait_event(dy_ready)                                    # dy, x (and zero_grad) are ready
                 with torch.cuda.stream(side):
                     run_wgrad()
                 dy.record_stream(side)
