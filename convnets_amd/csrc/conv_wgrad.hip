@@ -294,7 +294,7 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
     *ksteps = ceil_div(M, kp);
     // The kernel is resident at 2 workgroups per CU (80 KiB LDS each): 512 slots on 256 CUs.  Fill
     // them exactly once -- tiles*splits just ABOVE a multiple of 512 costs a whole extra round.
-    const int slots = 512;
+    const int slots = 512;                                   // (256..512 measure the same under the two-stream backward)
     int want = tiles >= slots ? 1 : slots / tiles;
     int max_by_k = *ksteps / 4 > 0 ? *ksteps / 4 : 1;       // at least 4 K steps per split
     int sp = want < max_by_k ? want : max_by_k;
