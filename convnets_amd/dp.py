@@ -54,6 +54,7 @@ class GradReducer:
         self._listener = lambda p: self._param_ready(self._index.get(id(p)))
         ops._grad_ready_listeners.append(self._listener)
         self._pending, self._launched, self._works, self._seen = None, None, None, None
+        self._compute_stream = None
         if flat_param is not None and self.world > 1:
             dist.broadcast(flat_param, src=0, group=process_group)      # identical replicas
 
@@ -73,6 +74,7 @@ class GradReducer:
         return lambda _param: self._param_ready(i)
 
     def begin_step(self):
+        self._compute_stream = torch.cuda.current_stream(self.flat_grad.device) if self.cuda else None
         self._pending = [sum(1 for i in ids if self.params[i].requires_grad) for _, _, ids in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._seen = [False] * len(self.params)
@@ -90,7 +92,9 @@ class GradReducer:
             from . import ops
             dev = self.flat_grad.device
             # the bucket's gradients were written on the compute stream and on the wgrad stream
-            for st in [torch.cuda.current_stream(dev), torch.cuda.default_stream(dev)] + ops.side_streams(dev):
+            streams = {st.cuda_stream: st for st in [torch.cuda.current_stream(dev), self._compute_stream] + ops.side_streams(dev)
+                       if st is not None}
+            for st in streams.values():
                 ev = torch.cuda.Event()
                 ev.record(st)
                 self.side.wait_event(ev)
