@@ -51,6 +51,10 @@ bool smallc_supported(const cnk_conv_desc* d);
 size_t smallc_packed_bytes(const cnk_conv_desc* d);
 int smallc_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
 int smallc_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, hipStream_t s);
+bool smallc_dgrad_desc(const cnk_conv_desc* d, cnk_conv_desc* t);
+size_t smallc_dgrad_packed_bytes(const cnk_conv_desc* d);
+int smallc_dgrad_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
+int smallc_dgrad(const cnk_conv_desc* d, const void* dy, const void* wpk, void* dx, hipStream_t s);
 size_t smallc_wgrad_workspace(const cnk_conv_desc* d);
 int smallc_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int nblocks, hipStream_t s);
@@ -160,6 +164,11 @@ size_t cnk_conv2d_packed_bytes(const cnk_conv_desc* d, int pass) {
     if (igemm_supported(d, pass)) return n * esize(d->dtype);
     if (pass == CNK_PASS_FWD && rowpatch_supported(d)) return rowpatch_packed_bytes(d);
     if (pass == CNK_PASS_FWD && smallc_supported(d)) return smallc_packed_bytes(d);
+    if (pass == CNK_PASS_DGRAD && smallc_dgrad_packed_bytes(d)) {
+        // room for both images: the transposed-forward one (used without an addend) and the direct one
+        size_t a = (smallc_dgrad_packed_bytes(d) + 255) & ~(size_t)255;
+        return a + n * sizeof(float);
+    }
     return n * sizeof(float);
 }
 
@@ -203,6 +212,10 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
                 if (int rc = pack_taps(d, w, (char*)w_dgrad + off * esize(d->dtype), cls[c].ntaps, cls[c].kh, cls[c].kw, 1, S(stream))) return rc;
                 off += (size_t)cls[c].ntaps * d->Cin * d->Cout;
             }
+        } else if (smallc_dgrad_packed_bytes(d)) {
+            size_t a = (smallc_dgrad_packed_bytes(d) + 255) & ~(size_t)255;
+            if (int rc = smallc_dgrad_pack(d, w, w_dgrad, S(stream))) return rc;
+            if (int rc = pack_direct(d, w, (char*)w_dgrad + a, S(stream))) return rc;
         } else if (!(direct_done && w_dgrad == w_fwd)) {
             if (int rc = pack_direct(d, w, w_dgrad, S(stream))) return rc;
         }
@@ -305,6 +318,10 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
         CNK_CHECK_ARG(!bn->relu || bn->relu_mask || (bn->gamma && bn->beta), "cnk_conv2d_dgrad: bn fuse: ReLU without a mask needs gamma and beta");
     }
     if (igemm_supported(d, CNK_PASS_DGRAD)) return igemm_dgrad(d, dy, w_dgrad, dx, addend, addend_mask, bn, S(stream));
+    if (size_t sb = smallc_dgrad_packed_bytes(d)) {
+        if (!addend) return smallc_dgrad(d, dy, w_dgrad, dx, S(stream));
+        w_dgrad = (const char*)w_dgrad + ((sb + 255) & ~(size_t)255);       // the direct image sits behind it
+    }
     return direct_dgrad(d, dy, w_dgrad, dx, addend, S(stream));
 }
 

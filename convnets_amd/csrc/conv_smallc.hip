@@ -289,16 +289,20 @@ __global__ __launch_bounds__(256) void smallc_wgrad_kernel(const SmallCParams p)
 }
 
 // wpk[co][k] (T, zero padded to [64][Kpad]) = w[co][ci][kh][kw], k = (kh*KW + kw)*Cin + ci
+// transpose: image of the TRANSPOSED, tap-flipped conv (the data gradient of a stride-1 conv as a
+// forward conv over dy): row = ci of the master weight, k = (r*KW + q)*Cout_master + co, value
+// w[co][ci][KH-1-r][KW-1-q]; Cout / Cin are then those of the transposed problem.
 template <typename T>
 __global__ void pack_smallc_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
-                                   int KH, int KW, int K, int Kpad) {
+                                   int KH, int KW, int K, int Kpad, int transpose) {
     int total = 64 * Kpad;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int co = i / Kpad, k = i - co * Kpad;
         float v = 0.f;
         if (co < Cout && k < K) {
             int t = k / Cin, ci = k - t * Cin;
-            v = w[((size_t)co * Cin + ci) * KH * KW + t];
+            if (transpose) v = w[((size_t)ci * Cout + co) * KH * KW + (KH * KW - 1 - t)];
+            else v = w[((size_t)co * Cin + ci) * KH * KW + t];
         }
         out[i] = from_f32<T>(v);
     }
@@ -357,16 +361,46 @@ size_t smallc_packed_bytes(const cnk_conv_desc* d) {
     return (size_t)64 * Kpad * (d->dtype == CNK_BF16 ? 2 : 4);
 }
 
-int smallc_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s) {
+static int smallc_pack_t(const cnk_conv_desc* d, const float* w, void* out, int transpose, hipStream_t s) {
     int K = d->kh * d->kw * d->Cin, Kpad = (K + 31) / 32 * 32;
     int grid = ceil_div(64 * Kpad, 256);
     if (d->dtype == CNK_BF16)
-        hipLaunchKernelGGL(pack_smallc_kernel<bf16>, dim3(grid), dim3(256), 0, s, w, (bf16*)out, d->Cout, d->Cin, d->kh, d->kw, K, Kpad);
+        hipLaunchKernelGGL(pack_smallc_kernel<bf16>, dim3(grid), dim3(256), 0, s, w, (bf16*)out, d->Cout, d->Cin, d->kh, d->kw, K, Kpad, transpose);
     else
-        hipLaunchKernelGGL(pack_smallc_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, d->Cout, d->Cin, d->kh, d->kw, K, Kpad);
+        hipLaunchKernelGGL(pack_smallc_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, d->Cout, d->Cin, d->kh, d->kw, K, Kpad, transpose);
     CNK_CHECK_LAUNCH("pack_smallc");
     return 0;
 }
+
+int smallc_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s) { return smallc_pack_t(d, w, out, 0, s); }
+
+// Data gradient of a STRIDE-1 conv = forward conv of dy with the transposed, tap-flipped weights and
+// padding k-1-p.  When that transposed problem is a small-channel one (Cin <= 64 of the original, e.g.
+// MobileNet's 32 -> 64 pointwise conv at 112x112) it runs on the MFMA forward kernel above instead of
+// the direct kernel.  Returns false when the trick does not apply.
+bool smallc_dgrad_desc(const cnk_conv_desc* d, cnk_conv_desc* t) {
+    if (d->stride_h != 1 || d->stride_w != 1) return false;
+    if (d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0) return false;
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    *t = *d;
+    t->H = Ho; t->W = Wo; t->Cin = d->Cout; t->Cout = d->Cin;
+    t->pad_h = d->kh - 1 - d->pad_h; t->pad_w = d->kw - 1 - d->pad_w;
+    return smallc_supported(t);
+}
+
+size_t smallc_dgrad_packed_bytes(const cnk_conv_desc* d) {
+    cnk_conv_desc t;
+    return smallc_dgrad_desc(d, &t) ? smallc_packed_bytes(&t) : 0;
+}
+
+int smallc_dgrad_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s) {
+    cnk_conv_desc t;
+    smallc_dgrad_desc(d, &t);
+    return smallc_pack_t(&t, w, out, 1, s);
+}
+
+int smallc_dgrad(const cnk_conv_desc* d, const void* dy, const void* wpk, void* dx, hipStream_t s);
 
 int smallc_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y,
                hipStream_t s) {
@@ -382,6 +416,12 @@ int smallc_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const flo
     }
     CNK_CHECK_LAUNCH("smallc_fwd");
     return 0;
+}
+
+int smallc_dgrad(const cnk_conv_desc* d, const void* dy, const void* wpk, void* dx, hipStream_t s) {
+    cnk_conv_desc t;
+    smallc_dgrad_desc(d, &t);
+    return smallc_fwd(&t, dy, wpk, nullptr, dx, s);
 }
 
 size_t smallc_wgrad_workspace(const cnk_conv_desc* d) {
