@@ -589,3 +589,55 @@ def test_depthwise_separable_block_golden(name, dtype):
     for k, b in blk.named_buffers():
         if 'running' in k:
             assert rel_l2(host(b), DWB[f'{name}/buf/{k}']) < (1e-5 if dtype == torch.float32 else 1e-2), k
+
+
+def _random_conv_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    chans = [1, 3, 6, 16, 32, 48, 64, 96, 128, 192, 256]
+    while len(cases) < n:
+        cin, cout = int(rng.choice(chans)), int(rng.choice(chans))
+        kh, kw = int(rng.randint(1, 6)), int(rng.randint(1, 6))
+        sh, sw = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+        ph, pw = int(rng.randint(0, kh)), int(rng.randint(0, kw))
+        H, W = int(rng.randint(1, 20)), int(rng.randint(1, 20))
+        N = int(rng.randint(1, 5))
+        if H + 2 * ph < kh or W + 2 * pw < kw or kh * kw > 25:
+            continue
+        cases.append((N, cin, H, W, cout, kh, kw, sh, sw, ph, pw, bool(rng.randint(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', _random_conv_cases(40, 11), ids=lambda c: 'n%d-c%d-%dx%d-o%d-k%dx%d-s%d%d-p%d%d-b%d' % c)
+def test_conv_random_shapes_vs_torch(case, dtype):
+    """Randomly drawn geometries (non-square kernels / strides / paddings, 1-pixel images, channel counts
+    on and off every kernel family's grid) through whichever kernel the dispatcher picks, against torch
+    fp64: forward, dx, dw, dbias."""
+    from convnets_amd import ops
+    N, cin, H, W, cout, kh, kw, sh, sw, ph, pw, bias = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, kh, kw, generator=g) / np.sqrt(cin * kh * kw)
+    b = torch.randn(cout, generator=g) if bias else None
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, (sh, sw), (ph, pw))
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy.double())
+    xt = dev(x.numpy(), dtype).requires_grad_(True)
+    wt = w.cuda().requires_grad_(True)
+    bt = b.cuda().requires_grad_(True) if bias else None
+    y = ops.Conv2dFn.apply(xt, wt, bt, (sh, sw), (ph, pw), ops.PackedWeights())
+    y.backward(dev(dy.numpy(), dtype))
+    torch.cuda.synchronize()
+    t = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_l2(host(y), yr.detach().numpy()) < t, 'fwd'
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < t, 'dgrad'
+    assert rel_l2(host(wt.grad), wr.grad.numpy()) < (5e-5 if dtype == torch.float32 else 1.5e-2), 'wgrad'
+    if bias:
+        assert rel_l2(host(bt.grad), br.grad.numpy()) < t, 'dbias'
