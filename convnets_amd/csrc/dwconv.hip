@@ -304,7 +304,7 @@ int dwconv_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, void* d
     return 0;
 }
 
-static int dw_wgrad_blocks() { return 1024; }
+static int dw_wgrad_blocks() { return 512; }      // slices to sum afterwards: keep them few
 
 size_t dwconv_wgrad_workspace(const cnk_conv_desc* d) {
     DwParams p = dw_params(d);
