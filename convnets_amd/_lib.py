@@ -18,7 +18,7 @@ CLS = dict(conv3x3_fwd=1, conv3x3_dgrad=2, conv3x3_wgrad=4, conv1x1_fwd=8, conv1
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('N', 'H', 'W', 'Cin', 'Cout', 'kh', 'kw', 'stride_h', 'stride_w', 'pad_h', 'pad_w',
-                 'dtype')]
+                 'dtype', 'groups')]
 
 
 class BnBwdFuse(ctypes.Structure):
@@ -29,7 +29,7 @@ class BnBwdFuse(ctypes.Structure):
 
 class PackJob(ctypes.Structure):
     _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + \
-               [(n, ctypes.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'ntaps', 'transpose', 'dtype', 'pad_')] + \
+               [(n, ctypes.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'ntaps', 'transpose', 'dtype', 'groups')] + \
                [('kh', ctypes.c_int8 * 32), ('kw', ctypes.c_int8 * 32)]
 
 

@@ -10,6 +10,7 @@
 
 // ---- kernel families (other translation units) ---------------------------------------------------
 bool igemm_supported(const cnk_conv_desc* d, int pass);
+bool igemm_grouped_ok(const cnk_conv_desc* d);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
@@ -129,6 +130,7 @@ static int check_desc(const cnk_conv_desc* d, const char* fn) {
     CNK_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive dims", fn);
     CNK_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0, "%s: bad kernel/stride/pad", fn);
     CNK_CHECK_ARG(d->H + 2 * d->pad_h >= d->kh && d->W + 2 * d->pad_w >= d->kw, "%s: kernel larger than padded input", fn);
+    CNK_CHECK_ARG(conv_groups(d) == 1 || igemm_grouped_ok(d), "%s: groups=%d needs Cin == Cout, Cin %% 64 == 0 and a group width that divides 64 (depthwise: cnk_dwconv2d_*)", fn, d->groups);
     int64_t Ho = (d->H + 2 * d->pad_h - d->kh) / d->stride_h + 1, Wo = (d->W + 2 * d->pad_w - d->kw) / d->stride_w + 1;
     CNK_CHECK_ARG((int64_t)d->N * d->H * d->W < (1ll << 31) && (int64_t)d->N * Ho * Wo < (1ll << 31), "%s: pixel count exceeds 2^31", fn);
     return 0;
@@ -232,7 +234,7 @@ int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, vo
         cnk_pack_job& j = jobs[n++];
         memset(&j, 0, sizeof(j));
         j.w = w; j.out = out; j.Cout = d->Cout; j.Cin = d->Cin; j.KH = d->kh; j.KW = d->kw;
-        j.ntaps = ntaps; j.transpose = transpose; j.dtype = d->dtype;
+        j.ntaps = ntaps; j.transpose = transpose; j.dtype = d->dtype; j.groups = conv_groups(d);
         for (int t = 0; t < ntaps; ++t) { j.kh[t] = kh[t]; j.kw[t] = kw[t]; }
         return true;
     };

@@ -121,9 +121,18 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 struct PackParams {
     const float* w;
     void* out;
-    int Cout, Cin, KH, KW, ntaps, transpose;
+    int Cout, Cin, KH, KW, ntaps, transpose, groups;
     signed char kh[32], kw[32];
 };
+// master weight value for dense image position (co, ci, tap): with groups > 1 the master tensor is
+// [Cout][Cin/groups][KH][KW] and the image is block-diagonal (zero outside co's group)
+__device__ __forceinline__ float master_w(const float* __restrict__ w, int co, int ci, int Cout, int Cin, int KH, int KW,
+                                          int kh, int kw, int groups) {
+    if (groups <= 1) return w[(((size_t)co * Cin + ci) * KH + kh) * KW + kw];
+    const int gw = Cin / groups, g = co / (Cout / groups), l = ci - g * gw;
+    if ((unsigned)l >= (unsigned)gw) return 0.f;
+    return w[(((size_t)co * gw + l) * KH + kh) * KW + kw];
+}
 template <typename T> __global__ void pack_kernel(const PackParams p) {
     int R = p.transpose ? p.Cin : p.Cout, Cred = p.transpose ? p.Cout : p.Cin;
     size_t total = (size_t)R * p.ntaps * Cred;
@@ -133,7 +142,7 @@ template <typename T> __global__ void pack_kernel(const PackParams p) {
         size_t q = i / Cred;
         int t = (int)(q % p.ntaps), r = (int)(q / p.ntaps);
         int co = p.transpose ? c : r, ci = p.transpose ? r : c;
-        float v = p.w[(((size_t)co * p.Cin + ci) * p.KH + p.kh[t]) * p.KW + p.kw[t]];
+        float v = master_w(p.w, co, ci, p.Cout, p.Cin, p.KH, p.KW, p.kh[t], p.kw[t], p.groups);
         ((T*)p.out)[i] = from_f32<T>(v);
     }
 }
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const cnk_pack_job* __r
             size_t q = i / Cred;
             int t = (int)(q % j.ntaps), r = (int)(q / j.ntaps);
             int co = j.transpose ? c : r, ci = j.transpose ? r : c;
-            float v = j.w[(((size_t)co * j.Cin + ci) * j.KH + j.kh[t]) * j.KW + j.kw[t]];
+            float v = master_w(j.w, co, ci, j.Cout, j.Cin, j.KH, j.KW, j.kh[t], j.kw[t], j.groups);
             if (j.dtype == CNK_BF16) ((bf16*)j.out)[i] = (bf16)v;
             else ((float*)j.out)[i] = v;
         }
@@ -294,7 +303,7 @@ int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, cons
     if (ntaps == 0) return 0;
     PackParams p = {};
     p.w = w; p.out = out; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->kh; p.KW = d->kw;
-    p.ntaps = ntaps; p.transpose = transpose;
+    p.ntaps = ntaps; p.transpose = transpose; p.groups = conv_groups(d);
     for (int t = 0; t < ntaps; ++t) { p.kh[t] = kh[t]; p.kw[t] = kw[t]; }
     size_t total = (size_t)d->Cout * d->Cin * ntaps;
     int grid = (int)((total + 255) / 256);

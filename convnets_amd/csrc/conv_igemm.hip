@@ -42,6 +42,7 @@ struct GatherParams {
     float* bnf_partial;      // [slices][Nout][2]
     int bnf_relu, bnf_tile0; // tile0: first slice of this launch (stride-parity classes)
     int relu;                // inference epilogue: dst = max(conv + bias [+ addend], 0)
+    int chunked;             // grouped conv: n-tile t (64 wide) reduces over channel chunk [64t, 64t+64) only
     int N, IH, IW, C;
     int OH, OW;
     int FH, FW, Nout;
@@ -336,7 +337,9 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
 
     const T* src = (const T*)p.src;
     const T* wpk = (const T*)p.wpk;
-    const int csteps = p.C / KSTEP;
+    // grouped conv (block-diagonal image): this 64-wide n-tile only sees its own 64 input channels
+    const int csteps = p.chunked ? 64 / KSTEP : p.C / KSTEP;
+    const int cs0 = p.chunked ? tile_n * (64 / KSTEP) : 0;
     const int nk = p.ntaps * csteps;
     const size_t wrow = (size_t)p.ntaps * p.C;
 
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     lds_u8* Bs3 = (lds_u8*)Bs;
     int ld_t = 0, ld_cs = 0;
     auto issue = [&]() {
-        const int t = ld_t, cb = ld_cs * KSTEP;
+        const int t = ld_t, cb = (cs0 + ld_cs) * KSTEP;
         if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
         const int dh = p.dh[t], dw = p.dw[t];
 #pragma unroll
@@ -775,12 +778,12 @@ template <typename T, int BN> int launch_halo(const GatherParams& p, hipStream_t
 
 template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     int tiles_m = ceil_div(p.M, BM);
-    bool use128 = pick_bn128(p.M, p.Nout);
+    bool use128 = !p.chunked && pick_bn128(p.M, p.Nout);
     int bn = use128 ? 128 : 64;
     p.tiles_n = p.Nout / bn;
     p.tiles_total = tiles_m * p.tiles_n;
     if (p.tiles_total == 0) return 0;
-    if (igemm_halo_enabled() && halo_shape(p)) {
+    if (igemm_halo_enabled() && !p.chunked && halo_shape(p)) {
         // three workgroups per CU need <= 53 KiB each; wider images fall back to the gather kernel
         size_t lds = use128 ? halo_lds<T, 128>(p) : halo_lds<T, 64>(p);
         if (lds <= (size_t)(igemm_halo_pf(p.tiles_total, bn) ? 80 : 53) * 1024) return use128 ? launch_halo<T, 128>(p, s) : launch_halo<T, 64>(p, s);
@@ -791,7 +794,15 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
 }  // namespace
 
 // ---- host entry points used by api.hip --------------------------------------------------------
+// grouped conv the chunked kernels can run: see cnk_conv_desc
+bool igemm_grouped_ok(const cnk_conv_desc* d) {
+    const int g = conv_groups(d);
+    if (g == 1) return true;
+    return d->Cin == d->Cout && d->Cin % 64 == 0 && d->Cin % g == 0 && 64 % (d->Cin / g) == 0 && g != d->Cin;
+}
+
 bool igemm_supported(const cnk_conv_desc* d, int pass) {
+    if (conv_groups(d) > 1 && !igemm_grouped_ok(d)) return false;
     int kstep = d->dtype == CNK_BF16 ? 64 : 32;
     int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout;
     int nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
@@ -812,7 +823,7 @@ int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const fl
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     GatherParams p = {};
     p.src = x; p.wpk = w_fwd; p.dst = y; p.bias = bias; p.stats = stats;
-    p.addend = residual; p.relu = relu;
+    p.addend = residual; p.relu = relu; p.chunked = conv_groups(d) > 1;
     p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cin;
     p.OH = Ho; p.OW = Wo; p.FH = Ho; p.FW = Wo; p.Nout = d->Cout;
     p.sm_h = d->stride_h; p.sm_w = d->stride_w;
@@ -883,7 +894,7 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
         const DgradClass& k = cls[c];
         GatherParams p = {};
         p.src = dy; p.wpk = (const char*)w_dgrad + woff * esz; p.dst = dx; p.bias = nullptr;
-        p.addend = addend; p.addend_mask = addend_mask;
+        p.addend = addend; p.addend_mask = addend_mask; p.chunked = conv_groups(d) > 1;
         p.N = d->N; p.IH = Ho; p.IW = Wo; p.C = d->Cout;
         p.OH = k.OH; p.OW = k.OW; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
         p.sm_h = 1; p.sm_w = 1;

@@ -24,6 +24,7 @@ struct WgradParams {
     int M;
     int ksteps, ksteps_per_split, splits;
     int tiles_co, tiles_ci, ntaps;
+    int diag;               // grouped conv: only the diagonal 64x64 (co chunk, same ci chunk) tiles exist
     FastDiv fd_howo, fd_wo;
 };
 
@@ -64,7 +65,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
     bid -= split * per_split;
     const int tile_co = bid / tiles_nc;
     const int rest = bid - tile_co * tiles_nc;
-    const int tap = rest / p.tiles_ci, tile_ci = rest - tap * p.tiles_ci;
+    const int tap = rest / p.tiles_ci;
+    // grouped conv: the x columns are those of the output chunk; the slab keeps 64 local ci per co
+    const int tile_ci = p.diag ? tile_co : rest - tap * p.tiles_ci;
+    const int slab_ci0 = p.diag ? 0 : tile_ci * BNW, slab_row = p.diag ? BNW : p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
     }
 
     const int l31 = lane & 31, lh = lane >> 5;
-    float* slab = p.slab + (size_t)split * p.Cout * p.ntaps * p.Cin;
+    float* slab = p.slab + (size_t)split * p.Cout * p.ntaps * slab_row;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int co = tile_co * BMW + wm * (BMW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                int ci = tile_ci * BNW + wn * (BNW / 2) + j * 32 + l31;
-                slab[((size_t)co * p.ntaps + tap) * p.Cin + ci] = acc[i][j][r];
+                int ci = slab_ci0 + wn * (BNW / 2) + j * 32 + l31;
+                slab[((size_t)co * p.ntaps + tap) * slab_row + ci] = acc[i][j][r];
             }
 }
 
@@ -279,18 +283,43 @@ int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_st
     return 0;
 }
 
-bool wgrad_mfma_supported(const cnk_conv_desc* d) { return d->Cin % 64 == 0 && d->Cout % 64 == 0; }
+bool igemm_grouped_ok(const cnk_conv_desc* d);
+bool wgrad_mfma_supported(const cnk_conv_desc* d) {
+    if (conv_groups(d) > 1 && !igemm_grouped_ok(d)) return false;
+    return d->Cin % 64 == 0 && d->Cout % 64 == 0;
+}
 
 // Tile shape and split count shared by the workspace query and the launch.
+// grouped conv: dw[co][l][t] (+)= sum_s slab[s][co][t][local ci], local ci = ((co % 64) / gw) * gw + l
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                   int splits, int Cout, int gw, int ntaps, int accumulate) {
+    const size_t total = (size_t)Cout * gw * ntaps, per = (size_t)Cout * ntaps * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ntaps);
+        const size_t r = i / ntaps;
+        const int l = (int)(r % gw), co = (int)(r / gw);
+        const float* sp = slab + ((size_t)co * ntaps + t) * 64 + ((co & 63) / gw) * gw + l;
+        float a0 = 0.f, a1 = 0.f;
+        int s = 0;
+        for (; s + 1 < splits; s += 2) {
+            a0 += sp[(size_t)s * per];
+            a1 += sp[(size_t)(s + 1) * per];
+        }
+        if (s < splits) a0 += sp[(size_t)s * per];
+        dw[i] = accumulate ? dw[i] + (a0 + a1) : (a0 + a1);
+    }
+}
+
 static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, int* ksteps,
                        int* per_split) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     int M = d->N * Ho * Wo;
     int kp = d->dtype == CNK_BF16 ? 64 : 32;
-    *bmw = d->Cout % 128 == 0 ? 128 : 64;
-    *bnw = d->Cin % 128 == 0 ? 128 : 64;
-    int tiles = (d->Cout / *bmw) * (d->Cin / *bnw) * d->kh * d->kw;
+    const bool grouped = conv_groups(d) > 1;
+    *bmw = (!grouped && d->Cout % 128 == 0) ? 128 : 64;
+    *bnw = (!grouped && d->Cin % 128 == 0) ? 128 : 64;
+    int tiles = grouped ? (d->Cout / 64) * d->kh * d->kw : (d->Cout / *bmw) * (d->Cin / *bnw) * d->kh * d->kw;
     *ksteps = ceil_div(M, kp);
     // The kernel is resident at 2 workgroups per CU (80 KiB LDS each): 512 slots on 256 CUs.  Fill
     // them exactly once -- tiles*splits just ABOVE a multiple of 512 costs a whole extra round.
@@ -306,7 +335,7 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d) {
     int bmw, bnw, splits, ksteps, per;
     wgrad_plan(d, &bmw, &bnw, &splits, &ksteps, &per);
-    return (size_t)splits * d->Cout * d->Cin * d->kh * d->kw * sizeof(float);
+    return (size_t)splits * d->Cout * (conv_groups(d) > 1 ? 64 : d->Cin) * d->kh * d->kw * sizeof(float);
 }
 
 int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate,
@@ -316,13 +345,15 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     WgradParams p = {};
     int bmw, bnw;
     wgrad_plan(d, &bmw, &bnw, &p.splits, &p.ksteps, &p.ksteps_per_split);
-    size_t need = (size_t)p.splits * d->Cout * d->Cin * d->kh * d->kw * sizeof(float);
+    const bool grouped = conv_groups(d) > 1;
+    size_t need = (size_t)p.splits * d->Cout * (grouped ? 64 : d->Cin) * d->kh * d->kw * sizeof(float);
     CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
     p.dy = dy; p.x = x; p.slab = (float*)ws;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
     p.KH = d->kh; p.KW = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
     p.M = d->N * Ho * Wo;
-    p.tiles_co = d->Cout / bmw; p.tiles_ci = d->Cin / bnw; p.ntaps = d->kh * d->kw;
+    p.tiles_co = d->Cout / bmw; p.tiles_ci = grouped ? 1 : d->Cin / bnw; p.ntaps = d->kh * d->kw;
+    p.diag = grouped;
     p.fd_howo = make_fastdiv(Ho * Wo);
     p.fd_wo = make_fastdiv(Wo);
     int rc;
@@ -332,6 +363,16 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     else if (bnw == 128) rc = b ? launch_wgrad<bf16, 64, 128>(p, s) : launch_wgrad<float, 64, 128>(p, s);
     else rc = b ? launch_wgrad<bf16, 64, 64>(p, s) : launch_wgrad<float, 64, 64>(p, s);
     if (rc) return rc;
+    if (grouped) {
+        const int gw = d->Cin / conv_groups(d);
+        size_t total = (size_t)d->Cout * gw * p.ntaps;
+        int grid = (int)((total + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3(grid), dim3(256), 0, s, p.slab, dw, p.splits, d->Cout, gw,
+                           p.ntaps, accumulate);
+        CNK_CHECK_LAUNCH("wgrad_reduce_grouped");
+        return 0;
+    }
     size_t per = (size_t)d->Cout * p.ntaps * d->Cin;
     return launch_wgrad_reduce(p.slab, dw, p.splits, per, d->Cout, d->Cin, p.ntaps,
                                (size_t)p.ntaps * d->Cin, (size_t)d->Cin, 1, 1, accumulate, s);

@@ -24,10 +24,14 @@ class Conv2d(nn.Conv2d):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._depthwise = self.groups > 1 and self.groups == self.in_channels == self.out_channels
-        if (self.groups != 1 and not self._depthwise) or _pair(self.dilation) != (1, 1) \
-                or self.padding_mode != 'zeros' or isinstance(self.padding, str):
-            raise NotImplementedError('convnets_amd.Conv2d: only groups=1 or depthwise (groups == in == out '
-                                      'channels), dilation=1, zeros padding are implemented')
+        gw = self.in_channels // self.groups
+        grouped_ok = self.groups == 1 or self._depthwise or (
+            self.in_channels == self.out_channels and self.in_channels % 64 == 0 and 64 % gw == 0)
+        if not grouped_ok or _pair(self.dilation) != (1, 1) or self.padding_mode != 'zeros' \
+                or isinstance(self.padding, str):
+            raise NotImplementedError('convnets_amd.Conv2d: groups=1, depthwise (groups == channels) or grouped '
+                                      'with in == out channels, channels % 64 == 0 and a group width that divides '
+                                      '64 (ResNeXt); dilation=1, zeros padding')
         self._packed = ops.PackedWeights()
 
     def __deepcopy__(self, memo):
@@ -46,7 +50,7 @@ class Conv2d(nn.Conv2d):
             return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
         # x._cnk_bn: set when x is the output of a training-mode BatchNorm2d of this package (ops.BnRecord)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
-                                  self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None))
+                                  self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -170,7 +174,7 @@ class ConvBlock(nn.Sequential):
                 stamp = (ops.weights_epoch(), getattr(bn, '_stats_epoch', 0), id(conv.weight), conv.weight._version,
                          bn.running_mean._version, bn.running_var._version, bn.weight._version, bn.bias._version)
                 y = fold.run(x, conv.weight, conv.bias, bn, _pair(conv.stride), _pair(conv.padding), residual,
-                             act or relu_after_add, stamp)
+                             act or relu_after_add, stamp, conv.groups)
                 if y is not None:
                     return y
             return bn(conv(x), residual=residual, relu=act or relu_after_add)

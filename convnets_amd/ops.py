@@ -133,13 +133,13 @@ def join_side_streams(device=None):
             torch.cuda.current_stream(dev).wait_stream(st)
 
 
-def make_desc(x_shape, weight_shape, stride, padding, dtype_code):
+def make_desc(x_shape, weight_shape, stride, padding, dtype_code, groups=1):
     N, Cin, H, W = x_shape
     Cout, Cin_w, kh, kw = weight_shape
-    if Cin != Cin_w:
-        raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_w))
+    if Cin != Cin_w * groups:
+        raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_w * groups))
     return ConvDesc(N, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1],
-                    dtype_code)
+                    dtype_code, groups)
 
 
 def masked_grad(dy, mask):
@@ -296,9 +296,9 @@ class PackedWeights:
                 and self.key[1] == weight._version:
             if self.batched_epoch != weights_epoch():
                 packer_for(weight.device).ensure()
-            self.key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad)
+            self.key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad, desc.groups)
             return self.w_fwd, self.w_dgrad
-        key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad)
+        key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad, desc.groups)
         if self.key != key:
             dev = weight.device
             nf = lib.cnk_conv2d_packed_bytes(ctypes.byref(desc), PASS_FWD)
@@ -327,7 +327,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None,
-                bn_rec=None):
+                bn_rec=None, groups=1):
         """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
         of y emitted by the conv epilogue (None when this conv shape cannot produce them).
         link: optional GradLink shared with the other consumer of x (residual blocks)."""
@@ -336,7 +336,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) bn_partial
         x = _nhwc(x)
         w = weight if weight.is_contiguous() else weight.contiguous()
-        desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x))
+        desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x), groups)
         need_dgrad = x.requires_grad
         w_fwd, w_dgrad = packed.get(w, desc, need_dgrad)
         Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
@@ -366,7 +366,7 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
         if dy is None:                        # y took no part in the loss
-            return (None,) * 9
+            return (None,) * 10
         x, w = ctx.saved_tensors
         desc = ctx.desc
         dy = _nhwc(dy)
@@ -443,7 +443,7 @@ class Conv2dFn(torch.autograd.Function):
                 _join_at_end_of_backward()
             else:
                 run_wgrad()
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -851,11 +851,13 @@ class FoldedConv:
         self.stamp = None
         self.w_img = self.bias = None
 
-    def run(self, x, conv_weight, conv_bias, bn, stride, padding, residual, relu, stamp):
+    def run(self, x, conv_weight, conv_bias, bn, stride, padding, residual, relu, stamp, groups=1):
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
-        desc = make_desc(x.shape, conv_weight.shape, stride, padding, _dtype_code(x))
+        if groups > 1 and groups == x.shape[1]:
+            return None                                   # depthwise: own kernels, not folded
+        desc = make_desc(x.shape, conv_weight.shape, stride, padding, _dtype_code(x), groups)
         if not lib.cnk_conv2d_fwd_act_supported(ctypes.byref(desc)):
             return None
         key = (stamp, desc.dtype, x.device)

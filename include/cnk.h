@@ -33,14 +33,19 @@ extern "C" {
 enum { CNK_F32 = 0, CNK_BF16 = 1 };
 enum { CNK_PASS_FWD = 0, CNK_PASS_DGRAD = 1, CNK_PASS_WGRAD = 2 };
 
-/* One nn.Conv2d as the reference factory builds it: groups=1, dilation=1, zero padding
- * (basemodel.py:966-979; kwargs forwarded verbatim at :974). */
+/* One nn.Conv2d as the reference factory builds it: dilation=1, zero padding (basemodel.py:966-979;
+ * kwargs forwarded verbatim at :974).  groups: 0 or 1 = dense.  groups > 1 (ResNeXt's cardinality,
+ * resnext.py:82-96) needs Cin == Cout, Cin % 64 == 0 and a group width Cin/groups that
+ * divides 64: each 64-channel chunk of the output depends only on the same chunk of the input, so the
+ * implicit-GEMM kernels run it as a block-diagonal 64 -> 64 conv per chunk (weights [Cout][Cin/groups][kh][kw]).
+ * groups == Cin is the depthwise case and has its own entry points (cnk_dwconv2d_*). */
 typedef struct cnk_conv_desc {
     int32_t N, H, W, Cin;      /* input  x[N][H][W][Cin]              */
-    int32_t Cout, kh, kw;      /* weight w[Cout][Cin][kh][kw] (fp32)  */
+    int32_t Cout, kh, kw;      /* weight w[Cout][Cin/groups][kh][kw] (fp32)  */
     int32_t stride_h, stride_w;
     int32_t pad_h, pad_w;
     int32_t dtype;             /* element type of x, y, dy, dx        */
+    int32_t groups;
 } cnk_conv_desc;
 
 int cnk_version(void);
@@ -71,7 +76,7 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
 typedef struct cnk_pack_job {
     const float* w;            /* master weight [Cout][Cin][KH][KW]            */
     void* out;                 /* image: [R][ntaps][Cred], R/Cred = Cout/Cin or swapped */
-    int32_t Cout, Cin, KH, KW, ntaps, transpose, dtype, pad_;
+    int32_t Cout, Cin, KH, KW, ntaps, transpose, dtype, groups;   /* groups <= 1: dense */
     int8_t kh[32], kw[32];     /* tap list                                      */
 } cnk_pack_job;
 int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,

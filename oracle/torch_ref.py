@@ -377,5 +377,37 @@ class RefMobileNetV1(RefBaseModel):                                # mobilenet_v
             self.init_params()
 
 
+class RefResNeXt(RefBaseModel):                                    # resnext.py:16-118 (bottleneck kinds)
+    config = {
+        '26': [(128, 2, 1), (256, 2, 2), (512, 2, 2), (1024, 2, 2)],
+        '50': [(128, 3, 1), (256, 4, 2), (512, 6, 2), (1024, 3, 2)],
+        '101': [(128, 3, 1), (256, 4, 2), (512, 23, 2), (1024, 3, 2)],
+        '152': [(128, 3, 1), (256, 8, 2), (512, 36, 2), (1024, 3, 2)],
+    }
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        mods = [self.conv2d_block(num_filters=64, kernel_size=7, stride=2, padding=3),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1)]
+        for num_filters, num_repeat, stride in self.config[str(setting.kind)]:
+            mods += [self.residual_block(num_filters, 2, stride)]
+            for _ in range(1, num_repeat):
+                mods += [self.residual_block(num_filters, 2)]
+        self.features = nn.Sequential(*mods)                         # no global pool (resnext.py:51-79)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+    def residual_block(self, num_filters, expansion, stride=1, cardinality=32):     # resnext.py:81-96
+        if stride != 1 or self.in_channels != num_filters * expansion:
+            dim_synch = self.conv2d_block(self.in_channels, num_filters * expansion, set_output=False,
+                                          activation=False, kernel_size=1, stride=stride)
+        else:
+            dim_synch = None
+        return RefResBottleneck(self, num_filters=num_filters, expansion=expansion, dim_synch=dim_synch,
+                                stride=stride, groups=cardinality)
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
-          'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1}
+          'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt}

@@ -40,6 +40,7 @@ def import_reference():
     import basemodel
     import mobilenet_v1
     import resnet
+    import resnext
     import settings
     import vggnet
     from torch.optim.lr_scheduler import ReduceLROnPlateau as _RLP
@@ -50,6 +51,7 @@ def import_reference():
 
     basemodel.ReduceLROnPlateau = _RLPCompat
     basemodel.mobilenet_v1 = mobilenet_v1          # carried along for make_models / make_dwblocks
+    basemodel.resnext = resnext
     return settings, basemodel, resnet, vggnet
 
 
@@ -226,7 +228,8 @@ def make_models(settings, basemodel, resnet, vggnet):
              ('resnet18', resnet.ResNet, 18, (3, 32, 32), True, 16),
              ('vgg11', vggnet.VGGNet, 11, (3, 32, 32), True, 16),
              ('convnet', basemodel.ConvNet, 0, (1, 28, 28), False, 8),
-             ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16)]
+             ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16),
+             ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)

@@ -641,3 +641,36 @@ def test_conv_random_shapes_vs_torch(case, dtype):
     assert rel_l2(host(wt.grad), wr.grad.numpy()) < (5e-5 if dtype == torch.float32 else 1.5e-2), 'wgrad'
     if bias:
         assert rel_l2(host(bt.grad), br.grad.numpy()) < t, 'dbias'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [(128, 32, 3, 1, 1, 14), (256, 32, 3, 2, 1, 13), (64, 2, 3, 1, 1, 9), (512, 32, 3, 1, 1, 7),
+                                 (128, 8, 1, 1, 0, 10), (1024, 32, 3, 2, 1, 6)], ids=lambda c: 'C%d-g%d-k%d-s%d-p%d-%d' % c)
+def test_grouped_conv_vs_torch(cfg, dtype):
+    """Grouped conv (ResNeXt cardinality, resnext.py:82-96) as a block-diagonal conv per 64-channel chunk on the
+    implicit-GEMM kernels: forward, dx, dw against torch fp64 (groups= in F.conv2d)."""
+    from convnets_amd import layers
+    C, groups, k, s, p, H = cfg
+    g = torch.Generator().manual_seed(C + groups + k + s)
+    N = 3
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(C, C // groups, k, k, generator=g) / np.sqrt(C // groups * k * k)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    conv = layers.Conv2d(C, C, kernel_size=k, stride=s, padding=p, groups=groups, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p, 1, groups)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy.double())
+    xt = dev(x.numpy(), dtype).requires_grad_(True)
+    y = conv(xt)
+    y.backward(dev(dy.numpy(), dtype))
+    torch.cuda.synchronize()
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(host(y), yr.detach().numpy()) < t, 'fwd'
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < t, 'dgrad'
+    assert rel_l2(host(conv.weight.grad), wr.grad.numpy()) < (2e-5 if dtype == torch.float32 else 1e-2), 'wgrad'

@@ -108,8 +108,10 @@ def test_factory_returns_stock_subclasses_and_tracks_shapes():
     assert isinstance(dwc, nn.Conv2d) and dwc.groups == 64 and tuple(dwc.weight.shape) == (64, 1, 3, 3)
     with pytest.raises(NotImplementedError):                                     # channel multiplier != 1
         net.conv2d_depthwise(num_filters=128, kernel_size=3)
-    with pytest.raises(NotImplementedError):                                     # general grouped conv
-        net.conv2d(num_filters=64, kernel_size=3, groups=2)
+    gc = net.conv2d(num_filters=64, kernel_size=3, groups=32, set_output=False)    # ResNeXt cardinality (resnext.py:82-96)
+    assert gc.groups == 32 and tuple(gc.weight.shape) == (64, 2, 3, 3)
+    with pytest.raises(NotImplementedError):                                     # group width 3 does not divide 64
+        net.conv2d(in_channels=96, num_filters=96, kernel_size=3, groups=32)
     with pytest.raises(TypeError):
         ca.Settings(kind=0, input_size=(1, 2, 2), num_classes=2, no_such_field=1)
 
