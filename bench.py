@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# The step uses four HIP streams (compute, weight gradients, gradient all-reduce, RCCL's own); the runtime
+# multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue
+# serialise.  Must be set before the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

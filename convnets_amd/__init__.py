@@ -2,6 +2,13 @@
 factory of milan-pavlovic-ai/ConvNets.  The compute lives in libcnk.so
 (include/cnk.h, convnets_amd/csrc/); this package is the host-side mirror of the reference's
 factory, models and training step.  There is no CPU fallback."""
+import os as _os
+
+# compute / weight-gradient / all-reduce / RCCL streams each need their own hardware queue (the HIP runtime
+# maps streams onto GPU_MAX_HW_QUEUES queues, default 4, and streams sharing a queue serialise); effective
+# only if this import happens before the first HIP call of the process
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 from .settings import Settings, DeviceMngr                      # noqa: F401
 from .basemodel import MultiClassBaseModel                      # noqa: F401
 from .resnet import ResNet, ResBlock, ResBottleneck             # noqa: F401
