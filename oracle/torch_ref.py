@@ -409,5 +409,49 @@ class RefResNeXt(RefBaseModel):                                    # resnext.py:
                                 stride=stride, groups=cardinality)
 
 
+class RefInceptionBlock(nn.Module):                                # inceptionnet_v1.py:99-143
+    def __init__(self, network, c1, c3r, c3, c5r, c5, pp):
+        super().__init__()
+        self.branch1 = network.conv2d_block(network.in_channels, c1, set_output=False, kernel_size=1)
+        self.branch2 = nn.Sequential(
+            network.conv2d_block(network.in_channels, c3r, set_output=False, kernel_size=1),
+            network.conv2d_block(c3r, c3, set_output=False, kernel_size=3, padding=1))
+        self.branch3 = nn.Sequential(
+            network.conv2d_block(network.in_channels, c5r, set_output=False, kernel_size=1),
+            network.conv2d_block(c5r, c5, set_output=False, kernel_size=5, padding=2))
+        self.branch4 = nn.Sequential(
+            network.maxpool2d(set_output=True, kernel_size=3, stride=1, padding=1),
+            network.conv2d_block(num_filters=pp, set_output=True, kernel_size=1))
+        network.in_channels = c1 + c3 + c5 + pp
+
+    def forward(self, x):
+        return torch.cat([self.branch1(x), self.branch2(x), self.branch3(x), self.branch4(x)], dim=1)
+
+
+class RefInceptionNetV1(RefBaseModel):                             # inceptionnet_v1.py:16-97
+    def __init__(self, setting):
+        super().__init__(setting)
+        B = RefInceptionBlock
+        mods = [self.conv2d_block(num_filters=64, kernel_size=7, stride=2, padding=3),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1),
+                self.conv2d_block(num_filters=64, kernel_size=1),
+                self.conv2d_block(num_filters=192, kernel_size=3, padding=1),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1),
+                B(self, 64, 96, 128, 16, 32, 32), B(self, 128, 128, 192, 32, 96, 64),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1),
+                B(self, 192, 96, 208, 16, 48, 64), B(self, 160, 112, 224, 24, 64, 64),
+                B(self, 128, 128, 256, 24, 64, 64), B(self, 112, 144, 288, 32, 64, 64),
+                B(self, 256, 160, 320, 32, 128, 128),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1),
+                B(self, 256, 160, 320, 32, 128, 128), B(self, 384, 192, 384, 48, 128, 128),
+                self.adapt_avgpool2d(output_size=1)]
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
-          'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt}
+          'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt,
+          'inception': RefInceptionNetV1}

@@ -38,6 +38,7 @@ def import_reference():
     if REF not in sys.path:
         sys.path.insert(0, REF)
     import basemodel
+    import inceptionnet_v1
     import mobilenet_v1
     import resnet
     import resnext
@@ -52,6 +53,7 @@ def import_reference():
     basemodel.ReduceLROnPlateau = _RLPCompat
     basemodel.mobilenet_v1 = mobilenet_v1          # carried along for make_models / make_dwblocks
     basemodel.resnext = resnext
+    basemodel.inceptionnet_v1 = inceptionnet_v1
     return settings, basemodel, resnet, vggnet
 
 
@@ -229,7 +231,8 @@ def make_models(settings, basemodel, resnet, vggnet):
              ('vgg11', vggnet.VGGNet, 11, (3, 32, 32), True, 16),
              ('convnet', basemodel.ConvNet, 0, (1, 28, 28), False, 8),
              ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16),
-             ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16)]
+             ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16),
+             ('inception', basemodel.inceptionnet_v1.InceptionNetV1, 1, (3, 32, 32), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)
