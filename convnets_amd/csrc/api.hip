@@ -11,6 +11,8 @@
 // ---- kernel families (other translation units) ---------------------------------------------------
 bool igemm_supported(const cnk_conv_desc* d, int pass);
 bool igemm_grouped_ok(const cnk_conv_desc* d);
+bool igemm_on_grid(const cnk_conv_desc* d, int pass);
+size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
@@ -163,7 +165,15 @@ int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo) {
 size_t cnk_conv2d_packed_bytes(const cnk_conv_desc* d, int pass) {
     size_t n = (size_t)d->Cout * d->Cin * d->kh * d->kw;
     if (pass != CNK_PASS_FWD && pass != CNK_PASS_DGRAD) return 0;
-    if (igemm_supported(d, pass)) return n * esize(d->dtype);
+    if (igemm_supported(d, pass)) {
+        if (pass == CNK_PASS_FWD) return igemm_image_elems(d, pass, d->kh * d->kw) * esize(d->dtype);
+        DgradClass cls[16];
+        if (d->stride_h * d->stride_w > 16) return 0;
+        int nc = dgrad_classes(d, cls);
+        size_t e = 0;
+        for (int c = 0; c < nc; ++c) e += igemm_image_elems(d, pass, cls[c].ntaps);
+        return e * esize(d->dtype);
+    }
     if (pass == CNK_PASS_FWD && rowpatch_supported(d)) return rowpatch_packed_bytes(d);
     if (pass == CNK_PASS_FWD && smallc_supported(d)) return smallc_packed_bytes(d);
     if (pass == CNK_PASS_DGRAD && smallc_dgrad_packed_bytes(d)) {
@@ -212,7 +222,7 @@ int cnk_conv2d_pack_weights(const cnk_conv_desc* d, const float* w, void* w_fwd,
             for (int c = 0; c < nc; ++c) {
                 CNK_CHECK_ARG(cls[c].ntaps <= 32, "cnk_conv2d_pack_weights: too many taps");
                 if (int rc = pack_taps(d, w, (char*)w_dgrad + off * esize(d->dtype), cls[c].ntaps, cls[c].kh, cls[c].kw, 1, S(stream))) return rc;
-                off += (size_t)cls[c].ntaps * d->Cin * d->Cout;
+                off += igemm_image_elems(d, CNK_PASS_DGRAD, cls[c].ntaps);
             }
         } else if (smallc_dgrad_packed_bytes(d)) {
             size_t a = (smallc_dgrad_packed_bytes(d) + 255) & ~(size_t)255;
@@ -239,13 +249,13 @@ int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, vo
         return true;
     };
     if (w_fwd) {
-        if (!igemm_supported(d, CNK_PASS_FWD)) return -1;            // only the implicit-GEMM images batch
+        if (!igemm_supported(d, CNK_PASS_FWD) || !igemm_on_grid(d, CNK_PASS_FWD)) return -1;   // only unpadded implicit-GEMM images batch
         signed char kh[32], kw[32];
         for (int t = 0; t < d->kh * d->kw; ++t) { kh[t] = (signed char)(t / d->kw); kw[t] = (signed char)(t % d->kw); }
         if (!add(w_fwd, d->kh * d->kw, kh, kw, 0)) return -1;
     }
     if (w_dgrad) {
-        if (!igemm_supported(d, CNK_PASS_DGRAD) || d->stride_h * d->stride_w > 16) return -1;
+        if (!igemm_supported(d, CNK_PASS_DGRAD) || !igemm_on_grid(d, CNK_PASS_DGRAD) || d->stride_h * d->stride_w > 16) return -1;
         DgradClass cls[16];
         int nc = dgrad_classes(d, cls);
         size_t off = 0;

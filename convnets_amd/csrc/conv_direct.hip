@@ -122,6 +122,7 @@ struct PackParams {
     const float* w;
     void* out;
     int Cout, Cin, KH, KW, ntaps, transpose, groups;
+    int Rpad, Cpad;          // image [Rpad][ntaps][Cpad], zero outside [R][..][Cred] (off-grid channel counts)
     signed char kh[32], kw[32];
 };
 // master weight value for dense image position (co, ci, tap): with groups > 1 the master tensor is
@@ -135,14 +136,17 @@ __device__ __forceinline__ float master_w(const float* __restrict__ w, int co, i
 }
 template <typename T> __global__ void pack_kernel(const PackParams p) {
     int R = p.transpose ? p.Cin : p.Cout, Cred = p.transpose ? p.Cout : p.Cin;
-    size_t total = (size_t)R * p.ntaps * Cred;
+    size_t total = (size_t)p.Rpad * p.ntaps * p.Cpad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % Cred);
-        size_t q = i / Cred;
+        int c = (int)(i % p.Cpad);
+        size_t q = i / p.Cpad;
         int t = (int)(q % p.ntaps), r = (int)(q / p.ntaps);
-        int co = p.transpose ? c : r, ci = p.transpose ? r : c;
-        float v = master_w(p.w, co, ci, p.Cout, p.Cin, p.KH, p.KW, p.kh[t], p.kw[t], p.groups);
+        float v = 0.f;
+        if (r < R && c < Cred) {
+            int co = p.transpose ? c : r, ci = p.transpose ? r : c;
+            v = master_w(p.w, co, ci, p.Cout, p.Cin, p.KH, p.KW, p.kh[t], p.kw[t], p.groups);
+        }
         ((T*)p.out)[i] = from_f32<T>(v);
     }
 }
@@ -305,7 +309,11 @@ int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, cons
     p.w = w; p.out = out; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->kh; p.KW = d->kw;
     p.ntaps = ntaps; p.transpose = transpose; p.groups = conv_groups(d);
     for (int t = 0; t < ntaps; ++t) { p.kh[t] = kh[t]; p.kw[t] = kw[t]; }
-    size_t total = (size_t)d->Cout * d->Cin * ntaps;
+    const int kstep = d->dtype == CNK_BF16 ? 64 : 32;
+    const int R = transpose ? d->Cin : d->Cout, Cred = transpose ? d->Cout : d->Cin;
+    p.Rpad = ceil_div(R, 64) * 64;                       // == R, Cred on the tile grid
+    p.Cpad = ceil_div(Cred, kstep) * kstep;
+    size_t total = (size_t)p.Rpad * p.Cpad * ntaps;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
     if (d->dtype == CNK_BF16) hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(256), 0, s, p);

@@ -43,6 +43,7 @@ struct GatherParams {
     int bnf_relu, bnf_tile0; // tile0: first slice of this launch (stride-parity classes)
     int relu;                // inference epilogue: dst = max(conv + bias [+ addend], 0)
     int chunked;             // grouped conv: n-tile t (64 wide) reduces over channel chunk [64t, 64t+64) only
+    int Cpad;                // K length of one tap in the weight image (C rounded up to the K step; == C on the grid)
     int N, IH, IW, C;
     int OH, OW;
     int FH, FW, Nout;
@@ -81,7 +82,8 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 
 // Shared epilogue of the implicit-GEMM kernels (see the comment inside): bias, LDS-staged
 // coalesced row stores, optional gradient addend (+ReLU mask), optional BN statistics partials.
-template <typename T, int BN>
+// EDGE: Nout is any multiple of one 16-byte vector (not of BN): the last n-tile has ncols < BN valid columns.
+template <typename T, int BN, bool EDGE = false>
 __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned char* smem,
                                                const int* row_dst, f32x16 (&acc)[2][BN / 64],
                                                int tile_m, int tile_n, int tid, int wm, int wn,
@@ -101,6 +103,8 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     unsigned char* Cs = smem + BM * sizeof(int);
     unsigned char* dst = (unsigned char*)p.dst;
     const int crow = tid / CPR, cc = tid - crow * CPR;
+    const int ncols = EDGE ? p.Nout - tile_n * BN : BN;          // valid columns of this n-tile
+    const bool colok = !EDGE || cc * PER16 < ncols;              // this thread's 16-byte column chunk exists
     float s8[PER16], q8[PER16];
 #pragma unroll
     for (int e = 0; e < PER16; ++e) s8[e] = q8[e] = 0.f;
@@ -116,7 +120,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
-                if (p.bias) {
+                if (p.bias && (!EDGE || col < ncols)) {          // (Nout % 4 == 0: a group of four is all in or all out)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += p.bias[tile_n * BN + col + e];
                 }
@@ -136,7 +140,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     float bmu[PER16], bsc[PER16], bsf[PER16];
     const bool bnf = p.bnf_x != nullptr;
     const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
-    if (bnf) {
+    if (bnf && colok) {
         const int c0 = tile_n * BN + cc * PER16;
 #pragma unroll
         for (int e = 0; e < PER16; ++e) {
@@ -152,7 +156,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
         for (int ps = 0; ps < NP; ++ps) {
             const int row = ps * RPP + crow;
             const int pix = row_dst[row];
-            if (pix >= 0) {
+            if (pix >= 0 && colok) {
                 Vec16<T> v;
                 v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
                 const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
@@ -178,7 +182,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
         int pixs[GP];
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
-            const int pix = row_dst[(g0 + u) * RPP + crow];
+            const int pix = colok ? row_dst[(g0 + u) * RPP + crow] : -1;
             pixs[u] = pix;
             am[u] = km[u] = 0xFFu;
             if (pix >= 0) {
@@ -256,7 +260,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
             red[(RPP + crow) * BN + cc * PER16 + e] = q8[e];
         }
         __syncthreads();
-        if (tid < BN) {
+        if (tid < BN && (!EDGE || tid < ncols)) {
             float S = 0.f, Q = 0.f;
 #pragma unroll 4
             for (int r = 0; r < RPP; ++r) {
@@ -281,7 +285,9 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     }
 }
 
-template <typename T, int BN>
+// EDGE: channel counts that are multiples of one 16-byte vector but not of the K step / BN: chunks past C fetch
+// zeros, the weight image is zero-padded to [tiles_n*BN][taps][Cpad], the epilogue skips the missing columns.
+template <typename T, int BN, bool EDGE = false>
 __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
     constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
@@ -338,10 +344,10 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     const T* src = (const T*)p.src;
     const T* wpk = (const T*)p.wpk;
     // grouped conv (block-diagonal image): this 64-wide n-tile only sees its own 64 input channels
-    const int csteps = p.chunked ? 64 / KSTEP : p.C / KSTEP;
+    const int csteps = p.chunked ? 64 / KSTEP : p.Cpad / KSTEP;
     const int cs0 = p.chunked ? tile_n * (64 / KSTEP) : 0;
     const int nk = p.ntaps * csteps;
-    const size_t wrow = (size_t)p.ntaps * p.C;
+    const size_t wrow = (size_t)p.ntaps * p.Cpad;
 
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -392,7 +398,8 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
             const int r = lrow + 32 * i;
             const int c = chunk ^ ((r >> 1) & 7);
             const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
-            const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW &&
+                            (!EDGE || cb + c * PER16 < p.C);
             const T* gp = ok ? src + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + cb + c * PER16
                              : (const T*)cnk_zero16;
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
         for (int i = 0; i < B_LOADS; ++i) {
             const int r = lrow + 32 * i;
             const int c = chunk ^ ((r >> 1) & 7);
-            const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.C + cb + c * PER16;
+            const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.Cpad + cb + c * PER16;
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
         }
     };
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     }
     if (nk == 0) __syncthreads();
 
-    igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
+    igemm_epilogue<T, BN, EDGE>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
 
 // 3x3 / stride 1 / "same" convolutions (forward, and the data gradient of such a conv): halo reuse.
@@ -707,13 +714,13 @@ __global__ __launch_bounds__(256, 2) void igemm_halo3x3_pf_kernel(const GatherPa
     igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
 
-template <typename T, int BN> int launch_gather(const GatherParams& p, hipStream_t s) {
+template <typename T, int BN, bool EDGE = false> int launch_gather(const GatherParams& p, hipStream_t s) {
     size_t pipe = BM * 128 + BN * 128;
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
     size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);     // aliases the staged tile
     if (red > epi) epi = red;
     size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
-    hipLaunchKernelGGL((igemm_gather_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
 }
@@ -778,6 +785,14 @@ template <typename T, int BN> int launch_halo(const GatherParams& p, hipStream_t
 
 template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     int tiles_m = ceil_div(p.M, BM);
+    constexpr int KS = 8 * ElemTraits<T>::PER16;
+    if (p.Cpad == 0) p.Cpad = ceil_div(p.C, KS) * KS;
+    if (p.C % KS || p.Nout % 64) {                   // off the tile grid: 64-wide tiles with edge handling
+        p.tiles_n = ceil_div(p.Nout, 64);
+        p.tiles_total = tiles_m * p.tiles_n;
+        if (p.tiles_total == 0) return 0;
+        return launch_gather<T, 64, true>(p, s);
+    }
     bool use128 = !p.chunked && pick_bn128(p.M, p.Nout);
     int bn = use128 ? 128 : 64;
     p.tiles_n = p.Nout / bn;
@@ -803,12 +818,30 @@ bool igemm_grouped_ok(const cnk_conv_desc* d) {
 
 bool igemm_supported(const cnk_conv_desc* d, int pass) {
     if (conv_groups(d) > 1 && !igemm_grouped_ok(d)) return false;
+    int kstep = d->dtype == CNK_BF16 ? 64 : 32, vec = kstep / 8;
+    int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout;
+    int nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
+    if (d->kh * d->kw > MAX_TAPS) return false;
+    if (cred % kstep == 0 && nout % 64 == 0) return true;          // on the tile grid
+    // off the grid (Inception / SqueezeNet / MobileNet widths): any multiple of one 16-byte vector, as long as
+    // the zero padding of K stays below 2x; narrower layers keep the small-channel kernels
+    if (conv_groups(d) > 1) return false;
+    return cred % vec == 0 && nout % vec == 0 && cred >= kstep / 2 && nout >= 16;
+}
+
+// elements of the (zero-padded) weight image of one pass: [ceil(nout/64)*64][taps][ceil(cred/kstep)*kstep]
+size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps) {
     int kstep = d->dtype == CNK_BF16 ? 64 : 32;
     int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout;
     int nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
-    if (cred % kstep || nout % 64) return false;
-    if (d->kh * d->kw > MAX_TAPS) return false;
-    return true;
+    return (size_t)(ceil_div(nout, 64) * 64) * ntaps * (ceil_div(cred, kstep) * kstep);
+}
+
+bool igemm_on_grid(const cnk_conv_desc* d, int pass) {
+    int kstep = d->dtype == CNK_BF16 ? 64 : 32;
+    int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout;
+    int nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
+    return cred % kstep == 0 && nout % 64 == 0;
 }
 
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
@@ -902,7 +935,7 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
         p.ntaps = k.ntaps;
         for (int t = 0; t < k.ntaps; ++t) { p.dh[t] = k.dh[t]; p.dw[t] = k.dw[t]; }
         p.M = d->N * k.OH * k.OW;
-        woff += (size_t)k.ntaps * d->Cin * d->Cout;
+        woff += igemm_image_elems(d, CNK_PASS_DGRAD, k.ntaps);
         if (p.M == 0) continue;
         if (bn) {
             p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;

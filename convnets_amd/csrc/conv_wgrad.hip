@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
             int idx = tid + 256 * i, r = idx / CPRA, c = idx - r * CPRA;
             int m = m0 + r;
             u32x4 v = {0, 0, 0, 0};
-            if (m < p.M) v = *(const u32x4*)(dy + (size_t)m * p.Cout + tile_co * BMW + c * PER16);
+            // (channel bound: Cout / Cin may be any multiple of one vector; columns past them are zeros)
+            if (m < p.M && tile_co * BMW + c * PER16 < p.Cout)
+                v = *(const u32x4*)(dy + (size_t)m * p.Cout + tile_co * BMW + c * PER16);
             ra[i] = v;
         }
 #pragma unroll
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
             int idx = tid + 256 * i, r = idx / CPRB, c = idx - r * CPRB;
             int m = m0 + r;
             u32x4 v = {0, 0, 0, 0};
-            if (m < p.M) {
+            if (m < p.M && tile_ci * BNW + c * PER16 < p.Cin) {
                 uint32_t img = fd_div(m, p.fd_howo);
                 uint32_t rem = m - img * p.fd_howo.d;
                 uint32_t ho = fd_div(rem, p.fd_wo);
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
             for (int r = 0; r < 16; ++r) {
                 int co = tile_co * BMW + wm * (BMW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 int ci = slab_ci0 + wn * (BNW / 2) + j * 32 + l31;
-                slab[((size_t)co * p.ntaps + tap) * slab_row + ci] = acc[i][j][r];
+                if (co < p.Cout && ci < slab_row) slab[((size_t)co * p.ntaps + tap) * slab_row + ci] = acc[i][j][r];
             }
 }
 
@@ -286,7 +288,10 @@ int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_st
 bool igemm_grouped_ok(const cnk_conv_desc* d);
 bool wgrad_mfma_supported(const cnk_conv_desc* d) {
     if (conv_groups(d) > 1 && !igemm_grouped_ok(d)) return false;
-    return d->Cin % 64 == 0 && d->Cout % 64 == 0;
+    if (d->Cin % 64 == 0 && d->Cout % 64 == 0) return true;
+    // off the tile grid: any multiple of one 16-byte vector (zero-filled columns), not for the tiny layers
+    const int vec = d->dtype == CNK_BF16 ? 8 : 4;
+    return conv_groups(d) == 1 && d->Cin % vec == 0 && d->Cout % vec == 0 && d->Cin >= 16 && d->Cout >= 16;
 }
 
 // Tile shape and split count shared by the workspace query and the launch.
@@ -319,7 +324,8 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
     const bool grouped = conv_groups(d) > 1;
     *bmw = (!grouped && d->Cout % 128 == 0) ? 128 : 64;
     *bnw = (!grouped && d->Cin % 128 == 0) ? 128 : 64;
-    int tiles = grouped ? (d->Cout / 64) * d->kh * d->kw : (d->Cout / *bmw) * (d->Cin / *bnw) * d->kh * d->kw;
+    int tiles = grouped ? (d->Cout / 64) * d->kh * d->kw
+                        : ceil_div(d->Cout, *bmw) * ceil_div(d->Cin, *bnw) * d->kh * d->kw;
     *ksteps = ceil_div(M, kp);
     // The kernel is resident at 2 workgroups per CU (80 KiB LDS each): 512 slots on 256 CUs.  Fill
     // them exactly once -- tiles*splits just ABOVE a multiple of 512 costs a whole extra round.
@@ -352,7 +358,7 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
     p.KH = d->kh; p.KW = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
     p.M = d->N * Ho * Wo;
-    p.tiles_co = d->Cout / bmw; p.tiles_ci = grouped ? 1 : d->Cin / bnw; p.ntaps = d->kh * d->kw;
+    p.tiles_co = ceil_div(d->Cout, bmw); p.tiles_ci = grouped ? 1 : ceil_div(d->Cin, bnw); p.ntaps = d->kh * d->kw;
     p.diag = grouped;
     p.fd_howo = make_fastdiv(Ho * Wo);
     p.fd_wo = make_fastdiv(Wo);
