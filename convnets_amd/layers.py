@@ -130,6 +130,8 @@ class Dropout(nn.Dropout):
             return x
         if self.p >= 1.0:
             return x * 0.0
+        if x.dtype != torch.float32:              # feature-map dropout (SqueezeNet's head): kernel computes in fp32
+            return ops.DropoutFn.apply(x.float(), self.p).to(x.dtype)
         return ops.DropoutFn.apply(x, self.p)
 
 

@@ -334,10 +334,11 @@ class Conv2dFn(torch.autograd.Function):
         _require_gpu(x)
         lib = _lib.load()
         ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) bn_partial
+        x_needs_grad = x.requires_grad        # before any layout copy made here (forward runs under no_grad)
         x = _nhwc(x)
         w = weight if weight.is_contiguous() else weight.contiguous()
         desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x), groups)
-        need_dgrad = x.requires_grad
+        need_dgrad = x_needs_grad
         w_fwd, w_dgrad = packed.get(w, desc, need_dgrad)
         Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
         lib.cnk_conv2d_out_hw(ctypes.byref(desc), ctypes.byref(Ho), ctypes.byref(Wo))
@@ -353,8 +354,8 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.desc, ctx.w_dgrad, ctx.has_bias = desc, w_dgrad, bias is not None
         ctx.params = (weight, bias)
-        ctx.link = link if x.requires_grad else None
-        ctx.bn_rec = bn_rec if (x.requires_grad and BN_BWD_FUSE) else None
+        ctx.link = link if x_needs_grad else None
+        ctx.bn_rec = bn_rec if (x_needs_grad and BN_BWD_FUSE) else None
         if want_bn_partial:
             if partial is None:
                 partial = torch.empty(0, device=x.device)         # placeholder: "not available"
@@ -455,6 +456,8 @@ class BatchNormActFn(torch.autograd.Function):
                 partial=None, link=None, rec=None):
         _require_gpu(x)
         lib = _lib.load()
+        x_needs_grad = x.requires_grad
+        res_needs_grad = residual is not None and residual.requires_grad
         x = _nhwc(x)
         if residual is not None:
             residual = _nhwc(residual)
@@ -472,7 +475,7 @@ class BatchNormActFn(torch.autograd.Function):
         # with a residual operand the ReLU mask cannot be re-derived from x alone: keep it as a
         # packed bit mask (1/16 of y's bytes) for the backward instead of re-reading y twice
         mask = None
-        if relu and residual is not None and x.requires_grad:
+        if relu and residual is not None and x_needs_grad:
             mask = torch.empty(lib.cnk_bn_mask_bytes(M, C, _dtype_code(x)), dtype=torch.uint8, device=x.device)
         check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mask),
                                    _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
@@ -483,9 +486,9 @@ class BatchNormActFn(torch.autograd.Function):
                               mask, gamma, beta, save_mean, save_invstd)
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.params = (gamma, beta)
-        ctx.link = link if (residual is not None and residual.requires_grad) else None
+        ctx.link = link if res_needs_grad else None
         ctx.rec = None
-        if rec is not None and x.requires_grad and (mask is not None or residual is None):
+        if rec is not None and x_needs_grad and (mask is not None or residual is None):
             # what a consumer conv needs to run this layer's backward reduction in its dgrad epilogue
             rec.x, rec.mean, rec.invstd, rec.gamma, rec.beta = x, save_mean, save_invstd, gamma.detach(), beta.detach()
             rec.mask, rec.relu = mask, bool(relu)
@@ -604,12 +607,13 @@ class MaxPool2dFn(torch.autograd.Function):
     def forward(ctx, x, ksize, stride, padding):
         _require_gpu(x)
         lib = _lib.load()
+        x_needs_grad = x.requires_grad
         x = _nhwc(x)
         N, C, H, W = x.shape
         Ho = (H + 2 * padding[0] - ksize[0]) // stride[0] + 1
         Wo = (W + 2 * padding[1] - ksize[1]) // stride[1] + 1
         y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=CL)
-        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device) if x.requires_grad else None
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device) if x_needs_grad else None
         check(lib.cnk_maxpool2d_fwd(_p(x), _p(y), _p(idx), N, H, W, C, ksize[0], ksize[1], stride[0],
                                     stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
         ctx.save_for_backward(idx)
@@ -784,7 +788,7 @@ class DropoutFn(torch.autograd.Function):
         lib = _lib.load()
         if x.dtype != torch.float32:
             raise ValueError('dropout: the head runs in fp32')
-        x = x.contiguous()
+        x = x if (x.is_contiguous() or x.is_contiguous(memory_format=CL)) else x.contiguous()
         y = torch.empty_like(x)
         mask = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
         _dropout_calls[0] += 1
@@ -792,13 +796,14 @@ class DropoutFn(torch.autograd.Function):
                                   torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_calls[0], _stream()))
         ctx.save_for_backward(mask)
         ctx.p = float(p)
+        ctx.fmt = CL if (x.dim() == 4 and not x.is_contiguous()) else torch.contiguous_format
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         (mask,) = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = dy.contiguous(memory_format=ctx.fmt)
         dx = torch.empty_like(dy)
         check(lib.cnk_dropout_bwd(_p(dy), _p(mask), _p(dx), dy.numel(), ctx.p, _stream()))
         return dx, None

@@ -452,6 +452,51 @@ class RefInceptionNetV1(RefBaseModel):                             # inceptionne
             self.init_params()
 
 
+class RefFire(nn.Module):                                          # squeezenet.py:122-152
+    def __init__(self, network, squeeze_num, expand_1x1_num, expand_3x3_num):
+        super().__init__()
+        self.squeeze = network.conv2d_block(num_filters=squeeze_num, kernel_size=1)
+        self.expand_1x1 = network.conv2d_block(network.in_channels, expand_1x1_num, set_output=False, kernel_size=1)
+        self.expand_3x3 = network.conv2d_block(network.in_channels, expand_3x3_num, set_output=True, kernel_size=3,
+                                               padding=1)
+        network.in_channels = expand_1x1_num + expand_3x3_num
+
+    def forward(self, x):
+        x = self.squeeze(x)
+        return torch.cat([self.expand_1x1(x), self.expand_3x3(x)], dim=1)
+
+
+class RefSqueezeNet(RefBaseModel):                                 # squeezenet.py:16-120
+    config = {
+        '1.0': [('conv', 96, 7, 2), ('maxpool', 3, 2), ('fire', 16, 64, 64), ('fire', 16, 64, 64), ('fire', 32, 128, 128),
+                ('maxpool', 3, 2), ('fire', 32, 128, 128), ('fire', 48, 192, 192), ('fire', 48, 192, 192),
+                ('fire', 64, 256, 256), ('maxpool', 3, 2), ('fire', 64, 256, 256)],
+        '1.1': [('conv', 64, 3, 2), ('maxpool', 3, 2), ('fire', 16, 64, 64), ('fire', 16, 64, 64), ('maxpool', 3, 2),
+                ('fire', 32, 128, 128), ('fire', 32, 128, 128), ('maxpool', 3, 2), ('fire', 48, 192, 192),
+                ('fire', 48, 192, 192), ('fire', 64, 256, 256), ('fire', 64, 256, 256)],
+    }
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        mods = []
+        for cfg in self.config[str(setting.kind)]:
+            if cfg[0] == 'fire':
+                mods.append(RefFire(self, *cfg[1:]))
+            elif cfg[0] == 'maxpool':
+                mods.append(self.maxpool2d(kernel_size=cfg[1], stride=cfg[2]))
+            else:
+                mods.append(self.conv2d_block(num_filters=cfg[1], kernel_size=cfg[2], stride=cfg[3]))
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        self.conv2d_block(num_filters=setting.num_classes, kernel_size=1),
+                                        self.adapt_avgpool2d(output_size=1))
+        if setting.init_params:
+            self.init_params()
+
+    def forward(self, x):
+        return torch.flatten(self.classifier(self.features(x)), start_dim=1)
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
           'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt,
-          'inception': RefInceptionNetV1}
+          'inception': RefInceptionNetV1, 'squeezenet': RefSqueezeNet}

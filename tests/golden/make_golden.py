@@ -42,6 +42,7 @@ def import_reference():
     import mobilenet_v1
     import resnet
     import resnext
+    import squeezenet
     import settings
     import vggnet
     from torch.optim.lr_scheduler import ReduceLROnPlateau as _RLP
@@ -54,6 +55,7 @@ def import_reference():
     basemodel.mobilenet_v1 = mobilenet_v1          # carried along for make_models / make_dwblocks
     basemodel.resnext = resnext
     basemodel.inceptionnet_v1 = inceptionnet_v1
+    basemodel.squeezenet = squeezenet
     return settings, basemodel, resnet, vggnet
 
 
@@ -232,7 +234,8 @@ def make_models(settings, basemodel, resnet, vggnet):
              ('convnet', basemodel.ConvNet, 0, (1, 28, 28), False, 8),
              ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16),
              ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16),
-             ('inception', basemodel.inceptionnet_v1.InceptionNetV1, 1, (3, 32, 32), True, 16)]
+             ('inception', basemodel.inceptionnet_v1.InceptionNetV1, 1, (3, 32, 32), True, 16),
+             ('squeezenet', basemodel.squeezenet.SqueezeNet, 1.1, (3, 64, 64), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)

@@ -674,3 +674,19 @@ def test_grouped_conv_vs_torch(cfg, dtype):
     assert rel_l2(host(y), yr.detach().numpy()) < t, 'fwd'
     assert rel_l2(host(xt.grad), xr.grad.numpy()) < t, 'dgrad'
     assert rel_l2(host(conv.weight.grad), wr.grad.numpy()) < (2e-5 if dtype == torch.float32 else 1e-2), 'wgrad'
+
+
+def test_conv_and_pool_backward_after_layout_copy():
+    """An NCHW-contiguous input that requires grad is re-laid to NHWC inside forward (under no_grad): the data
+    gradient / pool indices must still be produced (regression: requires_grad was read after the copy)."""
+    from convnets_amd import layers
+    g = torch.Generator().manual_seed(4)
+    conv = layers.Conv2d(64, 128, kernel_size=1, bias=False).cuda()
+    pool = layers.MaxPool2d(kernel_size=2, stride=2)
+    x = torch.randn(2, 64, 8, 8, generator=g).cuda().requires_grad_(True)        # plain NCHW, fp32
+    y = pool(conv(x * 1.0))
+    y.sum().backward()
+    torch.cuda.synchronize()
+    xr = x.detach().cpu().double().requires_grad_(True)
+    F.max_pool2d(F.conv2d(xr, conv.weight.detach().cpu().double()), 2, 2).sum().backward()
+    assert rel_l2(host(x.grad), xr.grad.numpy()) < 1e-5
