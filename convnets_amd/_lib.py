@@ -63,6 +63,8 @@ SIGNATURES = {
                                        ctypes.c_int, ctypes.c_int, _vp]),
     'cnk_bn_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                                   _vp, _i64, _i64, _i32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
+    'cnk_avgpool2d_fwd': (ctypes.c_int, [_vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
+    'cnk_avgpool2d_bwd': (ctypes.c_int, [_vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_maxpool2d_fwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_maxpool2d_bwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_relu_fwd': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp]),

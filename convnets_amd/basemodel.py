@@ -283,9 +283,11 @@ class MultiClassBaseModel(nn.Module):
             self.save_conv_outshape(layer)
         return layer
 
-    def avgpool2d(self, set_output=True, **kwargs):
-        raise NotImplementedError('avgpool2d (basemodel.py:1026-1033) is used only by DenseNet, '
-                                  'outside the hot path (SURVEY.md section 2, row 12)')
+    def avgpool2d(self, set_output=True, **kwargs):           # basemodel.py:1026-1033
+        layer = layers.AvgPool2d(**kwargs)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
 
     def adapt_avgpool2d(self, set_output=True, **kwargs):
         layer = layers.AdaptiveAvgPool2d(**kwargs)

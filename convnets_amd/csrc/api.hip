@@ -29,6 +29,7 @@ int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N
 int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax, float* row_loss_ws, int B, int N, hipStream_t s);
 int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
 int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s);
+int avgpool_dispatch(bool bwd, const void* a, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 size_t grad_clip_workspace_bytes();
 int grad_clip_norm(float* g, int64_t n, float max_norm, float* norm_out, float* ws, hipStream_t s);
 int grad_clip_value(float* g, int64_t n, float c, hipStream_t s);
@@ -400,6 +401,17 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
     // reduce pass (2 reads) + apply pass (2 reads, 1 write); a fused conv dgrad already did the first
     ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, (ext_partial ? 3.0 : 5.0) * (double)M * C * esize(dtype));
     return bn_bwd(dy, x, y, relu_mask, gamma, beta, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, accumulate, ext_partial, ext_slices, M, C, relu, dtype, (float*)workspace, S(stream));
+}
+
+int cnk_avgpool2d_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y, "cnk_avgpool2d_fwd: null pointer");
+    CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && H + 2 * ph >= kh && W + 2 * pw >= kw, "cnk_avgpool2d_fwd: bad geometry");
+    return avgpool_dispatch(false, x, y, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+}
+int cnk_avgpool2d_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+    CNK_CHECK_ARG(dy && dx, "cnk_avgpool2d_bwd: null pointer");
+    CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && H + 2 * ph >= kh && W + 2 * pw >= kw, "cnk_avgpool2d_bwd: bad geometry");
+    return avgpool_dispatch(true, dy, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
 }
 
 int cnk_maxpool2d_fwd(const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {

@@ -74,6 +74,74 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     }
 }
 
+// nn.AvgPool2d (count_include_pad=True, floor mode): y = sum over the window's in-image pixels / (kh*kw)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
+                                                          int64_t total) {
+    const int cols = p.C / VEC;
+    const float inv = 1.f / (float)(p.kh * p.kw);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t pix = fd_div((uint32_t)i, p.fd_cols), vc = (uint32_t)i - pix * cols;
+        uint32_t t = fd_div(pix, p.fd_wo), wo = pix - t * p.Wo;
+        uint32_t n = fd_div(t, p.fd_ho), ho = t - n * p.Ho;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        for (int r = 0; r < p.kh; ++r) {
+            int h = (int)ho * p.sh - p.ph + r;
+            if ((unsigned)h >= (unsigned)p.H) continue;
+            for (int q = 0; q < p.kw; ++q) {
+                int w = (int)wo * p.sw - p.pw + q;
+                if ((unsigned)w >= (unsigned)p.W) continue;
+                VL<T, VEC> v;
+                v.load(x + ((size_t)(n * p.H + h) * p.W + w) * p.C + vc * VEC);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += v.f[k];
+            }
+        }
+        VL<T, VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.f[k] = acc[k] * inv;
+        o.store(y + (size_t)i * VEC);
+    }
+}
+
+// dx[pixel] = sum over the windows that contain it of dy / (kh*kw)   (gather form, no atomics)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, PoolParams p,
+                                                          int64_t total) {
+    const int cols = p.C / VEC;
+    const float inv = 1.f / (float)(p.kh * p.kw);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t pix = fd_div((uint32_t)i, p.fd_cols), vc = (uint32_t)i - pix * cols;
+        uint32_t t = pix / p.W, w = pix - t * p.W;
+        uint32_t n = t / p.H, h = t - n * p.H;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        for (int r = 0; r < p.kh; ++r) {
+            int th = (int)h + p.ph - r;
+            if (th < 0 || th % p.sh) continue;
+            int ho = th / p.sh;
+            if (ho >= p.Ho) continue;
+            for (int q = 0; q < p.kw; ++q) {
+                int tw = (int)w + p.pw - q;
+                if (tw < 0 || tw % p.sw) continue;
+                int wo = tw / p.sw;
+                if (wo >= p.Wo) continue;
+                VL<T, VEC> v;
+                v.load(dy + ((size_t)(n * p.Ho + ho) * p.Wo + wo) * p.C + vc * VEC);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += v.f[k];
+            }
+        }
+        VL<T, VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.f[k] = acc[k] * inv;
+        o.store(dx + (size_t)i * VEC);
+    }
+}
+
 // Gather form of the backward from the saved window positions (first maximum in row-major window
 // order, torch's rule): every input element sums dy over the <= ceil(k/s)^2 windows that cover it
 // and whose saved arg-max is this element.  No atomics, deterministic.
@@ -319,6 +387,29 @@ static int maxpool_t(bool bwd, const void* a, void* b, void* o, int N, int H, in
     }
     CNK_CHECK_LAUNCH("maxpool");
     return 0;
+}
+
+template <typename T, int VEC>
+static int avgpool_t(bool bwd, const void* a, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                     int ph, int pw, hipStream_t s) {
+    PoolParams p = make_pool(N, H, W, C, kh, kw, sh, sw, ph, pw, VEC);
+    int64_t total = (int64_t)N * (bwd ? (int64_t)H * W : (int64_t)p.Ho * p.Wo) * (C / VEC);
+    CNK_CHECK_ARG(total < (1ll << 31), "avgpool: tensor too large");
+    if (total == 0) return 0;
+    if (!bwd) hipLaunchKernelGGL((avgpool_fwd_kernel<T, VEC>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)a, (T*)o, p, total);
+    else hipLaunchKernelGGL((avgpool_bwd_kernel<T, VEC>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)a, (T*)o, p, total);
+    CNK_CHECK_LAUNCH("avgpool");
+    return 0;
+}
+
+int avgpool_dispatch(bool bwd, const void* a, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                     int ph, int pw, int dtype, hipStream_t s) {
+    if (dtype == CNK_BF16) {
+        if (C % 8 == 0) return avgpool_t<bf16, 8>(bwd, a, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+        return avgpool_t<bf16, 1>(bwd, a, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    }
+    if (C % 4 == 0) return avgpool_t<float, 4>(bwd, a, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    return avgpool_t<float, 1>(bwd, a, o, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
 }
 
 int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C,

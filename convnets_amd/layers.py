@@ -105,6 +105,20 @@ class MaxPool2d(nn.MaxPool2d):
         return ops.MaxPool2dFn.apply(x, k, s, _pair(self.padding))
 
 
+class AvgPool2d(nn.AvgPool2d):
+    """nn.AvgPool2d of the factory (basemodel.py:1026-1033): count_include_pad=True, floor mode."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.ceil_mode or not self.count_include_pad or self.divisor_override is not None:
+            raise NotImplementedError('convnets_amd.AvgPool2d: ceil_mode=False, count_include_pad=True only')
+
+    def forward(self, x):
+        k = _pair(self.kernel_size)
+        s = _pair(self.stride if self.stride is not None else self.kernel_size)
+        return ops.AvgPool2dFn.apply(x, k, s, _pair(self.padding))
+
+
 class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
     def __init__(self, output_size):
         super().__init__(output_size)

@@ -950,3 +950,32 @@ class DepthwiseConv2dFn(torch.autograd.Function):
                 if bias is not None:
                     _grad_written(bias)
         return dx, dw, db, None, None
+
+
+class AvgPool2dFn(torch.autograd.Function):
+    """nn.AvgPool2d (avgpool2d, basemodel.py:1026-1033): count_include_pad=True, floor mode."""
+
+    @staticmethod
+    def forward(ctx, x, ksize, stride, padding):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        N, C, H, W = x.shape
+        Ho = (H + 2 * padding[0] - ksize[0]) // stride[0] + 1
+        Wo = (W + 2 * padding[1] - ksize[1]) // stride[1] + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=CL)
+        check(lib.cnk_avgpool2d_fwd(_p(x), _p(y), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
+                                    padding[0], padding[1], _dtype_code(x), _stream()))
+        ctx.geom = (ksize, stride, padding, tuple(x.shape), x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        ksize, stride, padding, shape, dt = ctx.geom
+        dy = _nhwc(dy)
+        N, C, H, W = shape
+        dx = torch.empty(shape, dtype=dt, device=dy.device, memory_format=CL)
+        check(lib.cnk_avgpool2d_bwd(_p(dy), _p(dx), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
+                                    padding[0], padding[1], _dtype_code(dy), _stream()))
+        return dx, None, None, None

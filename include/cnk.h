@@ -184,6 +184,13 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
                int64_t ext_slices, int64_t M, int32_t C, int relu,
                int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* nn.AvgPool2d (avgpool2d, basemodel.py:1026-1033; DenseNet's transition block, densenet.py:129): floor mode,
+ * count_include_pad=True (every window divides by kh*kw), zero padding.  SURVEY.md 8f n4. */
+int cnk_avgpool2d_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh,
+                      int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream);
+int cnk_avgpool2d_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh,
+                      int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream);
+
 /* nn.MaxPool2d (basemodel.py:1017-1024): floor mode, implicit -inf padding, dilation 1.
  * The forward optionally saves, per output element, the window-relative position r*kw+q (uint8)
  * of the arg-max -- the first maximum in row-major window order, as torch -- and the backward

@@ -135,6 +135,12 @@ class RefBaseModel(nn.Module):
             self.save_conv_outshape(layer)
         return layer
 
+    def avgpool2d(self, set_output=True, **kwargs):                                    # :1026-1033
+        layer = nn.AvgPool2d(**kwargs)
+        if set_output:
+            self.save_conv_outshape(layer)
+        return layer
+
     def adapt_avgpool2d(self, set_output=True, **kwargs):                              # :1035-1042
         layer = nn.AdaptiveAvgPool2d(**kwargs)
         if set_output:
@@ -497,6 +503,64 @@ class RefSqueezeNet(RefBaseModel):                                 # squeezenet.
         return torch.flatten(self.classifier(self.features(x)), start_dim=1)
 
 
+class RefDenseLayer(nn.Module):                                    # densenet.py:105-140
+    def __init__(self, network, growth_rate, bottleneck_factor):
+        super().__init__()
+        p = network.setting.dropout_rate
+        self.bottleneck = nn.Sequential(nn.BatchNorm2d(network.in_channels), nn.ReLU(inplace=True), nn.Dropout(p=p),
+                                        network.conv2d(num_filters=bottleneck_factor * growth_rate, kernel_size=1))
+        self.conv_block = nn.Sequential(nn.BatchNorm2d(network.in_channels), nn.ReLU(inplace=True), nn.Dropout(p=p),
+                                        network.conv2d(num_filters=growth_rate, kernel_size=3, padding=1))
+
+    def forward(self, x):
+        return torch.cat([x, self.conv_block(self.bottleneck(x))], dim=1)
+
+
+class RefDenseBlock(nn.Module):                                    # densenet.py:142-169
+    def __init__(self, network, dense_block_size, growth_rate, bottleneck_factor):
+        super().__init__()
+        mods = []
+        num_input_filters = network.in_channels
+        for i in range(dense_block_size):
+            mods.append(RefDenseLayer(network, growth_rate, bottleneck_factor))
+            network.in_channels += num_input_filters + i * growth_rate
+        self.dense_block = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.dense_block(x)
+
+
+class RefTransitionBlock(nn.Sequential):                           # densenet.py:171-188
+    def __init__(self, network, compression_factor):
+        super().__init__()
+        self.add_module('batch_norm', nn.BatchNorm2d(network.in_channels))
+        self.add_module('relu', nn.ReLU(inplace=True))
+        self.add_module('conv', network.conv2d(num_filters=network.in_channels // compression_factor, kernel_size=1))
+        self.add_module('avg_pool', network.avgpool2d(kernel_size=2, stride=2))
+
+
+class RefDenseNet(RefBaseModel):                                   # densenet.py:16-103
+    config = {'121': (32, [6, 12, 24, 16], 64), '169': (32, [6, 12, 32, 32], 64), '201': (32, [6, 12, 48, 32], 64),
+              '264': (32, [6, 12, 64, 48], 64), '161': (48, [6, 12, 36, 24], 96)}
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        growth_rate, blocks, init_features = self.config[str(setting.kind)]
+        mods = [self.conv2d_block(num_filters=init_features, kernel_size=7, stride=2, padding=3),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1)]
+        for i, size in enumerate(blocks):
+            mods.append(RefDenseBlock(self, size, growth_rate, bottleneck_factor=4))
+            if i != len(blocks) - 1:
+                mods.append(RefTransitionBlock(self, compression_factor=2))
+        mods += [nn.BatchNorm2d(num_features=self.in_channels), nn.ReLU(inplace=True), self.adapt_avgpool2d(output_size=1)]
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
           'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt,
-          'inception': RefInceptionNetV1, 'squeezenet': RefSqueezeNet}
+          'inception': RefInceptionNetV1, 'squeezenet': RefSqueezeNet,
+          'densenet': RefDenseNet}

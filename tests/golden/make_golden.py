@@ -38,6 +38,7 @@ def import_reference():
     if REF not in sys.path:
         sys.path.insert(0, REF)
     import basemodel
+    import densenet
     import inceptionnet_v1
     import mobilenet_v1
     import resnet
@@ -56,6 +57,7 @@ def import_reference():
     basemodel.resnext = resnext
     basemodel.inceptionnet_v1 = inceptionnet_v1
     basemodel.squeezenet = squeezenet
+    basemodel.densenet = densenet
     return settings, basemodel, resnet, vggnet
 
 
@@ -235,7 +237,8 @@ def make_models(settings, basemodel, resnet, vggnet):
              ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16),
              ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16),
              ('inception', basemodel.inceptionnet_v1.InceptionNetV1, 1, (3, 32, 32), True, 16),
-             ('squeezenet', basemodel.squeezenet.SqueezeNet, 1.1, (3, 64, 64), True, 16)]
+             ('squeezenet', basemodel.squeezenet.SqueezeNet, 1.1, (3, 64, 64), True, 16),
+             ('densenet121', basemodel.densenet.DenseNet, 121, (3, 32, 32), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)

@@ -690,3 +690,29 @@ def test_conv_and_pool_backward_after_layout_copy():
     xr = x.detach().cpu().double().requires_grad_(True)
     F.max_pool2d(F.conv2d(xr, conv.weight.detach().cpu().double()), 2, 2).sum().backward()
     assert rel_l2(host(x.grad), xr.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [(64, 8, 8, 2, 2, 0), (32, 9, 7, 3, 2, 1), (8, 5, 5, 2, 1, 1), (6, 4, 6, 2, 2, 0)],
+                         ids=lambda c: 'C%d-%dx%d-k%d-s%d-p%d' % c)
+def test_avgpool_vs_torch(cfg, dtype):
+    """nn.AvgPool2d (avgpool2d, basemodel.py:1026-1033): forward and input gradient against torch."""
+    from convnets_amd import layers
+    C, H, W, k, s, p = cfg
+    g = torch.Generator().manual_seed(C + H + k)
+    x = torch.randn(3, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.double().requires_grad_(True)
+    yr = F.avg_pool2d(xr, k, s, p)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy.double())
+    xt = dev(x.numpy(), dtype).requires_grad_(True)
+    y = layers.AvgPool2d(kernel_size=k, stride=s, padding=p)(xt)
+    y.backward(dev(dy.numpy(), dtype))
+    torch.cuda.synchronize()
+    t = 1e-6 if dtype == torch.float32 else 5e-3
+    assert rel_l2(host(y), yr.detach().numpy()) < t
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < t
