@@ -30,6 +30,10 @@ int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, floa
 int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
 int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s);
 int avgpool_dispatch(bool bwd, const void* a, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
+int sigmoid_fwd(const float* x, float* y, int64_t n, hipStream_t s);
+int sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, hipStream_t s);
+int channel_scale_fwd(const void* x, const float* g, void* y, int N, int HW, int C, int dtype, hipStream_t s);
+int channel_scale_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, int N, int HW, int C, int dtype, hipStream_t s);
 size_t grad_clip_workspace_bytes();
 int grad_clip_norm(float* g, int64_t n, float max_norm, float* norm_out, float* ws, hipStream_t s);
 int grad_clip_value(float* g, int64_t n, float c, hipStream_t s);
@@ -550,6 +554,23 @@ int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, 
     CNK_CHECK_ARG(dy && mask && dx && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_bwd: bad arguments (0 <= p < 1)");
     if (n == 0) return 0;
     return dropout_bwd(dy, mask, dx, n, p, S(stream));
+}
+
+int cnk_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) {
+    CNK_CHECK_ARG(x && y && n >= 0, "cnk_sigmoid_fwd: bad arguments");
+    return n ? sigmoid_fwd(x, y, n, S(stream)) : 0;
+}
+int cnk_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    CNK_CHECK_ARG(dy && y && dx && n >= 0, "cnk_sigmoid_bwd: bad arguments");
+    return n ? sigmoid_bwd(dy, y, dx, n, S(stream)) : 0;
+}
+int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && gate && y && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_fwd: bad arguments");
+    return channel_scale_fwd(x, gate, y, N, HW, C, dtype, S(stream));
+}
+int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
+    CNK_CHECK_ARG(dy && x && gate && dx && dgate && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_bwd: bad arguments");
+    return channel_scale_bwd(dy, x, gate, dx, dgate, N, HW, C, dtype, S(stream));
 }
 
 size_t cnk_grad_clip_workspace_bytes(void) { return grad_clip_workspace_bytes(); }

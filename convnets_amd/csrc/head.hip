@@ -229,6 +229,47 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
         dx[i] = mask[i] ? dy[i] * scale : 0.f;
 }
 
+// ---- squeeze-and-excitation unit (src/senet.py:215-254, src/se_resnet.py:216-255) -----------------------
+// excitation gate: nn.Sigmoid on the [N][C] fp32 descriptor
+__global__ __launch_bounds__(256) void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = 1.f / (1.f + __expf(-x[i]));
+}
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          float* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+
+// scale: y[n][p][c] = x[n][p][c] * g[n][c]   (x * output.expand_as(x)); lanes along C
+template <typename T>
+__global__ __launch_bounds__(256) void channel_scale_fwd_kernel(const T* __restrict__ x, const float* __restrict__ g,
+                                                                T* __restrict__ y, int64_t total, int HW, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t n = i / ((int64_t)HW * C);
+        y[i] = from_f32<T>(to_f32(x[i]) * g[n * C + c]);
+    }
+}
+// dx = dy * g;  dg[n][c] = sum_p dy*x : one thread per (n, c) walks the HW pixels (coalesced across c)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_scale_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                const float* __restrict__ g, T* __restrict__ dx,
+                                                                float* __restrict__ dg, int N, int HW, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const size_t base = (size_t)n * HW * C + c;
+    const float gv = g[i];
+    float acc = 0.f;
+    for (int k = 0; k < HW; ++k) {
+        const float d = to_f32(dy[base + (size_t)k * C]);
+        acc += d * to_f32(x[base + (size_t)k * C]);
+        dx[base + (size_t)k * C] = from_f32<T>(d * gv);
+    }
+    dg[i] = acc;
+}
+
 inline int grid1d(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -332,5 +373,31 @@ int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float 
 int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s) {
     hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, dy, mask, dx, n, 1.f / (1.f - p));
     CNK_CHECK_LAUNCH("dropout_bwd");
+    return 0;
+}
+
+int sigmoid_fwd(const float* x, float* y, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, y, n);
+    CNK_CHECK_LAUNCH("sigmoid_fwd");
+    return 0;
+}
+int sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, dy, y, dx, n);
+    CNK_CHECK_LAUNCH("sigmoid_bwd");
+    return 0;
+}
+int channel_scale_fwd(const void* x, const float* g, void* y, int N, int HW, int C, int dtype, hipStream_t s) {
+    const int64_t total = (int64_t)N * HW * C;
+    if (dtype == CNK_BF16) hipLaunchKernelGGL(channel_scale_fwd_kernel<bf16>, dim3(grid1d(total)), dim3(256), 0, s, (const bf16*)x, g, (bf16*)y, total, HW, C);
+    else hipLaunchKernelGGL(channel_scale_fwd_kernel<float>, dim3(grid1d(total)), dim3(256), 0, s, (const float*)x, g, (float*)y, total, HW, C);
+    CNK_CHECK_LAUNCH("channel_scale_fwd");
+    return 0;
+}
+int channel_scale_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, int N, int HW, int C, int dtype,
+                      hipStream_t s) {
+    const int grid = ceil_div(N * C, 256);
+    if (dtype == CNK_BF16) hipLaunchKernelGGL(channel_scale_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, g, (bf16*)dx, dg, N, HW, C);
+    else hipLaunchKernelGGL(channel_scale_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, g, (float*)dx, dg, N, HW, C);
+    CNK_CHECK_LAUNCH("channel_scale_bwd");
     return 0;
 }

@@ -167,6 +167,29 @@ class CrossEntropyLoss(nn.CrossEntropyLoss):
         return loss
 
 
+class Sigmoid(nn.Sigmoid):
+    def forward(self, x):
+        return ops.SigmoidFn.apply(x)
+
+
+class SEUnit(nn.Module):
+    """Squeeze-and-excitation unit (src/senet.py:215-254, identical in src/se_resnet.py:216-255): global average
+    pool -> Linear(C, C/r) -> ReLU -> Linear(C/r, C) -> Sigmoid -> per-channel scale.  Child names `squeeze` /
+    `excitation.{0,2}` as in the reference.  The descriptor path runs in fp32 (GAP output), the scale on NHWC."""
+
+    def __init__(self, network, reduction, **kwargs):
+        super().__init__()
+        num_features = network.in_channels
+        self.squeeze = network.adapt_avgpool2d(set_output=False, output_size=1)
+        self.excitation = nn.Sequential(Linear(num_features, num_features // reduction, bias=False), ReLU(inplace=True),
+                                        Linear(num_features // reduction, num_features, bias=False), Sigmoid())
+
+    def forward(self, x):
+        n, c = x.shape[0], x.shape[1]
+        gate = self.excitation(self.squeeze(x).view(n, c))
+        return ops.ChannelScaleFn.apply(x, gate)
+
+
 class ConvBlock(nn.Sequential):
     """conv -> [BN] -> [ReLU] as conv2d_block builds it (basemodel.py:999-1015): an nn.Sequential
     with children '0','1','2' (same state_dict keys), whose forward runs BN + ReLU (+ the residual

@@ -979,3 +979,55 @@ class AvgPool2dFn(torch.autograd.Function):
         check(lib.cnk_avgpool2d_bwd(_p(dy), _p(dx), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
                                     padding[0], padding[1], _dtype_code(dy), _stream()))
         return dx, None, None, None
+
+
+# ---- squeeze-and-excitation unit ----------------------------------------------------
+class SigmoidFn(torch.autograd.Function):
+    """nn.Sigmoid on the fp32 excitation descriptor (senet.py:236)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(_lib.load().cnk_sigmoid_fwd(_p(x), _p(y), x.numel(), _stream()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(_lib.load().cnk_sigmoid_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()))
+        return dx
+
+
+class ChannelScaleFn(torch.autograd.Function):
+    """x * gate.expand_as(x) (senet.py:252): NHWC activations scaled per (sample, channel) by the fp32 gate [N, C]."""
+
+    @staticmethod
+    def forward(ctx, x, gate):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        gate = gate.contiguous()
+        N, C, H, W = x.shape
+        if gate.shape != (N, C) or gate.dtype != torch.float32:
+            raise ValueError('channel scale: gate must be fp32 [N, C]')
+        y = torch.empty_like(x, memory_format=CL)
+        check(lib.cnk_channel_scale_fwd(_p(x), _p(gate), _p(y), N, H * W, C, _dtype_code(x), _stream()))
+        ctx.save_for_backward(x, gate)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gate = ctx.saved_tensors
+        dy = _nhwc(dy)
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x, memory_format=CL)
+        dgate = torch.empty_like(gate)
+        check(lib.cnk_channel_scale_bwd(_p(dy), _p(x), _p(gate), _p(dx), _p(dgate), N, H * W, C, _dtype_code(x),
+                                        _stream()))
+        return dx, dgate

@@ -269,6 +269,16 @@ int cnk_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p,
                     uint64_t offset, void* stream);
 int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
 
+/* Squeeze-and-excitation unit (SEUnit, senet.py:215-254 / se_resnet.py:216-255): nn.Sigmoid on the fp32 [N][C]
+ * descriptor, and the scale step x * gate.expand_as(x) on NHWC activations (gate fp32 [N][C]):
+ *   y[n][p][c] = x[n][p][c] * gate[n][c];   dx = dy * gate;   dgate[n][c] = sum_p dy * x.   SURVEY.md 8f n4. */
+int cnk_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+int cnk_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, int32_t HW, int32_t C, int dtype,
+                          void* stream);
+int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N,
+                          int32_t HW, int32_t C, int dtype, void* stream);
+
 /* Gradient clipping over the same flat fp32 gradient arena (gradient_clipping, basemodel.py:131-178).
  * cnk_grad_clip_norm == torch.nn.utils.clip_grad_norm_(params, max_norm) (L2, basemodel.py:156): the
  * norm is taken over all gradients together and every gradient is scaled by

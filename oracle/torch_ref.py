@@ -560,7 +560,133 @@ class RefDenseNet(RefBaseModel):                                   # densenet.py
             self.init_params()
 
 
+class RefSEUnit(nn.Module):                                        # senet.py:215-254 == se_resnet.py:216-255
+    def __init__(self, network, reduction):
+        super().__init__()
+        c = network.in_channels
+        self.squeeze = network.adapt_avgpool2d(set_output=False, output_size=1)
+        self.excitation = nn.Sequential(nn.Linear(c, c // reduction, bias=False), nn.ReLU(inplace=True),
+                                        nn.Linear(c // reduction, c, bias=False), nn.Sigmoid())
+
+    def forward(self, x):
+        n, c = x.shape[0], x.shape[1]
+        gate = self.excitation(self.squeeze(x).view(n, c)).view(n, c, 1, 1)
+        return x * gate.expand_as(x)
+
+
+class _RefSEBlockBase(nn.Module):
+    def _fwd(self, seq, x):
+        identity = x
+        output = seq(x)
+        if self.dim_synch is not None:
+            identity = self.dim_synch(identity)
+        output += identity
+        return F.relu(output)
+
+
+class RefSEResBlock(_RefSEBlockBase):                              # se_resnet.py:135-173
+    def __init__(self, network, num_filters, expansion, reduction, dim_synch=None, **kwargs):
+        super().__init__()
+        self.dim_synch = dim_synch
+        self.res_block = nn.Sequential(
+            RefConv2dBlock(network, num_filters=num_filters, kernel_size=3, padding=1, **kwargs),
+            RefConv2dBlock(network, num_filters=num_filters * expansion, activation=False, kernel_size=3, padding=1),
+            RefSEUnit(network, reduction))
+
+    def forward(self, x):
+        return self._fwd(self.res_block, x)
+
+
+class RefSEResBottleneck(_RefSEBlockBase):                         # se_resnet.py:175-214
+    def __init__(self, network, num_filters, expansion, reduction, dim_synch=None, **kwargs):
+        super().__init__()
+        self.dim_synch = dim_synch
+        self.res_bottleneck = nn.Sequential(
+            RefConv2dBlock(network, num_filters=num_filters, kernel_size=1),
+            RefConv2dBlock(network, num_filters=num_filters, kernel_size=3, padding=1, **kwargs),
+            RefConv2dBlock(network, num_filters=num_filters * expansion, activation=False, kernel_size=1),
+            RefSEUnit(network, reduction))
+
+    def forward(self, x):
+        return self._fwd(self.res_bottleneck, x)
+
+
+class RefSEBottleneck(_RefSEBlockBase):                            # senet.py:175-213
+    def __init__(self, network, num_filters, expansion, reduction, dim_synch=None, **kwargs):
+        super().__init__()
+        self.dim_synch = dim_synch
+        self.se_bottleneck = nn.Sequential(
+            RefConv2dBlock(network, num_filters=num_filters, kernel_size=1),
+            RefConv2dBlock(network, num_filters=num_filters, kernel_size=3, padding=1, **kwargs),
+            RefConv2dBlock(network, num_filters=num_filters * expansion, activation=False, kernel_size=1),
+            RefSEUnit(network, reduction))
+
+    def forward(self, x):
+        return self._fwd(self.se_bottleneck, x)
+
+
+class RefSEResNet(RefBaseModel):                                   # se_resnet.py:17-133
+    config = RefResNet.config
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        kind, cfg = self.config[str(setting.kind)]
+        block_type = RefSEResBottleneck if kind == 'bottleneck' else RefSEResBlock
+        expansion = 4 if kind == 'bottleneck' else 1
+        mods = [self.conv2d_block(num_filters=64, kernel_size=7, stride=2, padding=3),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1)]
+        for num_filters, num_repeat, stride in cfg:
+            mods.append(self.se_residual_block(block_type, num_filters, expansion, 16, stride))
+            for _ in range(1, num_repeat):
+                mods.append(self.se_residual_block(block_type, num_filters, expansion, 16))
+        mods.append(self.adapt_avgpool2d(output_size=1))
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+    def se_residual_block(self, block_type, num_filters, expansion, reduction, stride=1):
+        if stride != 1 or self.in_channels != num_filters * expansion:
+            dim_synch = self.conv2d_block(self.in_channels, num_filters * expansion, set_output=False,
+                                          activation=False, kernel_size=1, stride=stride)
+        else:
+            dim_synch = None
+        return block_type(self, num_filters=num_filters, expansion=expansion, reduction=reduction,
+                          dim_synch=dim_synch, stride=stride)
+
+
+class RefSENet(RefBaseModel):                                      # senet.py:17-133
+    config = RefResNeXt.config
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        mods = [self.conv2d_block(num_filters=64, kernel_size=7, stride=2, padding=3),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1)]
+        for num_filters, num_repeat, stride in self.config[str(setting.kind)]:
+            mods.append(self.se_block(num_filters, 2, 16, stride))
+            for _ in range(1, num_repeat):
+                mods.append(self.se_block(num_filters, 2, 16))
+        mods.append(self.adapt_avgpool2d(output_size=1))
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+    def se_block(self, num_filters, expansion, reduction, stride=1, cardinality=32):
+        if stride != 1 or self.in_channels != num_filters * expansion:
+            input_channels = self.in_channels
+            dim_synch = self.conv2d_block(self.in_channels, num_filters * expansion, set_output=True,
+                                          activation=False, kernel_size=1, stride=stride)
+            self.in_channels = input_channels
+        else:
+            dim_synch = None
+        return RefSEBottleneck(self, num_filters=num_filters, expansion=expansion, reduction=reduction,
+                               dim_synch=dim_synch, stride=stride, groups=cardinality)
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
           'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt,
           'inception': RefInceptionNetV1, 'squeezenet': RefSqueezeNet,
-          'densenet': RefDenseNet}
+          'densenet': RefDenseNet, 'seresnet': RefSEResNet, 'senet': RefSENet}

@@ -43,6 +43,8 @@ def import_reference():
     import mobilenet_v1
     import resnet
     import resnext
+    import se_resnet
+    import senet
     import squeezenet
     import settings
     import vggnet
@@ -58,6 +60,8 @@ def import_reference():
     basemodel.inceptionnet_v1 = inceptionnet_v1
     basemodel.squeezenet = squeezenet
     basemodel.densenet = densenet
+    basemodel.se_resnet = se_resnet
+    basemodel.senet = senet
     return settings, basemodel, resnet, vggnet
 
 
@@ -238,7 +242,9 @@ def make_models(settings, basemodel, resnet, vggnet):
              ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16),
              ('inception', basemodel.inceptionnet_v1.InceptionNetV1, 1, (3, 32, 32), True, 16),
              ('squeezenet', basemodel.squeezenet.SqueezeNet, 1.1, (3, 64, 64), True, 16),
-             ('densenet121', basemodel.densenet.DenseNet, 121, (3, 32, 32), True, 16)]
+             ('densenet121', basemodel.densenet.DenseNet, 121, (3, 32, 32), True, 16),
+             ('seresnet26', basemodel.se_resnet.SEResNet, 26, (3, 32, 32), True, 16),
+             ('senet26', basemodel.senet.SENet, 26, (3, 32, 32), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)
