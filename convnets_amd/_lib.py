@@ -89,6 +89,7 @@ SIGNATURES = {
     'cnk_sigmoid_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
     'cnk_channel_scale_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_channel_scale_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_input_pipeline': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 7 + [ctypes.c_int, _vp]),
     'cnk_grad_clip_workspace_bytes': (_sz, []),
     'cnk_grad_clip_norm': (ctypes.c_int, [_vp, _i64, _f32, _vp, _vp, _sz, _vp]),
     'cnk_grad_clip_value': (ctypes.c_int, [_vp, _i64, _f32, _vp]),

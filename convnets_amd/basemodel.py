@@ -299,7 +299,9 @@ class MultiClassBaseModel(nn.Module):
     def forward(self, x):
         if x.dim() != 4 or tuple(x.shape[1:]) != tuple(self.setting.input_size):
             raise ValueError('expected input [N,%d,%d,%d], got %s' % (*self.setting.input_size, tuple(x.shape)))
-        x = ops.nchw_to_nhwc(x, self.setting.compute_dtype)     # NCHW fp32 batch -> NHWC compute dtype
+        if not (x.dtype == self.setting.compute_dtype and x.is_contiguous(memory_format=torch.channels_last)):
+            x = ops.nchw_to_nhwc(x, self.setting.compute_dtype)     # NCHW fp32 batch -> NHWC compute dtype
+        # (else: already prepared on the device by ops.input_pipeline)
         x = self.features(x)
         x = torch.flatten(x, start_dim=1).float()               # head runs in fp32
         return self.classifier(x)

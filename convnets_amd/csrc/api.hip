@@ -34,6 +34,7 @@ int sigmoid_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 int sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, hipStream_t s);
 int channel_scale_fwd(const void* x, const float* g, void* y, int N, int HW, int C, int dtype, hipStream_t s);
 int channel_scale_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, int N, int HW, int C, int dtype, hipStream_t s);
+int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const float* mean, const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype, hipStream_t s);
 size_t grad_clip_workspace_bytes();
 int grad_clip_norm(float* g, int64_t n, float max_norm, float* norm_out, float* ws, hipStream_t s);
 int grad_clip_value(float* g, int64_t n, float c, hipStream_t s);
@@ -571,6 +572,12 @@ int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, 
 int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
     CNK_CHECK_ARG(dy && x && gate && dx && dgate && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_bwd: bad arguments");
     return channel_scale_bwd(dy, x, gate, dx, dgate, N, HW, C, dtype, S(stream));
+}
+
+int cnk_input_pipeline(const uint8_t* x, void* y, const int32_t* crop_yx, const uint8_t* flip, const float* mean, const float* std, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t pad, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y && mean && std && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && pad >= 0, "cnk_input_pipeline: bad arguments");
+    CNK_CHECK_ARG(Ho <= H + 2 * pad && Wo <= W + 2 * pad, "cnk_input_pipeline: crop larger than the padded image");
+    return input_pipeline(x, y, crop_yx, flip, mean, std, N, H, W, C, Ho, Wo, pad, dtype, S(stream));
 }
 
 size_t cnk_grad_clip_workspace_bytes(void) { return grad_clip_workspace_bytes(); }

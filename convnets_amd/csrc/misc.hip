@@ -247,6 +247,32 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
     }
 }
 
+// On-device input pipeline (src/mngrdata.py:139-165): RandomCrop(size, padding) + RandomHorizontalFlip + ToTensor
+// + Normalize(mean, std) + the NCHW->NHWC hand-off, in one pass over uint8 HWC images.  The random draws stay with
+// the caller: per sample a crop origin (oy, ox) in the zero-padded image and a flip flag.
+//   y[n][h][w][c] = (u8(x[n][h+oy-pad][wsrc+ox-pad][c]) / 255 - mean[c]) / std[c],  wsrc = flip ? Wo-1-w : w,
+//   pixels that fall into the padding are the value 0 before normalisation (torchvision pads the image, fill 0).
+template <typename T>
+__global__ __launch_bounds__(256) void input_pipeline_kernel(const unsigned char* __restrict__ x, T* __restrict__ y,
+                                                             const int* __restrict__ crop_yx, const unsigned char* __restrict__ flip,
+                                                             const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                             int N, int H, int W, int C, int Ho, int Wo, int pad) {
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t q = i / C;
+        const int w = (int)(q % Wo);
+        q /= Wo;
+        const int h = (int)(q % Ho), n = (int)(q / Ho);
+        const int oy = crop_yx ? crop_yx[2 * n] : pad, ox = crop_yx ? crop_yx[2 * n + 1] : pad;
+        const int ws = (flip && flip[n]) ? Wo - 1 - w : w;
+        const int sy = h + oy - pad, sx = ws + ox - pad;
+        float v = 0.f;
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) v = (float)x[(((size_t)n * H + sy) * W + sx) * C + c] * (1.f / 255.f);
+        y[i] = from_f32<T>((v - mean[c]) / stdv[c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n4, int64_t n, float lr, float b1, float b2,
@@ -504,5 +530,17 @@ int grad_clip_value(float* g, int64_t n, float c, hipStream_t s) {
     int64_t n4 = (n + 3) / 4;
     hipLaunchKernelGGL(grad_clip_value_kernel, dim3(grid_for(n4)), dim3(256), 0, s, g, n4, n, c);
     CNK_CHECK_LAUNCH("grad_clip_value");
+    return 0;
+}
+
+int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const float* mean,
+                   const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype, hipStream_t s) {
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    if (total == 0) return 0;
+    if (dtype == CNK_BF16)
+        hipLaunchKernelGGL(input_pipeline_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16*)y, crop_yx, flip, mean, stdv, N, H, W, C, Ho, Wo, pad);
+    else
+        hipLaunchKernelGGL(input_pipeline_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, crop_yx, flip, mean, stdv, N, H, W, C, Ho, Wo, pad);
+    CNK_CHECK_LAUNCH("input_pipeline");
     return 0;
 }

@@ -1031,3 +1031,27 @@ class ChannelScaleFn(torch.autograd.Function):
         check(lib.cnk_channel_scale_bwd(_p(dy), _p(x), _p(gate), _p(dx), _p(dgate), N, H * W, C, _dtype_code(x),
                                         _stream()))
         return dx, dgate
+
+
+def input_pipeline(images_u8, mean, std, dtype, crop_size=None, padding=0, crop_yx=None, flip=None):
+    """The reference's train/valid transforms (mngrdata.py:139-165) on the device in one pass: RandomCrop(crop_size,
+    padding) + RandomHorizontalFlip + ToTensor + Normalize(mean, std), uint8 [N, H, W, C] -> NHWC `dtype` tensor
+    [N, C, Ho, Wo] (channels_last) that the model forward takes as is.  crop_yx (int32 [N, 2]) and flip (uint8/bool
+    [N]) are the caller's random draws; None = centre crop / no flip.  No autograd (data)."""
+    _require_gpu(images_u8)
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4:
+        raise ValueError('input_pipeline: expected uint8 images [N, H, W, C]')
+    x = images_u8.contiguous()
+    N, H, W, C = x.shape
+    Ho, Wo = (H, W) if crop_size is None else ((crop_size, crop_size) if isinstance(crop_size, int) else tuple(crop_size))
+    dev = x.device
+    mean_t = torch.as_tensor(mean, dtype=torch.float32, device=dev).contiguous()
+    std_t = torch.as_tensor(std, dtype=torch.float32, device=dev).contiguous()
+    if crop_yx is not None:
+        crop_yx = crop_yx.to(device=dev, dtype=torch.int32).contiguous()
+    if flip is not None:
+        flip = flip.to(device=dev, dtype=torch.uint8).contiguous()
+    y = torch.empty((N, C, Ho, Wo), dtype=dtype, device=dev, memory_format=CL)
+    check(_lib.load().cnk_input_pipeline(_p(x), _p(y), _p(crop_yx), _p(flip), _p(mean_t), _p(std_t), N, H, W, C, Ho, Wo,
+                                         int(padding), _dtype_code(y), _stream()))
+    return y

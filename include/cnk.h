@@ -218,6 +218,15 @@ int cnk_gap_bwd(const float* dy, void* dx, int32_t N, int32_t HW, int32_t C, int
 int cnk_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int32_t N, int32_t C, int32_t H, int32_t W,
                      int dtype, void* stream);
 
+/* On-device input pipeline (mngrdata.py:139-165): RandomCrop(Ho x Wo, padding=pad) +
+ * RandomHorizontalFlip + ToTensor + Normalize(mean, std), from uint8 images x[N][H][W][C] (HWC, as decoded) straight
+ * to the NHWC `dtype` tensor the convs consume.  The random draws are the caller's: crop_yx (int32 [N][2], origin of
+ * the crop in the zero-padded image, 0 <= oy <= H + 2*pad - Ho; NULL: centred at `pad`) and flip (uint8 [N]; NULL: none).
+ * mean / std: fp32 [C].  RandomAffine (mngrdata.py:147) is not implemented. */
+int cnk_input_pipeline(const uint8_t* x, void* y, const int32_t* crop_yx, const uint8_t* flip, const float* mean,
+                       const float* std, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                       int32_t pad, int dtype, void* stream);
+
 /* optim.Adam with L2 weight decay as the reference configures it (basemodel.py:64-67; betas
  * (0.9,0.999), eps 1e-8), over one flat fp32 arena holding every parameter:
  *   g += wd*p; m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v/(1-b2^t))+eps)

@@ -716,3 +716,31 @@ def test_avgpool_vs_torch(cfg, dtype):
     t = 1e-6 if dtype == torch.float32 else 5e-3
     assert rel_l2(host(y), yr.detach().numpy()) < t
     assert rel_l2(host(xt.grad), xr.grad.numpy()) < t
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_input_pipeline_vs_torch(dtype):
+    """RandomCrop(32, padding=4) + RandomHorizontalFlip + ToTensor + Normalize (mngrdata.py:139-165) with the random
+    draws supplied by the caller, against the same transforms written with torch ops on the host."""
+    from convnets_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C, pad, size = 6, 32, 32, 3, 4, 32
+    img = torch.randint(0, 256, (N, H, W, C), generator=g, dtype=torch.uint8)
+    mean, std = [0.478, 0.472, 0.430], [0.242, 0.238, 0.258]
+    yx = torch.stack([torch.randint(0, 2 * pad + 1, (N,), generator=g), torch.randint(0, 2 * pad + 1, (N,), generator=g)], dim=1)
+    flip = torch.randint(0, 2, (N,), generator=g).bool()
+    out = ops.input_pipeline(img.cuda(), mean, std, dtype, crop_size=size, padding=pad, crop_yx=yx, flip=flip)
+    assert out.shape == (N, C, size, size) and out.is_contiguous(memory_format=CL)
+    ref = []
+    for n in range(N):
+        t = F.pad(img[n].permute(2, 0, 1).double() / 255.0, (pad, pad, pad, pad))          # ToTensor on the padded image
+        t = t[:, yx[n, 0]:yx[n, 0] + size, yx[n, 1]:yx[n, 1] + size]
+        if flip[n]:
+            t = t.flip(-1)
+        ref.append((t - torch.tensor(mean).double().view(3, 1, 1)) / torch.tensor(std).double().view(3, 1, 1))
+    ref = torch.stack(ref)
+    assert rel_l2(host(out), ref.numpy()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    # plain ToTensor + Normalize (validation transforms, mngrdata.py:176-190)
+    out2 = ops.input_pipeline(img.cuda(), mean, std, dtype)
+    ref2 = (img.permute(0, 3, 1, 2).double() / 255.0 - torch.tensor(mean).double().view(1, 3, 1, 1)) / torch.tensor(std).double().view(1, 3, 1, 1)
+    assert rel_l2(host(out2), ref2.numpy()) < (1e-6 if dtype == torch.float32 else 4e-3)
