@@ -744,3 +744,50 @@ def test_input_pipeline_vs_torch(dtype):
     out2 = ops.input_pipeline(img.cuda(), mean, std, dtype)
     ref2 = (img.permute(0, 3, 1, 2).double() / 255.0 - torch.tensor(mean).double().view(1, 3, 1, 1)) / torch.tensor(std).double().view(1, 3, 1, 1)
     assert rel_l2(host(out2), ref2.numpy()) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+def _random_bn_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.randint(1, 9)), int(rng.choice([1, 3, 8, 24, 64, 72, 200, 512])), int(rng.randint(1, 15)),
+                    int(rng.randint(1, 15)), str(rng.choice(['plain', 'relu', 'add_relu']))))
+    return out
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', _random_bn_cases(16, 5), ids=lambda c: 'n%d-c%d-%dx%d-%s' % c)
+def test_batchnorm_random_shapes_vs_torch(case, dtype):
+    """Randomly drawn BN geometries (1-pixel maps, channel counts off the vector width, tiny batches) in the three
+    fused modes, against torch fp64."""
+    N, C, H, W, mode = case
+    if N * H * W < 2:
+        N = 2                                                 # torch refuses batch statistics over one value
+    g = torch.Generator().manual_seed(N * 1000 + C * 10 + H)
+    shape = (N, C, H, W)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.2
+    res = torch.randn(shape, generator=g) if mode == 'add_relu' else None
+    dy = torch.randn(shape, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+        res = res.bfloat16().float() if res is not None else None
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if res is not None else None
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if rr is not None:
+        z = z + rr
+    yr = torch.relu(z) if mode != 'plain' else z
+    yr.backward(dy.double())
+    y, dx, dg, db, dres, _, _ = run_bn(x.numpy(), gamma.numpy(), beta.numpy(), None if res is None else res.numpy(),
+                                       dy.numpy(), mode != 'plain', dtype)
+    t = 5e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_l2(y, yr.detach().numpy()) < t, 'y'
+    # tiny reductions (a handful of values per channel) amplify rounding in dx: scale the bound with 1/sqrt(count)
+    amp = max(1.0, 8.0 / np.sqrt(N * H * W))
+    assert rel_l2(dx, xr.grad.numpy()) < (2e-4 if dtype == torch.float32 else 3e-2) * amp, 'dx'
+    assert rel_l2(dg, gr.grad.numpy()) < (1e-4 if dtype == torch.float32 else 3e-2) * amp, 'dgamma'
+    assert rel_l2(db, br.grad.numpy()) < (1e-4 if dtype == torch.float32 else 3e-2), 'dbeta'
+    if res is not None:
+        assert rel_l2(dres, rr.grad.numpy()) < t, 'dres'
