@@ -78,6 +78,9 @@ SIGNATURES = {
     'cnk_dwconv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp]),
     'cnk_dwconv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp]),
     'cnk_dwconv2d_wgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
+    'cnk_grouped_expand': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'cnk_grouped_extract': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'cnk_channel_shuffle': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_linear_workspace_bytes': (_sz, [ctypes.c_int, _i32, _i32, _i32]),
     'cnk_linear_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     'cnk_linear_dgrad': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),

@@ -256,8 +256,8 @@ class MultiClassBaseModel(nn.Module):
         return layer
 
     def conv2d_depthwise(self, in_channels=None, num_filters=None, set_output=True, **kwargs):
-        """basemodel.py:981-997: nn.Conv2d(in, filters, groups=in): the depthwise kernels need
-        filters == in (channel multiplier 1, as every caller in the reference uses it)."""
+        """basemodel.py:981-997: nn.Conv2d(in, filters, groups=in); filters == in (every caller in the reference)
+        runs on the depthwise kernels, a channel multiplier on the dense grouped path."""
         if in_channels is None:
             in_channels = self.in_channels
         if num_filters is None:

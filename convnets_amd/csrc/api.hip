@@ -35,6 +35,9 @@ int sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, hipStream
 int channel_scale_fwd(const void* x, const float* g, void* y, int N, int HW, int C, int dtype, hipStream_t s);
 int channel_scale_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, int N, int HW, int C, int dtype, hipStream_t s);
 int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const float* mean, const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype, hipStream_t s);
+int grouped_expand(const float* w, float* wd, int Cout, int Cin, int groups, int T, hipStream_t s);
+int grouped_extract(const float* dwd, float* dw, int Cout, int Cin, int groups, int T, hipStream_t s);
+int channel_shuffle(const void* x, void* y, int64_t pixels, int C, int groups, int dtype, hipStream_t s);
 size_t grad_clip_workspace_bytes();
 int grad_clip_norm(float* g, int64_t n, float max_norm, float* norm_out, float* ws, hipStream_t s);
 int grad_clip_value(float* g, int64_t n, float c, hipStream_t s);
@@ -482,21 +485,21 @@ size_t cnk_dwconv2d_workspace_bytes(const cnk_conv_desc* d) {
 
 int cnk_dwconv2d_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y, void* stream) {
     if (int rc = check_desc(d, "cnk_dwconv2d_fwd")) return rc;
-    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_fwd: needs Cin == Cout, C %% 8 (bf16) / 4 (fp32) == 0, kh*kw <= 25");
+    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_fwd: needs Cin == Cout and kh*kw <= 25");
     CNK_CHECK_ARG(x && w && y, "cnk_dwconv2d_fwd: null pointer");
     return dwconv_fwd(d, x, w, bias, y, S(stream));
 }
 
 int cnk_dwconv2d_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, void* dx, void* stream) {
     if (int rc = check_desc(d, "cnk_dwconv2d_dgrad")) return rc;
-    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_dgrad: needs Cin == Cout, C %% 8 (bf16) / 4 (fp32) == 0, kh*kw <= 25");
+    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_dgrad: needs Cin == Cout and kh*kw <= 25");
     CNK_CHECK_ARG(dy && w && dx, "cnk_dwconv2d_dgrad: null pointer");
     return dwconv_dgrad(d, dy, w, dx, S(stream));
 }
 
 int cnk_dwconv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(d, "cnk_dwconv2d_wgrad")) return rc;
-    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_wgrad: needs Cin == Cout, C %% 8 (bf16) / 4 (fp32) == 0, kh*kw <= 25");
+    CNK_CHECK_ARG(dwconv_supported(d), "cnk_dwconv2d_wgrad: needs Cin == Cout and kh*kw <= 25");
     CNK_CHECK_ARG(dy && x && dw, "cnk_dwconv2d_wgrad: null pointer");
     CNK_CHECK_ARG(workspace && workspace_bytes >= dw_ws(d), "cnk_dwconv2d_wgrad: workspace too small");
     if (int rc = dwconv_wgrad(d, dy, x, dw, accumulate, (float*)workspace, S(stream))) return rc;
@@ -506,6 +509,19 @@ int cnk_dwconv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, fl
         return colsum(dy, dbias, (int64_t)d->N * Ho * Wo, d->Cout, d->dtype, accumulate, workspace, workspace_bytes, S(stream));
     }
     return 0;
+}
+
+int cnk_grouped_expand(const float* w, float* w_dense, int32_t Cout, int32_t Cin, int32_t groups, int32_t T, void* stream) {
+    CNK_CHECK_ARG(w && w_dense && Cout > 0 && Cin > 0 && T > 0 && groups > 0 && Cout % groups == 0 && Cin % groups == 0, "cnk_grouped_expand: bad arguments");
+    return grouped_expand(w, w_dense, Cout, Cin, groups, T, S(stream));
+}
+int cnk_grouped_extract(const float* dw_dense, float* dw, int32_t Cout, int32_t Cin, int32_t groups, int32_t T, void* stream) {
+    CNK_CHECK_ARG(dw_dense && dw && Cout > 0 && Cin > 0 && T > 0 && groups > 0 && Cout % groups == 0 && Cin % groups == 0, "cnk_grouped_extract: bad arguments");
+    return grouped_extract(dw_dense, dw, Cout, Cin, groups, T, S(stream));
+}
+int cnk_channel_shuffle(const void* x, void* y, int64_t pixels, int32_t C, int32_t groups, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y && pixels >= 0 && C > 0 && groups > 0 && C % groups == 0, "cnk_channel_shuffle: bad arguments");
+    return channel_shuffle(x, y, pixels, C, groups, dtype, S(stream));
 }
 
 size_t cnk_linear_workspace_bytes(int pass, int32_t B, int32_t K, int32_t N) {

@@ -29,6 +29,7 @@ struct DwParams {
     FastDiv fd_hw, fd_w;  // decomposition of the walked pixel index
 };
 
+// VEC = elements per 16-byte vector, or 1 (scalar path for channel counts off the vector width)
 template <typename T, int VEC> struct RawV {
     using V = decltype(Vec16<T>::v);
     V v;
@@ -37,11 +38,17 @@ template <typename T, int VEC> struct RawV {
     __device__ __forceinline__ float get(int i) const { return to_f32(v[i]); }
     __device__ __forceinline__ void set(int i, float f) { v[i] = from_f32<T>(f); }
 };
+template <typename T> struct RawV<T, 1> {
+    T v;
+    __device__ __forceinline__ void load(const T* p) { v = *p; }
+    __device__ __forceinline__ void store(T* p) const { *p = v; }
+    __device__ __forceinline__ float get(int) const { return to_f32(v); }
+    __device__ __forceinline__ void set(int, float f) { v = from_f32<T>(f); }
+};
 
 // TAPS > 0: compile-time tap count with the weights in registers (3x3: 9); TAPS == 0: run-time
-template <typename T, int TAPS, bool DGRAD>
+template <typename T, int VEC, int TAPS, bool DGRAD>
 __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
-    constexpr int VEC = ElemTraits<T>::PER16;
     const int tid = threadIdx.x, tcol = tid % p.cpb, trow = tid / p.cpb;
     const int vcol = blockIdx.y * p.cpb + tcol;
     if (trow >= p.rpb || vcol >= p.cols) return;
@@ -105,9 +112,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
 
 // wgrad partials: thread (column, row-thread) accumulates dy*x for its pixels and taps, rows of a
 // block are summed through LDS in fixed order -> partial[blockIdx.x][t][c]
-template <typename T, int TAPS>
+template <typename T, int VEC, int TAPS>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwParams p) {
-    constexpr int VEC = ElemTraits<T>::PER16;
     extern __shared__ float sh[];                       // [256][VEC]
     const int tid = threadIdx.x, tcol = tid % p.cpb, trow = tid / p.cpb;
     const int vcol = blockIdx.y * p.cpb + tcol;
@@ -165,9 +171,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwParams p) {
 }
 
 // generic tap count: one launch per tap with TAPS == 1 semantics is avoided by looping taps here
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void dwconv_wgrad_generic_kernel(const DwParams p) {
-    constexpr int VEC = ElemTraits<T>::PER16;
     extern __shared__ float sh[];
     const int tid = threadIdx.x, tcol = tid % p.cpb, trow = tid / p.cpb;
     const int vcol = blockIdx.y * p.cpb + tcol;
@@ -234,7 +239,10 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_sum_kernel(const float* __re
     *o = accumulate ? *o + (a0 + a1) : (a0 + a1);
 }
 
-int dw_vec(int dtype) { return dtype == CNK_BF16 ? 8 : 4; }
+int dw_vec(int dtype, int C) {
+    const int v = dtype == CNK_BF16 ? 8 : 4;
+    return C % v == 0 ? v : 1;
+}
 
 void dw_geom(DwParams& p, int64_t M, int C, int vec, int target_blocks) {
     p.cols = C / vec;
@@ -252,9 +260,7 @@ void dw_geom(DwParams& p, int64_t M, int C, int vec, int target_blocks) {
 
 }  // namespace
 
-bool dwconv_supported(const cnk_conv_desc* d) {
-    return d->Cin == d->Cout && d->Cin % dw_vec(d->dtype) == 0 && d->kh * d->kw <= DW_MAX_TAPS;
-}
+bool dwconv_supported(const cnk_conv_desc* d) { return d->Cin == d->Cout && d->kh * d->kw <= DW_MAX_TAPS; }
 
 static DwParams dw_params(const cnk_conv_desc* d) {
     DwParams p = {};
@@ -264,22 +270,27 @@ static DwParams dw_params(const cnk_conv_desc* d) {
     return p;
 }
 
+template <bool DGRAD> static void dw_launch(const cnk_conv_desc* d, const DwParams& p, dim3 grid, hipStream_t s) {
+    const bool k3 = d->kh == 3 && d->kw == 3, vec = dw_vec(d->dtype, d->Cin) > 1;
+#define CNK_DW(T, V)                                                                                     \
+    do {                                                                                                 \
+        if (k3) hipLaunchKernelGGL((dwconv_kernel<T, V, 9, DGRAD>), grid, dim3(256), 0, s, p);          \
+        else hipLaunchKernelGGL((dwconv_kernel<T, V, 0, DGRAD>), grid, dim3(256), 0, s, p);             \
+    } while (0)
+    if (d->dtype == CNK_BF16) { if (vec) CNK_DW(bf16, 8); else CNK_DW(bf16, 1); }
+    else { if (vec) CNK_DW(float, 4); else CNK_DW(float, 1); }
+#undef CNK_DW
+}
+
 int dwconv_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y, hipStream_t s) {
     DwParams p = dw_params(d);
     p.a = x; p.w = w; p.bias = bias; p.out = y;
-    dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, dw_vec(d->dtype), 4096);
+    dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, dw_vec(d->dtype, d->Cin), 4096);
     if (p.M == 0) return 0;
     p.fd_hw = make_fastdiv(p.Ho * p.Wo);
     p.fd_w = make_fastdiv(p.Wo);
     dim3 grid((unsigned)ceil_div64(p.M, p.slice), ceil_div(p.cols, p.cpb));
-    const bool k3 = d->kh == 3 && d->kw == 3;
-    if (d->dtype == CNK_BF16) {
-        if (k3) hipLaunchKernelGGL((dwconv_kernel<bf16, 9, false>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((dwconv_kernel<bf16, 0, false>), grid, dim3(256), 0, s, p);
-    } else {
-        if (k3) hipLaunchKernelGGL((dwconv_kernel<float, 9, false>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((dwconv_kernel<float, 0, false>), grid, dim3(256), 0, s, p);
-    }
+    dw_launch<false>(d, p, grid, s);
     CNK_CHECK_LAUNCH("dwconv_fwd");
     return 0;
 }
@@ -287,19 +298,12 @@ int dwconv_fwd(const cnk_conv_desc* d, const void* x, const float* w, const floa
 int dwconv_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, void* dx, hipStream_t s) {
     DwParams p = dw_params(d);
     p.a = dy; p.w = w; p.out = dx;
-    dw_geom(p, (int64_t)d->N * d->H * d->W, d->Cin, dw_vec(d->dtype), 4096);
+    dw_geom(p, (int64_t)d->N * d->H * d->W, d->Cin, dw_vec(d->dtype, d->Cin), 4096);
     if (p.M == 0) return 0;
     p.fd_hw = make_fastdiv(d->H * d->W);
     p.fd_w = make_fastdiv(d->W);
     dim3 grid((unsigned)ceil_div64(p.M, p.slice), ceil_div(p.cols, p.cpb));
-    const bool k3 = d->kh == 3 && d->kw == 3;
-    if (d->dtype == CNK_BF16) {
-        if (k3) hipLaunchKernelGGL((dwconv_kernel<bf16, 9, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((dwconv_kernel<bf16, 0, true>), grid, dim3(256), 0, s, p);
-    } else {
-        if (k3) hipLaunchKernelGGL((dwconv_kernel<float, 9, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((dwconv_kernel<float, 0, true>), grid, dim3(256), 0, s, p);
-    }
+    dw_launch<true>(d, p, grid, s);
     CNK_CHECK_LAUNCH("dwconv_dgrad");
     return 0;
 }
@@ -308,7 +312,7 @@ static int dw_wgrad_blocks() { return 512; }      // slices to sum afterwards: k
 
 size_t dwconv_wgrad_workspace(const cnk_conv_desc* d) {
     DwParams p = dw_params(d);
-    dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, dw_vec(d->dtype), dw_wgrad_blocks());
+    dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, dw_vec(d->dtype, d->Cin), dw_wgrad_blocks());
     size_t slices = (size_t)ceil_div64(p.M > 0 ? p.M : 1, p.slice);
     return slices * d->kh * d->kw * d->Cin * sizeof(float);
 }
@@ -317,7 +321,7 @@ int dwconv_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* d
                  hipStream_t s) {
     DwParams p = dw_params(d);
     p.a = dy; p.b = x; p.partial = ws;
-    const int vec = dw_vec(d->dtype), taps = d->kh * d->kw;
+    const int vec = dw_vec(d->dtype, d->Cin), taps = d->kh * d->kw;
     dw_geom(p, (int64_t)d->N * p.Ho * p.Wo, d->Cin, vec, dw_wgrad_blocks());
     if (p.M == 0) return 0;
     p.fd_hw = make_fastdiv(p.Ho * p.Wo);
@@ -326,16 +330,83 @@ int dwconv_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* d
     dim3 grid(slices, ceil_div(p.cols, p.cpb));
     const size_t lds = 256 * vec * sizeof(float);
     const bool k3 = d->kh == 3 && d->kw == 3;
-    if (d->dtype == CNK_BF16) {
-        if (k3) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16, 9>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((dwconv_wgrad_generic_kernel<bf16>), grid, dim3(256), lds, s, p);
-    } else {
-        if (k3) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, 9>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((dwconv_wgrad_generic_kernel<float>), grid, dim3(256), lds, s, p);
-    }
+#define CNK_DWW(T, V)                                                                                    \
+    do {                                                                                                 \
+        if (k3) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, V, 9>), grid, dim3(256), lds, s, p);         \
+        else hipLaunchKernelGGL((dwconv_wgrad_generic_kernel<T, V>), grid, dim3(256), lds, s, p);       \
+    } while (0)
+    if (d->dtype == CNK_BF16) { if (vec > 1) CNK_DWW(bf16, 8); else CNK_DWW(bf16, 1); }
+    else { if (vec > 1) CNK_DWW(float, 4); else CNK_DWW(float, 1); }
+#undef CNK_DWW
     CNK_CHECK_LAUNCH("dwconv_wgrad");
     hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3(ceil_div(taps * d->Cin, 256)), dim3(256), 0, s, ws, slices, taps,
                        d->Cin, dw, accumulate);
     CNK_CHECK_LAUNCH("dwconv_wgrad_sum");
+    return 0;
+}
+
+// ---- general grouped conv through the dense kernels, and ShuffleNet's channel shuffle ------------------------
+// A grouped conv whose shape the chunked implicit-GEMM path cannot take (Cin != Cout or a group width that does
+// not divide 64: ShuffleNet's grouped 1x1 convs, shufflenet_v1.py:117-141) runs as the DENSE conv of its
+// block-diagonal weight: expand [Cout][Cin/g][T] -> [Cout][Cin][T] (zeros off the diagonal) before the conv, extract
+// the diagonal blocks of the dense weight gradient after it.
+namespace {
+__global__ __launch_bounds__(256) void grouped_expand_kernel(const float* __restrict__ w, float* __restrict__ wd, int Cout,
+                                                             int Cin, int groups, int T) {
+    const size_t total = (size_t)Cout * Cin * T;
+    const int gw = Cin / groups, go = Cout / groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const size_t r = i / T;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const int l = ci - (co / go) * gw;
+        wd[i] = (unsigned)l < (unsigned)gw ? w[((size_t)co * gw + l) * T + t] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void grouped_extract_kernel(const float* __restrict__ dwd, float* __restrict__ dw, int Cout,
+                                                              int Cin, int groups, int T) {
+    const int gw = Cin / groups, go = Cout / groups;
+    const size_t total = (size_t)Cout * gw * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const size_t r = i / T;
+        const int l = (int)(r % gw), co = (int)(r / gw);
+        dw[i] = dwd[((size_t)co * Cin + (co / go) * gw + l) * T + t];
+    }
+}
+// y[p][j*g + i] = x[p][i*(C/g) + j]  (view(N, g, C/g, H, W).transpose(1, 2), shufflenet_v1.py:173-186) on NHWC rows
+template <typename T>
+__global__ __launch_bounds__(256) void channel_shuffle_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t total,
+                                                              int C, int groups) {
+    const int cg = C / groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % C);
+        const int64_t p = i / C;
+        const int j = co / groups, g = co - j * groups;
+        y[i] = x[p * C + (int64_t)g * cg + j];
+    }
+}
+inline int grid_g(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096);
+}
+}  // namespace
+
+int grouped_expand(const float* w, float* wd, int Cout, int Cin, int groups, int T, hipStream_t s) {
+    hipLaunchKernelGGL(grouped_expand_kernel, dim3(grid_g((int64_t)Cout * Cin * T)), dim3(256), 0, s, w, wd, Cout, Cin, groups, T);
+    CNK_CHECK_LAUNCH("grouped_expand");
+    return 0;
+}
+int grouped_extract(const float* dwd, float* dw, int Cout, int Cin, int groups, int T, hipStream_t s) {
+    hipLaunchKernelGGL(grouped_extract_kernel, dim3(grid_g((int64_t)Cout * (Cin / groups) * T)), dim3(256), 0, s, dwd, dw, Cout, Cin, groups, T);
+    CNK_CHECK_LAUNCH("grouped_extract");
+    return 0;
+}
+int channel_shuffle(const void* x, void* y, int64_t pixels, int C, int groups, int dtype, hipStream_t s) {
+    const int64_t total = pixels * C;
+    if (total == 0) return 0;
+    if (dtype == CNK_BF16) hipLaunchKernelGGL(channel_shuffle_kernel<bf16>, dim3(grid_g(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, total, C, groups);
+    else hipLaunchKernelGGL(channel_shuffle_kernel<float>, dim3(grid_g(total)), dim3(256), 0, s, (const float*)x, (float*)y, total, C, groups);
+    CNK_CHECK_LAUNCH("channel_shuffle");
     return 0;
 }

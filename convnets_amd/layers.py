@@ -25,13 +25,13 @@ class Conv2d(nn.Conv2d):
         super().__init__(*args, **kwargs)
         self._depthwise = self.groups > 1 and self.groups == self.in_channels == self.out_channels
         gw = self.in_channels // self.groups
-        grouped_ok = self.groups == 1 or self._depthwise or (
-            self.in_channels == self.out_channels and self.in_channels % 64 == 0 and 64 % gw == 0)
-        if not grouped_ok or _pair(self.dilation) != (1, 1) or self.padding_mode != 'zeros' \
-                or isinstance(self.padding, str):
-            raise NotImplementedError('convnets_amd.Conv2d: groups=1, depthwise (groups == channels) or grouped '
-                                      'with in == out channels, channels % 64 == 0 and a group width that divides '
-                                      '64 (ResNeXt); dilation=1, zeros padding')
+        # grouped conv: block-diagonal per 64-channel chunk on the implicit-GEMM kernels when the shape allows it
+        # (ResNeXt), else the dense conv of the block-diagonal weight (ShuffleNet's grouped 1x1 convs)
+        self._chunked = self.groups > 1 and not self._depthwise and self.in_channels == self.out_channels \
+            and self.in_channels % 64 == 0 and 64 % gw == 0
+        self._dense_grouped = self.groups > 1 and not self._depthwise and not self._chunked
+        if _pair(self.dilation) != (1, 1) or self.padding_mode != 'zeros' or isinstance(self.padding, str):
+            raise NotImplementedError('convnets_amd.Conv2d: dilation=1 and zeros padding only')
         self._packed = ops.PackedWeights()
 
     def __deepcopy__(self, memo):
@@ -49,6 +49,10 @@ class Conv2d(nn.Conv2d):
             y = ops.DepthwiseConv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
             return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
         # x._cnk_bn: set when x is the output of a training-mode BatchNorm2d of this package (ops.BnRecord)
+        if self._dense_grouped:
+            wd = ops.GroupedDenseWeightFn.apply(self.weight, self.groups)
+            return ops.Conv2dFn.apply(x, wd, self.bias, _pair(self.stride), _pair(self.padding),
+                                      self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), 1)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
                                   self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups)
 

@@ -1055,3 +1055,47 @@ def input_pipeline(images_u8, mean, std, dtype, crop_size=None, padding=0, crop_
     check(_lib.load().cnk_input_pipeline(_p(x), _p(y), _p(crop_yx), _p(flip), _p(mean_t), _p(std_t), N, H, W, C, Ho, Wo,
                                          int(padding), _dtype_code(y), _stream()))
     return y
+
+
+# ---- general grouped conv through the dense kernels; channel shuffle (ShuffleNet, SURVEY.md 8f n4) ------
+class GroupedDenseWeightFn(torch.autograd.Function):
+    """[Cout, Cin/g, kh, kw] -> dense block-diagonal [Cout, Cin, kh, kw]; backward extracts the diagonal blocks."""
+
+    @staticmethod
+    def forward(ctx, weight, groups):
+        w = weight.contiguous()
+        Cout, gw, kh, kw = w.shape
+        wd = torch.empty((Cout, gw * groups, kh, kw), dtype=torch.float32, device=w.device)
+        check(_lib.load().cnk_grouped_expand(_p(w), _p(wd), Cout, gw * groups, groups, kh * kw, _stream()))
+        ctx.geom = (Cout, gw * groups, groups, kh, kw)
+        return wd
+
+    @staticmethod
+    def backward(ctx, dwd):
+        Cout, Cin, groups, kh, kw = ctx.geom
+        dwd = dwd.contiguous()
+        dw = torch.empty((Cout, Cin // groups, kh, kw), dtype=torch.float32, device=dwd.device)
+        check(_lib.load().cnk_grouped_extract(_p(dwd), _p(dw), Cout, Cin, groups, kh * kw, _stream()))
+        return dw, None
+
+
+class ChannelShuffleFn(torch.autograd.Function):
+    """view(N, g, C/g, H, W).transpose(1, 2).contiguous().view(N, C, H, W) (shufflenet_v1.py:173-186) on NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, groups):
+        _require_gpu(x)
+        x = _nhwc(x)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x, memory_format=CL)
+        check(_lib.load().cnk_channel_shuffle(_p(x), _p(y), N * H * W, C, groups, _dtype_code(x), _stream()))
+        ctx.groups, ctx.C = groups, C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _nhwc(dy)
+        N, C, H, W = dy.shape
+        dx = torch.empty_like(dy, memory_format=CL)
+        check(_lib.load().cnk_channel_shuffle(_p(dy), _p(dx), N * H * W, C, C // ctx.groups, _dtype_code(dy), _stream()))
+        return dx, None

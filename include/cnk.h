@@ -248,6 +248,18 @@ int cnk_dwconv2d_dgrad(const cnk_conv_desc* d, const void* dy, const float* w, v
 int cnk_dwconv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* General grouped conv (ShuffleNet's grouped 1x1 convs, shufflenet_v1.py:117-141: Cin != Cout, group widths off
+ * the 64-channel chunks): run the DENSE conv of the block-diagonal weight.  cnk_grouped_expand writes
+ * wd[Cout][Cin][T] (zeros off the diagonal) from w[Cout][Cin/groups][T] (T = kh*kw); cnk_grouped_extract reads the
+ * diagonal blocks of the dense weight gradient back into dw[Cout][Cin/groups][T].
+ * cnk_channel_shuffle: y[p][j*groups + i] = x[p][i*(C/groups) + j] on NHWC rows (shufflenet_v1.py:173-186); its
+ * gradient is the same call with groups' = C/groups. */
+int cnk_grouped_expand(const float* w, float* w_dense, int32_t Cout, int32_t Cin, int32_t groups, int32_t T,
+                       void* stream);
+int cnk_grouped_extract(const float* dw_dense, float* dw, int32_t Cout, int32_t Cin, int32_t groups, int32_t T,
+                        void* stream);
+int cnk_channel_shuffle(const void* x, void* y, int64_t pixels, int32_t C, int32_t groups, int dtype, void* stream);
+
 /* ---- classifier head -- fp32, row-major, no workspace ---------------------------
  * nn.Linear (resnet.py:106, vggnet.py:83-92): y[B][N] = x[B][K] W[N][K]^T + bias (bias may be NULL);
  * dx[B][K] = dy[B][N] W[N][K]; dW[N][K] (+)= dy^T x, dbias[N] (+)= column sums of dy (dbias may be

@@ -686,7 +686,66 @@ class RefSENet(RefBaseModel):                                      # senet.py:17
                                dim_synch=dim_synch, stride=stride, groups=cardinality)
 
 
+class RefShuffleUnit(nn.Module):                                   # shufflenet_v1.py:99-187
+    def __init__(self, network, num_output_channels, groups, stride, downsample, first_conv):
+        super().__init__()
+        self.groups = groups
+        self.downsample = downsample
+        bottleneck = num_output_channels // 4
+        ident = network.in_channels
+        if downsample:
+            num_output_channels -= ident
+        self.conv1x1_group_compress = RefConv2dBlock(network, num_filters=bottleneck, kernel_size=1,
+                                                     groups=1 if first_conv else groups)
+        self.conv3x3_depthwise = RefConv2dBlock(network, num_filters=bottleneck, activation=False, kernel_size=3,
+                                                stride=stride, padding=1, groups=bottleneck)
+        self.conv1x1_group_expand = RefConv2dBlock(network, num_filters=num_output_channels, activation=False,
+                                                   kernel_size=1, groups=groups)
+        if downsample:
+            network.in_channels += ident
+        self.avg_pool = network.avgpool2d(set_output=False, kernel_size=3, stride=2, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        identity = self.avg_pool(x) if self.downsample else x
+        out = self.conv1x1_group_compress(x)
+        n, c, h, w = out.shape
+        out = out.view(n, self.groups, c // self.groups, h, w).transpose(1, 2).contiguous().view(n, -1, h, w)
+        out = self.conv1x1_group_expand(self.conv3x3_depthwise(out))
+        if self.downsample:
+            out = torch.cat([identity, out], dim=1)
+        else:
+            out += identity
+        return self.relu(out)
+
+
+class RefShuffleNetV1(RefBaseModel):                               # shufflenet_v1.py:16-97
+    config = {
+        'g1': [(2, 1, 144), (1, 3, 144), (2, 1, 288), (1, 7, 288), (2, 1, 576), (1, 3, 576)],
+        'g2': [(2, 1, 200), (1, 3, 200), (2, 1, 400), (1, 7, 400), (2, 1, 800), (1, 3, 800)],
+        'g3': [(2, 1, 240), (1, 3, 240), (2, 1, 480), (1, 7, 480), (2, 1, 960), (1, 3, 960)],
+        'g4': [(2, 1, 272), (1, 3, 272), (2, 1, 544), (1, 7, 544), (2, 1, 1088), (1, 3, 1088)],
+        'g8': [(2, 1, 384), (1, 3, 384), (2, 1, 768), (1, 7, 768), (2, 1, 1536), (1, 3, 1536)],
+    }
+
+    def __init__(self, setting):
+        super().__init__(setting)
+        groups = int(str(setting.kind)[1:])
+        mods = [self.conv2d_block(num_filters=24, kernel_size=3, stride=2, padding=1),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1)]
+        for i, (stride, repeat, out_ch) in enumerate(self.config[str(setting.kind)]):
+            for j in range(repeat):
+                mods.append(RefShuffleUnit(self, out_ch, groups, stride, stride == 2, i == 0 and j == 0))
+        mods.append(self.adapt_avgpool2d(output_size=1))
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
           'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt,
           'inception': RefInceptionNetV1, 'squeezenet': RefSqueezeNet,
-          'densenet': RefDenseNet, 'seresnet': RefSEResNet, 'senet': RefSENet}
+          'densenet': RefDenseNet, 'seresnet': RefSEResNet, 'senet': RefSENet,
+          'shufflenet': RefShuffleNetV1}

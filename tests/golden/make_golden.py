@@ -45,6 +45,7 @@ def import_reference():
     import resnext
     import se_resnet
     import senet
+    import shufflenet_v1
     import squeezenet
     import settings
     import vggnet
@@ -62,6 +63,7 @@ def import_reference():
     basemodel.densenet = densenet
     basemodel.se_resnet = se_resnet
     basemodel.senet = senet
+    basemodel.shufflenet_v1 = shufflenet_v1
     return settings, basemodel, resnet, vggnet
 
 
@@ -244,7 +246,8 @@ def make_models(settings, basemodel, resnet, vggnet):
              ('squeezenet', basemodel.squeezenet.SqueezeNet, 1.1, (3, 64, 64), True, 16),
              ('densenet121', basemodel.densenet.DenseNet, 121, (3, 32, 32), True, 16),
              ('seresnet26', basemodel.se_resnet.SEResNet, 26, (3, 32, 32), True, 16),
-             ('senet26', basemodel.senet.SENet, 26, (3, 32, 32), True, 16)]
+             ('senet26', basemodel.senet.SENet, 26, (3, 32, 32), True, 16),
+             ('shufflenet_g4', basemodel.shufflenet_v1.ShuffleNetV1, 'g4', (3, 32, 32), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)

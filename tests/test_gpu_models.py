@@ -63,7 +63,7 @@ MODEL_CASES = [('resnet26', 'resnet', 26, (3, 32, 32), True), ('resnet18', 'resn
                ('mobilenet', 'mobilenet', 1, (3, 32, 32), True), ('resnext26', 'resnext', 26, (3, 32, 32), True),
                ('inception', 'inception', 1, (3, 32, 32), True), ('squeezenet', 'squeezenet', 1.1, (3, 64, 64), True),
                ('densenet121', 'densenet', 121, (3, 32, 32), True), ('seresnet26', 'seresnet', 26, (3, 32, 32), True),
-               ('senet26', 'senet', 26, (3, 32, 32), True)]
+               ('senet26', 'senet', 26, (3, 32, 32), True), ('shufflenet_g4', 'shufflenet', 'g4', (3, 32, 32), True)]
 
 
 @pytest.mark.parametrize('mixed', [False, True], ids=['f32', 'bf16'])
@@ -93,7 +93,7 @@ def test_model_one_step_golden(name, family, kind, in_size, bn, mixed):
     out = model(x.cuda())
     # bf16 vs fp32 is loose by nature (see the emulation test); MobileNet's 27 BN layers at 32x32 / batch 16
     # end in 1x1 maps normalised over 16 samples, which amplifies bf16 rounding most
-    t_out = 2e-4 if not mixed else (5e-1 if name in ('mobilenet', 'resnext26', 'inception', 'squeezenet', 'densenet121', 'seresnet26', 'senet26') else 2.5e-1)
+    t_out = 2e-4 if not mixed else (5e-1 if name in ('mobilenet', 'resnext26', 'inception', 'squeezenet', 'densenet121', 'seresnet26', 'senet26', 'shufflenet_g4') else 2.5e-1)
     assert rel_l2(host(out), g('logits')) < t_out
     for b in model.buffers():                   # undo the extra forward's running-stat update
         pass
@@ -105,6 +105,8 @@ def test_model_one_step_golden(name, family, kind, in_size, bn, mixed):
     loss, correct = model.train_batch((x, y))
     torch.cuda.synchronize()
     t_loss, t_g, t_w = (1e-4, 2e-3, 1e-4) if not mixed else (3e-2, 2.5e-1, 3e-2)
+    if name == 'shufflenet_g4' and not mixed:
+        t_w = 1e-3       # one BN bias has gradients ~1e-9: Adam's first step lr*g/(|g|+eps) moves it by a noise-decided amount
     assert abs(float(loss) - float(g('loss'))) <= t_loss * abs(float(g('loss')))
     if not mixed:
         assert int(correct) == int(g('correct'))

@@ -106,12 +106,14 @@ def test_factory_returns_stock_subclasses_and_tracks_shapes():
     assert c.bias is not None and (nobn.height, nobn.width) == (26, 26)
     dwc = net.conv2d_depthwise(kernel_size=3, padding=1, set_output=False)       # basemodel.py:981-997
     assert isinstance(dwc, nn.Conv2d) and dwc.groups == 64 and tuple(dwc.weight.shape) == (64, 1, 3, 3)
-    with pytest.raises(NotImplementedError):                                     # channel multiplier != 1
-        net.conv2d_depthwise(num_filters=128, kernel_size=3)
+    dm = net.conv2d_depthwise(num_filters=128, kernel_size=3, set_output=False)   # channel multiplier 2: dense grouped path
+    assert dm.groups == 64 and dm._dense_grouped and not dm._depthwise
     gc = net.conv2d(num_filters=64, kernel_size=3, groups=32, set_output=False)    # ResNeXt cardinality (resnext.py:82-96)
     assert gc.groups == 32 and tuple(gc.weight.shape) == (64, 2, 3, 3)
-    with pytest.raises(NotImplementedError):                                     # group width 3 does not divide 64
-        net.conv2d(in_channels=96, num_filters=96, kernel_size=3, groups=32)
+    gd = net.conv2d(in_channels=96, num_filters=48, kernel_size=1, groups=3, set_output=False)   # ShuffleNet-style: dense path
+    assert gd._dense_grouped and tuple(gd.weight.shape) == (48, 32, 1, 1)
+    with pytest.raises(NotImplementedError):                                     # dilation is not implemented
+        net.conv2d(in_channels=64, num_filters=64, kernel_size=3, dilation=2)
     with pytest.raises(TypeError):
         ca.Settings(kind=0, input_size=(1, 2, 2), num_classes=2, no_such_field=1)
 

@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import convnets_amd as ca
-family, kind, size, classes, bs, dt = sys.argv[1], (float(sys.argv[2]) if '.' in sys.argv[2] else int(sys.argv[2])), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+family, kind, size, classes, bs, dt = sys.argv[1], (float(sys.argv[2]) if '.' in sys.argv[2] else int(sys.argv[2]) if sys.argv[2].isdigit() else sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 torch.manual_seed(21)
 s = ca.Settings(kind=kind, input_size=(3, size, size), num_classes=classes, batch_size=bs, mixed_precision=dt == 'bf16')
 m = ca.MODELS[family](s).cuda(); m.init_optimizer(); m.train()
