@@ -21,10 +21,11 @@ from .squeezenet import SqueezeNet                              # noqa: F401
 from .densenet import DenseNet                                  # noqa: F401
 from .senet import SENet, SEResNet                              # noqa: F401
 from .shufflenet import ShuffleNetV1                            # noqa: F401
+from .sknet import SKNet, SKResNet                              # noqa: F401
 from .optim import FlatAdam                                     # noqa: F401
 
 MODELS = {'resnet': ResNet, 'vgg': VGGNet, 'convnet': ConvNet, 'lenet5': LeNet5, 'alexnet': AlexNet,
           'mobilenet': MobileNetV1, 'resnext': ResNeXt,
           'inception': InceptionNetV1, 'squeezenet': SqueezeNet,
           'densenet': DenseNet, 'seresnet': SEResNet, 'senet': SENet,
-          'shufflenet': ShuffleNetV1}
+          'shufflenet': ShuffleNetV1, 'sknet': SKNet, 'skresnet': SKResNet}

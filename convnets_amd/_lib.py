@@ -18,7 +18,7 @@ CLS = dict(conv3x3_fwd=1, conv3x3_dgrad=2, conv3x3_wgrad=4, conv1x1_fwd=8, conv1
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('N', 'H', 'W', 'Cin', 'Cout', 'kh', 'kw', 'stride_h', 'stride_w', 'pad_h', 'pad_w',
-                 'dtype', 'groups')]
+                 'dtype', 'groups', 'dilation')]
 
 
 class BnBwdFuse(ctypes.Structure):
@@ -92,6 +92,12 @@ SIGNATURES = {
     'cnk_sigmoid_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
     'cnk_channel_scale_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_channel_scale_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_sk_workspace_bytes': (ctypes.c_size_t, [_i32, _i32, _i32, _i32]),
+    'cnk_sk_pool_fwd': (ctypes.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    'cnk_sk_select_fwd': (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_sk_select_bwd_logits': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_int, _vp,
+                                                ctypes.c_size_t, _vp]),
+    'cnk_sk_maps_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_input_pipeline': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 7 + [ctypes.c_int, _vp]),
     'cnk_grad_clip_workspace_bytes': (_sz, []),
     'cnk_grad_clip_norm': (ctypes.c_int, [_vp, _i64, _f32, _vp, _vp, _sz, _vp]),

@@ -34,6 +34,12 @@ int sigmoid_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 int sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, hipStream_t s);
 int channel_scale_fwd(const void* x, const float* g, void* y, int N, int HW, int C, int dtype, hipStream_t s);
 int channel_scale_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, int N, int HW, int C, int dtype, hipStream_t s);
+bool sk_supported(int C, int P, int dtype);
+size_t sk_workspace(int N, int HW, int C, int P);
+int sk_pool_fwd(const void* const* u, int P, float* pooled, int N, int HW, int C, int dtype, float* ws, hipStream_t s);
+int sk_select_fwd(const void* const* u, const float* const* logits, int P, float* attn, void* out, int N, int HW, int C, int dtype, hipStream_t s);
+int sk_select_bwd_logits(const void* const* u, const float* attn, const void* dout, float* const* dlogits, int P, int N, int HW, int C, int dtype, float* ws, hipStream_t s);
+int sk_maps_bwd(const void* dout, const float* attn, const float* dpooled, void* const* du, int P, int N, int HW, int C, int dtype, hipStream_t s);
 int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const float* mean, const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype, hipStream_t s);
 int grouped_expand(const float* w, float* wd, int Cout, int Cin, int groups, int T, hipStream_t s);
 int grouped_extract(const float* dwd, float* dw, int Cout, int Cin, int groups, int T, hipStream_t s);
@@ -140,9 +146,12 @@ static int check_desc(const cnk_conv_desc* d, const char* fn) {
     CNK_CHECK_ARG(d->dtype == CNK_F32 || d->dtype == CNK_BF16, "%s: bad dtype %d", fn, d->dtype);
     CNK_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive dims", fn);
     CNK_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0, "%s: bad kernel/stride/pad", fn);
-    CNK_CHECK_ARG(d->H + 2 * d->pad_h >= d->kh && d->W + 2 * d->pad_w >= d->kw, "%s: kernel larger than padded input", fn);
+    const int dl = conv_dil(d);
+    CNK_CHECK_ARG(d->H + 2 * d->pad_h >= dl * (d->kh - 1) + 1 && d->W + 2 * d->pad_w >= dl * (d->kw - 1) + 1, "%s: kernel larger than padded input", fn);
+    CNK_CHECK_ARG(dl == 1 || (igemm_supported(d, CNK_PASS_FWD) && igemm_supported(d, CNK_PASS_DGRAD) && wgrad_mfma_supported(d) && (dl * (d->kh - 1) < 120 && dl * (d->kw - 1) < 120)),
+                  "%s: dilation=%d is implemented on the implicit-GEMM kernels only (channel counts that are multiples of 8)", fn, dl);
     CNK_CHECK_ARG(conv_groups(d) == 1 || igemm_grouped_ok(d), "%s: groups=%d needs Cin == Cout, Cin %% 64 == 0 and a group width that divides 64 (depthwise: cnk_dwconv2d_*)", fn, d->groups);
-    int64_t Ho = (d->H + 2 * d->pad_h - d->kh) / d->stride_h + 1, Wo = (d->W + 2 * d->pad_w - d->kw) / d->stride_w + 1;
+    int64_t Ho = (d->H + 2 * d->pad_h - dl * (d->kh - 1) - 1) / d->stride_h + 1, Wo = (d->W + 2 * d->pad_w - dl * (d->kw - 1) - 1) / d->stride_w + 1;
     CNK_CHECK_ARG((int64_t)d->N * d->H * d->W < (1ll << 31) && (int64_t)d->N * Ho * Wo < (1ll << 31), "%s: pixel count exceeds 2^31", fn);
     return 0;
 }
@@ -166,8 +175,9 @@ int cnk_version(void) { return 100; }
 const char* cnk_last_error(void) { return g_err; }
 
 int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo) {
-    *Ho = (d->H + 2 * d->pad_h - d->kh) / d->stride_h + 1;
-    *Wo = (d->W + 2 * d->pad_w - d->kw) / d->stride_w + 1;
+    const int dl = conv_dil(d);
+    *Ho = (d->H + 2 * d->pad_h - dl * (d->kh - 1) - 1) / d->stride_h + 1;
+    *Wo = (d->W + 2 * d->pad_w - dl * (d->kw - 1) - 1) / d->stride_w + 1;
     return 0;
 }
 
@@ -588,6 +598,41 @@ int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, 
 int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
     CNK_CHECK_ARG(dy && x && gate && dx && dgate && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_bwd: bad arguments");
     return channel_scale_bwd(dy, x, gate, dx, dgate, N, HW, C, dtype, S(stream));
+}
+
+static int sk_check(const char* fn, const void* const* ptrs, int P, int N, int HW, int C, int dtype) {
+    CNK_CHECK_ARG(dtype == CNK_F32 || dtype == CNK_BF16, "%s: bad dtype %d", fn, dtype);
+    CNK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && (int64_t)N * C < (1ll << 31), "%s: bad shape", fn);
+    CNK_CHECK_ARG(sk_supported(C, P, dtype), "%s: needs 1..4 paths and C %% %d == 0 (got P=%d, C=%d)", fn, dtype == CNK_BF16 ? 8 : 4, P, C);
+    CNK_CHECK_ARG(ptrs, "%s: null pointer table", fn);
+    for (int i = 0; i < P; ++i) CNK_CHECK_ARG(ptrs[i], "%s: null pointer for path %d", fn, i);
+    return 0;
+}
+size_t cnk_sk_workspace_bytes(int32_t N, int32_t HW, int32_t C, int32_t P) {
+    return N > 0 && HW > 0 && C > 0 && P > 0 ? sk_workspace(N, HW, C, P) : 0;
+}
+int cnk_sk_pool_fwd(const void* const* u, int32_t P, float* pooled, int32_t N, int32_t HW, int32_t C, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = sk_check("cnk_sk_pool_fwd", u, P, N, HW, C, dtype)) return rc;
+    CNK_CHECK_ARG(pooled && ws && ws_bytes >= sk_workspace(N, HW, C, 1), "cnk_sk_pool_fwd: null output or workspace too small");
+    return sk_pool_fwd(u, P, pooled, N, HW, C, dtype, (float*)ws, S(stream));
+}
+int cnk_sk_select_fwd(const void* const* u, const float* const* logits, int32_t P, float* attn, void* out, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
+    if (int rc = sk_check("cnk_sk_select_fwd", u, P, N, HW, C, dtype)) return rc;
+    if (int rc = sk_check("cnk_sk_select_fwd", (const void* const*)logits, P, N, HW, C, dtype)) return rc;
+    CNK_CHECK_ARG(attn && out, "cnk_sk_select_fwd: null output");
+    return sk_select_fwd(u, logits, P, attn, out, N, HW, C, dtype, S(stream));
+}
+int cnk_sk_select_bwd_logits(const void* const* u, const float* attn, const void* dout, float* const* dlogits, int32_t P, int32_t N, int32_t HW, int32_t C, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = sk_check("cnk_sk_select_bwd_logits", u, P, N, HW, C, dtype)) return rc;
+    if (int rc = sk_check("cnk_sk_select_bwd_logits", (const void* const*)dlogits, P, N, HW, C, dtype)) return rc;
+    CNK_CHECK_ARG(attn && dout && ws && ws_bytes >= sk_workspace(N, HW, C, P), "cnk_sk_select_bwd_logits: null operand or workspace too small");
+    return sk_select_bwd_logits(u, attn, dout, dlogits, P, N, HW, C, dtype, (float*)ws, S(stream));
+}
+int cnk_sk_maps_bwd(const void* dout, const float* attn, const float* dpooled, void* const* du, int32_t P, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
+    if (int rc = sk_check("cnk_sk_maps_bwd", (const void* const*)du, P, N, HW, C, dtype)) return rc;
+    CNK_CHECK_ARG((dout && attn) || dpooled, "cnk_sk_maps_bwd: needs dout + attn and/or dpooled");
+    CNK_CHECK_ARG(!dout == !attn, "cnk_sk_maps_bwd: dout and attn go together");
+    return sk_maps_bwd(dout, attn, dpooled, du, P, N, HW, C, dtype, S(stream));
 }
 
 int cnk_input_pipeline(const uint8_t* x, void* y, const int32_t* crop_yx, const uint8_t* flip, const float* mean, const float* std, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t pad, int dtype, void* stream) {

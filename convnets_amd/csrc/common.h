@@ -110,4 +110,5 @@ struct DgradClass {
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int conv_groups(const cnk_conv_desc* d) { return d->groups > 1 ? d->groups : 1; }
+static inline int conv_dil(const cnk_conv_desc* d) { return d->dilation > 1 ? d->dilation : 1; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -864,8 +864,8 @@ int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const fl
     p.ntaps = d->kh * d->kw;
     for (int r = 0; r < d->kh; ++r)
         for (int c = 0; c < d->kw; ++c) {
-            p.dh[r * d->kw + c] = (signed char)(r - d->pad_h);
-            p.dw[r * d->kw + c] = (signed char)(c - d->pad_w);
+            p.dh[r * d->kw + c] = (signed char)(r * conv_dil(d) - d->pad_h);
+            p.dw[r * d->kw + c] = (signed char)(c * conv_dil(d) - d->pad_w);
         }
     p.M = d->N * Ho * Wo;
     p.fd_ohw = make_fastdiv(Ho * Wo);
@@ -885,10 +885,10 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w]
             c.OW = pw < d->W ? (d->W - pw + d->stride_w - 1) / d->stride_w : 0;
             c.ntaps = 0;
             for (int r = 0; r < d->kh; ++r) {
-                int th = ph + d->pad_h - r;
+                int th = ph + d->pad_h - r * conv_dil(d);
                 if (th % d->stride_h) continue;
                 for (int q = 0; q < d->kw; ++q) {
-                    int tw = pw + d->pad_w - q;
+                    int tw = pw + d->pad_w - q * conv_dil(d);
                     if (tw % d->stride_w) continue;
                     if (c.ntaps < MAX_TAPS) {
                         c.kh[c.ntaps] = (signed char)r; c.kw[c.ntaps] = (signed char)q;

@@ -20,7 +20,7 @@ struct WgradParams {
     const void* dy;
     const void* x;
     float* slab;
-    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, sh, sw, ph, pw, dil;
     int M;
     int ksteps, ksteps_per_split, splits;
     int tiles_co, tiles_ci, ntaps;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
                 uint32_t rem = m - img * p.fd_howo.d;
                 uint32_t ho = fd_div(rem, p.fd_wo);
                 uint32_t wo = rem - ho * p.fd_wo.d;
-                int ih = (int)ho * p.sh - p.ph + kh, iw = (int)wo * p.sw - p.pw + kw;
+                int ih = (int)ho * p.sh - p.ph + kh * p.dil, iw = (int)wo * p.sw - p.pw + kw * p.dil;
                 if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
                     v = *(const u32x4*)(x + ((size_t)(img * p.H + ih) * p.W + iw) * p.Cin +
                                         tile_ci * BNW + c * PER16);
@@ -357,6 +357,7 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     p.dy = dy; p.x = x; p.slab = (float*)ws;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
     p.KH = d->kh; p.KW = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+    p.dil = conv_dil(d);
     p.M = d->N * Ho * Wo;
     p.tiles_co = ceil_div(d->Cout, bmw); p.tiles_ci = grouped ? 1 : ceil_div(d->Cin, bnw); p.ntaps = d->kh * d->kw;
     p.diag = grouped;

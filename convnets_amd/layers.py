@@ -30,8 +30,14 @@ class Conv2d(nn.Conv2d):
         self._chunked = self.groups > 1 and not self._depthwise and self.in_channels == self.out_channels \
             and self.in_channels % 64 == 0 and 64 % gw == 0
         self._dense_grouped = self.groups > 1 and not self._depthwise and not self._chunked
-        if _pair(self.dilation) != (1, 1) or self.padding_mode != 'zeros' or isinstance(self.padding, str):
-            raise NotImplementedError('convnets_amd.Conv2d: dilation=1 and zeros padding only')
+        dl = _pair(self.dilation)
+        self._dil = dl[0]
+        vec_ok = self.in_channels % 8 == 0 and self.out_channels % 8 == 0 and self.in_channels >= 32 \
+            and self.out_channels >= 16 and not self._depthwise and not self._dense_grouped
+        if dl[0] != dl[1] or (dl[0] != 1 and not vec_ok) or self.padding_mode != 'zeros' \
+                or isinstance(self.padding, str):
+            raise NotImplementedError('convnets_amd.Conv2d: zeros padding; dilation (equal in h and w) only on the '
+                                      'implicit-GEMM shapes (channel counts that are multiples of 8, not depthwise)')
         self._packed = ops.PackedWeights()
 
     def __deepcopy__(self, memo):
@@ -54,7 +60,8 @@ class Conv2d(nn.Conv2d):
             return ops.Conv2dFn.apply(x, wd, self.bias, _pair(self.stride), _pair(self.padding),
                                       self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), 1)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
-                                  self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups)
+                                  self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups,
+                                  self._dil)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -194,6 +201,36 @@ class SEUnit(nn.Module):
         return ops.ChannelScaleFn.apply(x, gate)
 
 
+class SKConv(nn.Module):
+    """Selective-kernel convolution (src/sknet.py:172-240, identical in src/sk_resnet.py:171-239): num_paths
+    grouped 3x3 conv blocks with dilation 1+i, their sum squeezed by a global average pool into a descriptor
+    (1x1 conv block), one 1x1 attention conv per path, softmax across the paths and the attention-weighted sum.
+    Child names kernels / attentions / global_avgpool / descriptor / softmax as in the reference (same
+    state_dict keys).  The fuse sum + pool and the softmax + weighted sum are one HIP pass each (csrc/sk.hip)."""
+
+    def __init__(self, network, num_paths=2, groups=32, reduction=16, min_descriptor=32, **kwargs):
+        super().__init__()
+        self.num_paths = num_paths
+        self.num_features = network.in_channels
+        self.kernels = nn.ModuleList([])
+        self.attentions = nn.ModuleList([])
+        descriptor_size = max(network.in_channels // reduction, min_descriptor)
+        for i in range(num_paths):
+            self.kernels.append(Conv2dBlock(network, num_filters=network.in_channels, set_output=False, kernel_size=3,
+                                            padding=1 + i, dilation=1 + i, groups=groups, **kwargs))
+            self.attentions.append(nn.Sequential(Conv2d(descriptor_size, network.in_channels, kernel_size=1)))
+        self.global_avgpool = network.adapt_avgpool2d(set_output=False, output_size=1)
+        self.descriptor = Conv2dBlock(network, num_filters=descriptor_size, set_output=False, kernel_size=1)
+        self.softmax = nn.Softmax(dim=1)              # kept for the module tree; the math runs in cnk_sk_select_fwd
+
+    def forward(self, x):
+        maps = [path(x) for path in self.kernels]
+        link = ops.SKLink() if torch.is_grad_enabled() and maps[0].requires_grad else None
+        features = self.descriptor(ops.SKPoolFn.apply(link, *maps))
+        logits = [attention(features) for attention in self.attentions]
+        return ops.SKSelectFn.apply(link, self.num_paths, *maps, *logits)
+
+
 class ConvBlock(nn.Sequential):
     """conv -> [BN] -> [ReLU] as conv2d_block builds it (basemodel.py:999-1015): an nn.Sequential
     with children '0','1','2' (same state_dict keys), whose forward runs BN + ReLU (+ the residual
@@ -217,7 +254,7 @@ class ConvBlock(nn.Sequential):
                 stamp = (ops.weights_epoch(), getattr(bn, '_stats_epoch', 0), id(conv.weight), conv.weight._version,
                          bn.running_mean._version, bn.running_var._version, bn.weight._version, bn.bias._version)
                 y = fold.run(x, conv.weight, conv.bias, bn, _pair(conv.stride), _pair(conv.padding), residual,
-                             act or relu_after_add, stamp, conv.groups)
+                             act or relu_after_add, stamp, conv.groups, conv._dil)
                 if y is not None:
                     return y
             return bn(conv(x), residual=residual, relu=act or relu_after_add)

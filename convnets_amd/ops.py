@@ -133,13 +133,13 @@ def join_side_streams(device=None):
             torch.cuda.current_stream(dev).wait_stream(st)
 
 
-def make_desc(x_shape, weight_shape, stride, padding, dtype_code, groups=1):
+def make_desc(x_shape, weight_shape, stride, padding, dtype_code, groups=1, dilation=1):
     N, Cin, H, W = x_shape
     Cout, Cin_w, kh, kw = weight_shape
     if Cin != Cin_w * groups:
         raise ValueError('conv2d: input has %d channels, weight expects %d' % (Cin, Cin_w * groups))
     return ConvDesc(N, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1],
-                    dtype_code, groups)
+                    dtype_code, groups, dilation)
 
 
 def masked_grad(dy, mask):
@@ -296,9 +296,9 @@ class PackedWeights:
                 and self.key[1] == weight._version:
             if self.batched_epoch != weights_epoch():
                 packer_for(weight.device).ensure()
-            self.key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad, desc.groups)
+            self.key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad, desc.groups, desc.dilation)
             return self.w_fwd, self.w_dgrad
-        key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad, desc.groups)
+        key = (weight.data_ptr(), weight._version, weights_epoch(), desc.dtype, need_dgrad, desc.groups, desc.dilation)
         if self.key != key:
             dev = weight.device
             nf = lib.cnk_conv2d_packed_bytes(ctypes.byref(desc), PASS_FWD)
@@ -327,7 +327,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None,
-                bn_rec=None, groups=1):
+                bn_rec=None, groups=1, dilation=1):
         """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
         of y emitted by the conv epilogue (None when this conv shape cannot produce them).
         link: optional GradLink shared with the other consumer of x (residual blocks)."""
@@ -337,7 +337,7 @@ class Conv2dFn(torch.autograd.Function):
         x_needs_grad = x.requires_grad        # before any layout copy made here (forward runs under no_grad)
         x = _nhwc(x)
         w = weight if weight.is_contiguous() else weight.contiguous()
-        desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x), groups)
+        desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x), groups, dilation)
         need_dgrad = x_needs_grad
         w_fwd, w_dgrad = packed.get(w, desc, need_dgrad)
         Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
@@ -367,7 +367,7 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
         if dy is None:                        # y took no part in the loss
-            return (None,) * 10
+            return (None,) * 11
         x, w = ctx.saved_tensors
         desc = ctx.desc
         dy = _nhwc(dy)
@@ -444,7 +444,7 @@ class Conv2dFn(torch.autograd.Function):
                 _join_at_end_of_backward()
             else:
                 run_wgrad()
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -856,13 +856,13 @@ class FoldedConv:
         self.stamp = None
         self.w_img = self.bias = None
 
-    def run(self, x, conv_weight, conv_bias, bn, stride, padding, residual, relu, stamp, groups=1):
+    def run(self, x, conv_weight, conv_bias, bn, stride, padding, residual, relu, stamp, groups=1, dilation=1):
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
         if groups > 1 and groups == x.shape[1]:
             return None                                   # depthwise: own kernels, not folded
-        desc = make_desc(x.shape, conv_weight.shape, stride, padding, _dtype_code(x), groups)
+        desc = make_desc(x.shape, conv_weight.shape, stride, padding, _dtype_code(x), groups, dilation)
         if not lib.cnk_conv2d_fwd_act_supported(ctypes.byref(desc)):
             return None
         key = (stamp, desc.dtype, x.device)
@@ -1031,6 +1031,103 @@ class ChannelScaleFn(torch.autograd.Function):
         check(lib.cnk_channel_scale_bwd(_p(dy), _p(x), _p(gate), _p(dx), _p(dgate), N, H * W, C, _dtype_code(x),
                                         _stream()))
         return dx, dgate
+
+
+# ---- selective-kernel unit (sknet.py:172-240) ---------------------------------------------------------
+def _ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class SKLink:
+    """Joins the two backward passes of one SKConv.  Each feature map U_i is read twice in forward (by the fuse
+    sum and by the select sum).  The select backward runs first (its output is the block's activation); it hands
+    (dout, attn) to the pool backward, which runs last (its gradient comes back through descriptor + attentions)
+    and writes dU_i = dout * a_i + dpooled / HW in ONE pass over the maps instead of two passes plus an add."""
+
+    def __init__(self):
+        self.pool_pending = False
+        self.stash = None
+
+
+class SKPoolFn(torch.autograd.Function):
+    """torch.sum(feature_maps, dim=1) + AdaptiveAvgPool2d(1) (sknet.py:227-228) -> fp32 [N, C, 1, 1]."""
+
+    @staticmethod
+    def forward(ctx, link, *maps):
+        _require_gpu(maps[0])
+        lib = _lib.load()
+        maps = [_nhwc(u) for u in maps]
+        N, C, H, W = maps[0].shape
+        if any(u.shape != maps[0].shape or u.dtype != maps[0].dtype for u in maps):
+            raise ValueError('sk pool: the paths must produce one shape and dtype')
+        pooled = torch.empty((N, C, 1, 1), dtype=torch.float32, device=maps[0].device)
+        nws = lib.cnk_sk_workspace_bytes(N, H * W, C, 1)
+        ws = workspace(nws, pooled.device)
+        check(lib.cnk_sk_pool_fwd(_ptr_table(maps), len(maps), _p(pooled), N, H * W, C, _dtype_code(maps[0]), _p(ws), nws,
+                                  _stream()))
+        ctx.link, ctx.shape, ctx.dt, ctx.P = link, maps[0].shape, maps[0].dtype, len(maps)
+        if link is not None:
+            link.pool_pending = any(ctx.needs_input_grad[1:])
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        lib = _lib.load()
+        N, C, H, W = ctx.shape
+        dpooled = dpooled.contiguous().float()
+        link = ctx.link
+        dout, attn = (None, None)
+        if link is not None:
+            link.pool_pending = False
+            if link.stash is not None:
+                dout, attn = link.stash
+                link.stash = None
+        du = [torch.empty(ctx.shape, dtype=ctx.dt, device=dpooled.device, memory_format=CL) for _ in range(ctx.P)]
+        check(lib.cnk_sk_maps_bwd(_p(dout), _p(attn), _p(dpooled), _ptr_table(du), ctx.P, N, H * W, C,
+                                  CNK_BF16 if ctx.dt == torch.bfloat16 else CNK_F32, _stream()))
+        return (None,) + tuple(du)
+
+
+class SKSelectFn(torch.autograd.Function):
+    """softmax over the paths of the attention logits, then the attention-weighted sum of the feature maps
+    (sknet.py:231-237).  Arguments: link, P, then the P maps, then the P fp32 logits [N, C, 1, 1]."""
+
+    @staticmethod
+    def forward(ctx, link, P, *args):
+        lib = _lib.load()
+        maps = [_nhwc(u) for u in args[:P]]
+        logits = [l.contiguous() for l in args[P:]]
+        _require_gpu(maps[0])
+        N, C, H, W = maps[0].shape
+        if len(logits) != P or any(l.dtype != torch.float32 or l.numel() != N * C for l in logits):
+            raise ValueError('sk select: one fp32 [N, C, 1, 1] logit tensor per path')
+        attn = torch.empty((P, N, C), dtype=torch.float32, device=maps[0].device)
+        out = torch.empty_like(maps[0], memory_format=CL)
+        check(lib.cnk_sk_select_fwd(_ptr_table(maps), _ptr_table(logits), P, _p(attn), _p(out), N, H * W, C,
+                                    _dtype_code(out), _stream()))
+        ctx.save_for_backward(attn, *maps)
+        ctx.link, ctx.P, ctx.lshape = link, P, logits[0].shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        attn, maps = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
+        P, link = ctx.P, ctx.link
+        dout = _nhwc(dout)
+        N, C, H, W = maps[0].shape
+        dt = _dtype_code(maps[0])
+        dlogits = [torch.empty(ctx.lshape, dtype=torch.float32, device=dout.device) for _ in range(P)]
+        nws = lib.cnk_sk_workspace_bytes(N, H * W, C, P)
+        ws = workspace(nws, dout.device)
+        check(lib.cnk_sk_select_bwd_logits(_ptr_table(maps), _p(attn), _p(dout), _ptr_table(dlogits), P, N, H * W, C, dt,
+                                           _p(ws), nws, _stream()))
+        if link is not None and link.pool_pending and any(ctx.needs_input_grad[2:2 + P]):
+            link.stash = (dout, attn)                  # SKPoolFn.backward writes the map gradients
+            return (None, None) + (None,) * P + tuple(dlogits)
+        du = [torch.empty_like(maps[0], memory_format=CL) for _ in range(P)]
+        check(lib.cnk_sk_maps_bwd(_p(dout), _p(attn), None, _ptr_table(du), P, N, H * W, C, dt, _stream()))
+        return (None, None) + tuple(du) + tuple(dlogits)
 
 
 def input_pipeline(images_u8, mean, std, dtype, crop_size=None, padding=0, crop_yx=None, flip=None):

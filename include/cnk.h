@@ -46,12 +46,13 @@ typedef struct cnk_conv_desc {
     int32_t pad_h, pad_w;
     int32_t dtype;             /* element type of x, y, dy, dx        */
     int32_t groups;
+    int32_t dilation;          /* 0 or 1 = none; > 1 (SKNet's second path, sknet.py:198): implicit-GEMM shapes only */
 } cnk_conv_desc;
 
 int cnk_version(void);
 const char* cnk_last_error(void);
 
-/* Output spatial size, floor((H + 2p - k)/s) + 1 -- the reference's shape tracker formula
+/* Output spatial size, floor((H + 2p - dilation*(k-1) - 1)/s) + 1 -- the reference's shape tracker formula
  * (basemodel.py:770-771). */
 int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo);
 
@@ -299,6 +300,25 @@ int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, 
                           void* stream);
 int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N,
                           int32_t HW, int32_t C, int dtype, void* stream);
+
+/* ---- selective-kernel unit (reference src/sknet.py:172-240 == src/sk_resnet.py:171-239) -----------------
+ * P (<= 4) NHWC feature maps u[i] of one shape [N][HW][C] (the grouped, dilated conv paths, sknet.py:186-198).
+ * `u`, `logits`, `dlogits`, `du` are HOST arrays of P device pointers.  C must be a multiple of 8 (bf16) / 4 (f32).
+ *   cnk_sk_pool_fwd    pooled[n][c] = mean_hw sum_i u_i        -- torch.sum(feature_maps, 1) + global_avgpool, :222-228
+ *   cnk_sk_select_fwd  attn[i][n][c] = softmax_i(logits_i[n][c]); out = sum_i u_i * attn_i   -- :231-237
+ *   cnk_sk_select_bwd_logits  dlogits_i from dout (reduction over HW + the softmax Jacobian)
+ *   cnk_sk_maps_bwd    du_i = dout * attn_i + dpooled / HW  (the gradient of BOTH reads of u_i in one pass;
+ *                      dout/attn or dpooled may be NULL, not both)
+ * ws: cnk_sk_workspace_bytes(N, HW, C, P) bytes (fixed-order partial sums; deterministic). */
+size_t cnk_sk_workspace_bytes(int32_t N, int32_t HW, int32_t C, int32_t P);
+int cnk_sk_pool_fwd(const void* const* u, int32_t P, float* pooled, int32_t N, int32_t HW, int32_t C, int dtype,
+                    void* ws, size_t ws_bytes, void* stream);
+int cnk_sk_select_fwd(const void* const* u, const float* const* logits, int32_t P, float* attn, void* out, int32_t N,
+                      int32_t HW, int32_t C, int dtype, void* stream);
+int cnk_sk_select_bwd_logits(const void* const* u, const float* attn, const void* dout, float* const* dlogits, int32_t P,
+                             int32_t N, int32_t HW, int32_t C, int dtype, void* ws, size_t ws_bytes, void* stream);
+int cnk_sk_maps_bwd(const void* dout, const float* attn, const float* dpooled, void* const* du, int32_t P, int32_t N,
+                    int32_t HW, int32_t C, int dtype, void* stream);
 
 /* Gradient clipping over the same flat fp32 gradient arena (gradient_clipping, basemodel.py:131-178).
  * cnk_grad_clip_norm == torch.nn.utils.clip_grad_norm_(params, max_norm) (L2, basemodel.py:156): the

@@ -744,8 +744,94 @@ class RefShuffleNetV1(RefBaseModel):                               # shufflenet_
             self.init_params()
 
 
+class RefSKConv(nn.Module):                                        # sknet.py:172-240 == sk_resnet.py:171-239
+    def __init__(self, network, num_paths=2, groups=32, reduction=16, min_descriptor=32, **kwargs):
+        super().__init__()
+        self.num_paths = num_paths
+        self.num_features = network.in_channels
+        self.kernels = nn.ModuleList([])
+        self.attentions = nn.ModuleList([])
+        width = max(network.in_channels // reduction, min_descriptor)
+        for i in range(num_paths):
+            self.kernels.append(RefConv2dBlock(network, num_filters=network.in_channels, set_output=False,
+                                               kernel_size=3, padding=1 + i, dilation=1 + i, groups=groups, **kwargs))
+            self.attentions.append(nn.Sequential(nn.Conv2d(width, network.in_channels, kernel_size=1)))
+        self.global_avgpool = network.adapt_avgpool2d(set_output=False, output_size=1)
+        self.descriptor = RefConv2dBlock(network, num_filters=width, set_output=False, kernel_size=1)
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, x):
+        maps = torch.stack([path(x) for path in self.kernels], dim=1)          # [N, P, C, H, W]
+        squeezed = self.descriptor(self.global_avgpool(maps.sum(dim=1)))
+        logits = torch.stack([att(squeezed) for att in self.attentions], dim=1)   # [N, P, C, 1, 1]
+        return (maps * self.softmax(logits)).sum(dim=1)
+
+
+class RefSKBlock(nn.Module):                                       # sknet.py:133-170, sk_resnet.py:131-169
+    def __init__(self, network, num_filters, expansion, dim_synch=None, seq_name='sk_bottleneck', **kwargs):
+        super().__init__()
+        self.dim_synch = dim_synch
+        self.seq_name = seq_name                                   # 'sk_bottleneck' in sknet.py, 'res_bottleneck' in sk_resnet.py
+        setattr(self, seq_name, nn.Sequential(
+            RefConv2dBlock(network, num_filters=num_filters, kernel_size=1),
+            RefSKConv(network, **kwargs),
+            RefConv2dBlock(network, num_filters=num_filters * expansion, activation=False, kernel_size=1)))
+
+    def forward(self, x):
+        identity = x
+        output = getattr(self, self.seq_name)(x)
+        if self.dim_synch is not None:
+            identity = self.dim_synch(identity)
+        output += identity
+        return F.relu(output)
+
+
+class _RefSKModel(RefBaseModel):
+    def __init__(self, setting):
+        super().__init__(setting)
+        mods = [self.conv2d_block(num_filters=64, kernel_size=7, stride=2, padding=3),
+                self.maxpool2d(kernel_size=3, stride=2, padding=1)]
+        for num_filters, num_repeat, stride in self.config[str(setting.kind)]:
+            mods.append(self.make_block(num_filters, stride))
+            for _ in range(1, num_repeat):
+                mods.append(self.make_block(num_filters, 1))
+        mods.append(self.adapt_avgpool2d(output_size=1))
+        self.features = nn.Sequential(*mods)
+        self.classifier = nn.Sequential(nn.Dropout(p=setting.dropout_rate),
+                                        nn.Linear(self.num_flat_features(), setting.num_classes))
+        if setting.init_params:
+            self.init_params()
+
+
+class RefSKNet(_RefSKModel):                                       # sknet.py:17-131
+    config = RefResNeXt.config
+
+    def make_block(self, num_filters, stride):                     # sk_block, :86-112 (expansion 2, cardinality 32)
+        if stride != 1 or self.in_channels != num_filters * 2:
+            keep = self.in_channels
+            dim_synch = self.conv2d_block(self.in_channels, num_filters * 2, set_output=True, activation=False,
+                                          kernel_size=1, stride=stride)
+            self.in_channels = keep
+        else:
+            dim_synch = None
+        return RefSKBlock(self, num_filters=num_filters, expansion=2, dim_synch=dim_synch, stride=stride, groups=32)
+
+
+class RefSKResNet(_RefSKModel):                                    # sk_resnet.py:17-129
+    config = {k: v[1] for k, v in RefResNet.config.items() if v[0] == 'bottleneck'}
+
+    def make_block(self, num_filters, stride):                     # sk_residual_block, :87-110 (expansion 4)
+        if stride != 1 or self.in_channels != num_filters * 4:
+            dim_synch = self.conv2d_block(self.in_channels, num_filters * 4, set_output=False, activation=False,
+                                          kernel_size=1, stride=stride)
+        else:
+            dim_synch = None
+        return RefSKBlock(self, num_filters=num_filters, expansion=4, dim_synch=dim_synch, seq_name='res_bottleneck',
+                          stride=stride)
+
+
 MODELS = {'resnet': RefResNet, 'vgg': RefVGGNet, 'convnet': RefConvNet, 'lenet5': RefLeNet5,
           'alexnet': RefAlexNet, 'mobilenet': RefMobileNetV1, 'resnext': RefResNeXt,
           'inception': RefInceptionNetV1, 'squeezenet': RefSqueezeNet,
           'densenet': RefDenseNet, 'seresnet': RefSEResNet, 'senet': RefSENet,
-          'shufflenet': RefShuffleNetV1}
+          'shufflenet': RefShuffleNetV1, 'sknet': RefSKNet, 'skresnet': RefSKResNet}

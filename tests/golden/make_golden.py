@@ -46,6 +46,8 @@ def import_reference():
     import se_resnet
     import senet
     import shufflenet_v1
+    import sk_resnet
+    import sknet
     import squeezenet
     import settings
     import vggnet
@@ -64,6 +66,8 @@ def import_reference():
     basemodel.se_resnet = se_resnet
     basemodel.senet = senet
     basemodel.shufflenet_v1 = shufflenet_v1
+    basemodel.sknet = sknet
+    basemodel.sk_resnet = sk_resnet
     return settings, basemodel, resnet, vggnet
 
 
@@ -247,7 +251,9 @@ def make_models(settings, basemodel, resnet, vggnet):
              ('densenet121', basemodel.densenet.DenseNet, 121, (3, 32, 32), True, 16),
              ('seresnet26', basemodel.se_resnet.SEResNet, 26, (3, 32, 32), True, 16),
              ('senet26', basemodel.senet.SENet, 26, (3, 32, 32), True, 16),
-             ('shufflenet_g4', basemodel.shufflenet_v1.ShuffleNetV1, 'g4', (3, 32, 32), True, 16)]
+             ('shufflenet_g4', basemodel.shufflenet_v1.ShuffleNetV1, 'g4', (3, 32, 32), True, 16),
+             ('sknet26', basemodel.sknet.SKNet, 26, (3, 32, 32), True, 16),
+             ('skresnet26', basemodel.sk_resnet.SKResNet, 26, (3, 32, 32), True, 16)]
     for name, cls, kind, in_size, bn, bs in cases:
         s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
                               batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)

@@ -676,6 +676,91 @@ def test_grouped_conv_vs_torch(cfg, dtype):
     assert rel_l2(host(conv.weight.grad), wr.grad.numpy()) < (2e-5 if dtype == torch.float32 else 1e-2), 'wgrad'
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [(64, 64, 1, 3, 1, 2, 2, 14), (128, 128, 32, 3, 1, 2, 2, 14), (128, 128, 32, 3, 2, 2, 2, 13),
+                                 (64, 96, 1, 3, 1, 3, 3, 11), (256, 256, 32, 3, 2, 3, 3, 12), (40, 72, 1, 3, 2, 2, 1, 9)],
+                         ids=lambda c: 'Ci%d-Co%d-g%d-k%d-s%d-d%d-p%d-%d' % c)
+def test_dilated_conv_vs_torch(cfg, dtype):
+    """Dilated (and dilated grouped) conv -- the SK paths, sknet.py:186-198 (dilation=1+i, padding=1+i,
+    groups=32): forward, dx, dw against torch fp64."""
+    from convnets_amd import layers
+    Ci, Co, groups, k, s, dl, p, H = cfg
+    g = torch.Generator().manual_seed(Ci + Co + groups + dl + s)
+    N = 3
+    x = torch.randn(N, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci // groups, k, k, generator=g) / np.sqrt(Ci // groups * k * k)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    conv = layers.Conv2d(Ci, Co, kernel_size=k, stride=s, padding=p, dilation=dl, groups=groups, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p, dl, groups)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy.double())
+    xt = dev(x.numpy(), dtype).requires_grad_(True)
+    y = conv(xt)
+    assert tuple(y.shape) == tuple(yr.shape)
+    y.backward(dev(dy.numpy(), dtype))
+    torch.cuda.synchronize()
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(host(y), yr.detach().numpy()) < t, 'fwd'
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < t, 'dgrad'
+    assert rel_l2(host(conv.weight.grad), wr.grad.numpy()) < (2e-5 if dtype == torch.float32 else 1e-2), 'wgrad'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [(3, 64, 7, 7, 2), (2, 128, 14, 9, 2), (5, 256, 1, 1, 2), (2, 72, 5, 5, 3), (1, 2048, 3, 3, 2),
+                                 (2, 4096, 2, 2, 4), (4, 64, 33, 31, 1)], ids=lambda c: 'N%d-C%d-%dx%d-P%d' % c)
+def test_sk_fuse_and_select_vs_torch(cfg, dtype):
+    """The two fused passes of the selective-kernel unit (sknet.py:222-237): pooled = GAP(sum_i U_i) and
+    out = sum_i U_i * softmax_i(logits), forward and every gradient (maps through BOTH reads, logits) vs torch
+    fp64 -- with the SKLink hand-off (one pass writes dU_i) and without it."""
+    from convnets_amd import ops
+    N, C, H, W, P = cfg
+    g = torch.Generator().manual_seed(N * C + H + P)
+    maps = [torch.randn(N, C, H, W, generator=g) for _ in range(P)]
+    if dtype == torch.bfloat16:
+        maps = [m.bfloat16().float() for m in maps]
+    mix = torch.randn(C, C, generator=g) / np.sqrt(C)           # stands in for descriptor + attentions
+    shift = [torch.randn(C, generator=g) for _ in range(P)]
+    dy = torch.randn(N, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+
+    mr = [m.double().requires_grad_(True) for m in maps]
+    st = torch.stack(mr, 1)
+    pooled_r = st.sum(1).mean((2, 3))
+    lr = [(pooled_r @ mix.double()) * (i + 1) + shift[i].double() for i in range(P)]
+    for l in lr:
+        l.retain_grad()
+    out_r = (st * torch.softmax(torch.stack(lr, 1), 1)[..., None, None]).sum(1)
+    out_r.backward(dy.double())
+
+    for linked in (True, False):
+        mt = [dev(m.numpy(), dtype).requires_grad_(True) for m in maps]
+        link = ops.SKLink() if linked else None
+        pooled = ops.SKPoolFn.apply(link, *mt)
+        assert pooled.dtype == torch.float32 and tuple(pooled.shape) == (N, C, 1, 1)
+        flat = pooled.view(N, C)
+        lt = [((flat @ mix.cuda()) * (i + 1) + shift[i].cuda()).view(N, C, 1, 1) for i in range(P)]
+        for l in lt:
+            l.retain_grad()
+        out = ops.SKSelectFn.apply(link, P, *mt, *lt)
+        out.backward(dev(dy.numpy(), dtype))
+        torch.cuda.synchronize()
+        t = 1e-5 if dtype == torch.float32 else 1e-2
+        assert rel_l2(pooled.detach().cpu().numpy().reshape(N, C), pooled_r.detach().numpy()) < (1e-5 if dtype == torch.float32 else 1e-6 + 1e-5)
+        assert rel_l2(host(out), out_r.detach().numpy()) < t, 'select fwd'
+        for i in range(P):
+            assert rel_l2(lt[i].grad.cpu().numpy().reshape(N, C), lr[i].grad.numpy()) < (1e-4 if dtype == torch.float32 else 2e-2), 'dlogits'
+            assert rel_l2(host(mt[i].grad), mr[i].grad.numpy()) < t, 'dmaps (linked=%s)' % linked
+        if linked:
+            assert link.stash is None and not link.pool_pending
+
+
 def test_conv_and_pool_backward_after_layout_copy():
     """An NCHW-contiguous input that requires grad is re-laid to NHWC inside forward (under no_grad): the data
     gradient / pool indices must still be produced (regression: requires_grad was read after the copy)."""

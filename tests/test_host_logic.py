@@ -112,8 +112,13 @@ def test_factory_returns_stock_subclasses_and_tracks_shapes():
     assert gc.groups == 32 and tuple(gc.weight.shape) == (64, 2, 3, 3)
     gd = net.conv2d(in_channels=96, num_filters=48, kernel_size=1, groups=3, set_output=False)   # ShuffleNet-style: dense path
     assert gd._dense_grouped and tuple(gd.weight.shape) == (48, 32, 1, 1)
-    with pytest.raises(NotImplementedError):                                     # dilation is not implemented
-        net.conv2d(in_channels=64, num_filters=64, kernel_size=3, dilation=2)
+    before = (net.height, net.width)
+    dc = net.conv2d(in_channels=64, num_filters=64, kernel_size=3, dilation=2, padding=2, set_output=False)
+    assert dc._dil == 2 and (net.height, net.width) == before                    # sknet.py:190-193 dilated paths
+    with pytest.raises(NotImplementedError):                                     # dilation only on the implicit-GEMM shapes
+        net.conv2d(in_channels=3, num_filters=64, kernel_size=3, dilation=2)
+    with pytest.raises(NotImplementedError):
+        net.conv2d(in_channels=64, num_filters=64, kernel_size=3, dilation=(1, 2))
     with pytest.raises(TypeError):
         ca.Settings(kind=0, input_size=(1, 2, 2), num_classes=2, no_such_field=1)
 

@@ -87,7 +87,8 @@ MODEL_CASES = [('resnet26', 'resnet', 26, (3, 32, 32), True), ('resnet18', 'resn
                ('mobilenet', 'mobilenet', 1, (3, 32, 32), True), ('resnext26', 'resnext', 26, (3, 32, 32), True),
                ('inception', 'inception', 1, (3, 32, 32), True), ('squeezenet', 'squeezenet', 1.1, (3, 64, 64), True),
                ('densenet121', 'densenet', 121, (3, 32, 32), True), ('seresnet26', 'seresnet', 26, (3, 32, 32), True),
-               ('senet26', 'senet', 26, (3, 32, 32), True), ('shufflenet_g4', 'shufflenet', 'g4', (3, 32, 32), True)]
+               ('senet26', 'senet', 26, (3, 32, 32), True), ('shufflenet_g4', 'shufflenet', 'g4', (3, 32, 32), True),
+               ('sknet26', 'sknet', 26, (3, 32, 32), True), ('skresnet26', 'skresnet', 26, (3, 32, 32), True)]
 
 
 @pytest.mark.parametrize('name,family,kind,in_size,bn', MODEL_CASES)
