@@ -22,6 +22,7 @@ from .densenet import DenseNet                                  # noqa: F401
 from .senet import SENet, SEResNet                              # noqa: F401
 from .shufflenet import ShuffleNetV1                            # noqa: F401
 from .sknet import SKNet, SKResNet                              # noqa: F401
+from .graph import GraphedTrainStep                            # noqa: F401
 from .optim import FlatAdam                                     # noqa: F401
 
 MODELS = {'resnet': ResNet, 'vgg': VGGNet, 'convnet': ConvNet, 'lenet5': LeNet5, 'alexnet': AlexNet,

@@ -87,6 +87,7 @@ SIGNATURES = {
     'cnk_linear_wgrad': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _vp, _sz, _vp]),
     'cnk_softmax_ce_sum': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     'cnk_dropout_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    'cnk_dropout_fwd_dev': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     'cnk_dropout_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
     'cnk_sigmoid_fwd': (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     'cnk_sigmoid_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
@@ -104,6 +105,8 @@ SIGNATURES = {
     'cnk_grad_clip_value': (ctypes.c_int, [_vp, _i64, _f32, _vp]),
     'cnk_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32,
                                      _vp]),
+    'cnk_adam_bias_corrections': (None, [_f32, _f32, _i32, ctypes.POINTER(ctypes.c_float)]),
+    'cnk_adam_step_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     'cnk_prof_begin': (ctypes.c_int, [_i32]),
     'cnk_prof_collect': (ctypes.c_int, [_i32, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double),

@@ -27,7 +27,7 @@ int linear_fwd(const float* x, const float* w, const float* bias, float* y, int 
 int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, float* ws, size_t ws_bytes, hipStream_t s);
 int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax, float* row_loss_ws, int B, int N, hipStream_t s);
-int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
+int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t s);
 int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s);
 int avgpool_dispatch(bool bwd, const void* a, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 int sigmoid_fwd(const float* x, float* y, int64_t n, hipStream_t s);
@@ -85,7 +85,8 @@ int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, in
 template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
 int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
 int nchw_to_nhwc_dispatch(const float* x, void* y, int N, int C, int H, int W, int dtype, hipStream_t s);
-int adam_dispatch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
+int adam_dispatch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step, const float* bias_dev, hipStream_t s);
+void adam_bias_corrections(float b1, float b2, int step, float* out);
 
 // ---- error text -----------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -474,7 +475,15 @@ int cnk_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int32_t N, int32_t C, in
 int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
     CNK_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "cnk_adam_step: bad arguments");
     CNK_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "cnk_adam_step: arenas must be 16-byte aligned");
-    return adam_dispatch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+    return adam_dispatch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, S(stream));
+}
+void cnk_adam_bias_corrections(float beta1, float beta2, int32_t step, float* out2) {
+    if (out2) adam_bias_corrections(beta1, beta2, step < 1 ? 1 : step, out2);
+}
+int cnk_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, const float* bias_dev, void* stream) {
+    CNK_CHECK_ARG(p && g && m && v && n > 0 && bias_dev, "cnk_adam_step_dev: bad arguments");
+    CNK_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "cnk_adam_step_dev: arenas must be 16-byte aligned");
+    return adam_dispatch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, 1, bias_dev, S(stream));
 }
 
 int cnk_dwconv2d_supported(const cnk_conv_desc* d) {
@@ -574,7 +583,12 @@ int cnk_softmax_ce_sum(const float* logits, const int64_t* target, float* loss, 
 int cnk_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
     CNK_CHECK_ARG(x && y && mask && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_fwd: bad arguments (0 <= p < 1)");
     if (n == 0) return 0;
-    return dropout_fwd(x, y, mask, n, p, seed, offset, S(stream));
+    return dropout_fwd(x, y, mask, n, p, seed, offset, nullptr, S(stream));
+}
+int cnk_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
+    CNK_CHECK_ARG(x && y && mask && offset_dev && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_fwd_dev: bad arguments (0 <= p < 1)");
+    if (n == 0) return 0;
+    return dropout_fwd(x, y, mask, n, p, seed, offset, offset_dev, S(stream));
 }
 
 int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {

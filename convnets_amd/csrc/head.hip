@@ -214,7 +214,9 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {
 
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           unsigned char* __restrict__ mask, int64_t n,
-                                                          uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
+                                                          uint32_t thresh, float scale, uint64_t seed, uint64_t offset,
+                                                          const uint64_t* __restrict__ offset_dev) {
+    if (offset_dev) offset += *offset_dev;        // hipGraph-captured step: the call counter of THIS replay
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t r = mix32(seed * 0xD1342543DE82EF95ull + offset * 0x2545F4914F6CDD1Dull + (uint64_t)i);
         const bool keep = r >= thresh;
@@ -361,11 +363,11 @@ int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, floa
 }
 
 int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
-                hipStream_t s) {
+                const uint64_t* offset_dev, hipStream_t s) {
     double t = (double)p * 4294967296.0;
     uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, y, mask, n, thresh, 1.f / (1.f - p),
-                       seed, offset);
+                       seed, offset, offset_dev);
     CNK_CHECK_LAUNCH("dropout_fwd");
     return 0;
 }

@@ -276,8 +276,12 @@ __global__ __launch_bounds__(256) void input_pipeline_kernel(const unsigned char
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n4, int64_t n, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2_sqrt) {
+                                                   float eps, float wd, float bc1, float bc2_sqrt,
+                                                   const float* __restrict__ bias_dev) {
     // step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps   (torch.optim.Adam)
+    // bias_dev: the two bias corrections in device memory (a hipGraph-captured step replays this launch with
+    // the values of ITS step, cnk_adam_step_dev)
+    if (bias_dev) { bc1 = bias_dev[0]; bc2_sqrt = bias_dev[1]; }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
         int64_t base = i * 4;
@@ -502,13 +506,18 @@ int nchw_to_nhwc_dispatch(const float* x, void* y, int N, int C, int H, int W, i
     return 0;
 }
 
+void adam_bias_corrections(float b1, float b2, int step, float* out) {
+    out[0] = 1.f - powf(b1, (float)step);
+    out[1] = sqrtf(1.f - powf(b2, (float)step));
+}
+
 int adam_dispatch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
-                  float b2, float eps, float wd, int step, hipStream_t s) {
-    float bc1 = 1.f - powf(b1, (float)step);
-    float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+                  float b2, float eps, float wd, int step, const float* bias_dev, hipStream_t s) {
+    float bc[2] = {1.f, 1.f};
+    if (!bias_dev) adam_bias_corrections(b1, b2, step, bc);
     int64_t n4 = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4)), dim3(256), 0, s, p, g, m, v, n4, n, lr, b1, b2,
-                       eps, wd, bc1, bc2_sqrt);
+                       eps, wd, bc[0], bc[1], bias_dev);
     CNK_CHECK_LAUNCH("adam");
     return 0;
 }

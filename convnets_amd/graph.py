@@ -1,0 +1,106 @@
+"""hipGraph-captured training step (BASELINE config 5: "comm/compute overlap + hipGraph-captured step").
+
+A ResNet-152 step is ~1,900 kernel launches issued from Python: 27 ms of host work against ~30 ms of GPU work at
+bs 128, so the step is launch-bound as soon as anything else (a data loader, a gradient reducer) shares the host
+thread.  `GraphedTrainStep` captures ONE iteration of the reference's loop body (src/basemodel.py:245-288 --
+zero_grad, forward, CE(sum), backward, clipping, Adam) into a hipGraph and replays it with one launch per step.
+
+What makes the step capturable:
+  * no host sync inside the step: loss and score stay device scalars (basemodel.train_batch);
+  * every buffer comes from the caller (the library never allocates), the workspaces are grow-only;
+  * the two step-varying kernel arguments -- Adam's bias corrections and the dropout call counter -- are read from
+    device memory that the host refreshes before each replay (ops.CaptureScalars, cnk_adam_step_dev,
+    cnk_dropout_fwd_dev), so a replay computes exactly what the eager step would have computed;
+  * the weight-gradient side stream forks from and re-joins the capturing stream through events, so it is part of
+    the captured graph (two branches that the runtime may run concurrently, as in the eager step).
+The learning rate is a kernel argument: `replay` re-captures when the scheduler (src/basemodel.py:69-76) changes it.
+"""
+import torch
+
+from . import ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model, example_batch, warmup=3):
+        """model: a MultiClassBaseModel on the GPU with its optimizer initialised; example_batch: (x, y) device
+        tensors of the shapes every later batch will have.  The warm-up steps (lazy initialisation: packed
+        weight tables, workspaces, allocator pools) run on a snapshot, so constructing the object does NOT
+        advance training."""
+        if model.optimizer is None:
+            model.init_optimizer()
+        if getattr(model, 'grad_reducer', None) is not None:
+            raise NotImplementedError('GraphedTrainStep: a data-parallel gradient reducer is attached; capture of the '
+                                      'RCCL all-reduce is not supported yet -- run the eager step under dp.attach')
+        x, y = example_batch
+        if not (x.is_cuda and y.is_cuda):
+            raise ValueError('GraphedTrainStep: the example batch must live on the GPU')
+        self.model = model
+        self.x = x.clone()
+        self.y = y.clone()
+        self.scalars = ops.CaptureScalars(x.device)
+        self.graph = None
+        self.lr = None
+        self.replays = 0
+        model.train()
+        snap = self._snapshot()
+        for _ in range(warmup):
+            model.train_batch((self.x, self.y))
+        self._bn_layers = [m for m in model.modules() if hasattr(m, '_stats_epoch')]
+        self._restore(snap)
+        self._capture()
+
+    # ---- state that a throw-away step must not leave behind ----------------------------------------------
+    def _snapshot(self):
+        opt = self.model.optimizer
+        return dict(p=opt.flat_p.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), step=opt.step_count,
+                    bufs=[b.clone() for b in self.model.buffers()], drop=ops._dropout_calls[0])
+
+    def _restore(self, snap):
+        opt = self.model.optimizer
+        with torch.no_grad():
+            opt.flat_p.copy_(snap['p'])
+            opt.exp_avg.copy_(snap['m'])
+            opt.exp_avg_sq.copy_(snap['v'])
+            for b, saved in zip(self.model.buffers(), snap['bufs']):
+                b.copy_(saved)
+        opt.step_count = snap['step']
+        ops._dropout_calls[0] = snap['drop']
+        self._mark_weights_changed()
+
+    def _mark_weights_changed(self):
+        ops.bump_weights_epoch()
+        for m in self._bn_layers:
+            m._stats_epoch += 1
+
+    def _capture(self):
+        opt = self.model.optimizer
+        self.lr = opt.param_groups[0]['lr']
+        step0, drop0 = opt.step_count, ops._dropout_calls[0]
+        self.scalars.dropout_calls = 0
+        self.graph = torch.cuda.CUDAGraph()
+        ops.CAPTURE[0] = self.scalars
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss, self.score = self.model.train_batch((self.x, self.y))
+        finally:
+            ops.CAPTURE[0] = None
+        # capture ran the Python side of one step without executing it
+        opt.step_count, ops._dropout_calls[0] = step0, drop0
+
+    def replay(self, batch=None):
+        """One training step on `batch` (None: the resident batch again).  Returns (loss, correct) as device
+        scalars, the tensors of the captured step: read or accumulate them before the next replay."""
+        opt = self.model.optimizer
+        if opt.param_groups[0]['lr'] != self.lr:
+            self._capture()
+        if batch is not None:
+            x, y = batch
+            self.x.copy_(x, non_blocking=True)
+            self.y.copy_(y, non_blocking=True)
+        self.scalars.push(opt.bias_corrections(opt.step_count + 1), ops._dropout_calls[0])
+        self.graph.replay()
+        opt.step_count += 1
+        ops._dropout_calls[0] += self.scalars.dropout_calls
+        self._mark_weights_changed()
+        self.replays += 1
+        return self.loss, self.score

@@ -126,11 +126,19 @@ def _join_at_end_of_backward():
     torch.autograd.Variable._execution_engine.queue_callback(cb)
 
 
+def _is_capturing(stream):
+    with torch.cuda.stream(stream):
+        return torch.cuda.is_current_stream_capturing()
+
+
 def join_side_streams(device=None):
     """Makes the current stream wait for everything issued on the weight-gradient stream(s)."""
     for dev, st in _side_streams.items():
         if device is None or dev == device:
-            torch.cuda.current_stream(dev).wait_stream(st)
+            cur = torch.cuda.current_stream(dev)
+            if CAPTURE[0] is not None and not _is_capturing(st):
+                continue              # hipGraph capture: nothing of this capture has been forked to that stream
+            cur.wait_stream(st)
 
 
 def make_desc(x_shape, weight_shape, stride, padding, dtype_code, groups=1, dilation=1):
@@ -778,6 +786,48 @@ class LinearFn(torch.autograd.Function):
 _dropout_calls = [0]
 
 
+class CaptureScalars:
+    """Step-varying scalars of a hipGraph-captured training step (convnets_amd/graph.py).  A captured launch
+    replays with the arguments it was captured with, so what changes from step to step -- Adam's two bias
+    corrections and the dropout call counter -- lives in a 16-byte device record that the host refreshes
+    (pinned ring + async copy on the replay stream) before every replay: [bc1 f32][bc2_sqrt f32][dropout base u64]."""
+
+    RING = 64
+
+    def __init__(self, device):
+        self.dev = torch.zeros(16, dtype=torch.uint8, device=device)
+        self.ring = torch.zeros(self.RING, 16, dtype=torch.uint8).pin_memory()
+        self.events = [None] * self.RING
+        self.slot = 0
+        self.dropout_base = 0            # _dropout_calls at the start of the captured step
+        self.dropout_calls = 0           # dropout launches inside one step
+
+    @property
+    def bias_ptr(self):
+        return ctypes.c_void_p(self.dev.data_ptr())
+
+    @property
+    def dropout_ptr(self):
+        return ctypes.c_void_p(self.dev.data_ptr() + 8)
+
+    def push(self, bc, dropout_base):
+        """Queue the record of the next replay on the current stream."""
+        import struct
+        i = self.slot
+        self.slot = (i + 1) % self.RING
+        if self.events[i] is not None:
+            self.events[i].synchronize()          # the copy that last read this pinned slot (RING replays ago)
+        self.ring[i].copy_(torch.frombuffer(bytearray(struct.pack('<ffQ', bc[0], bc[1], dropout_base)), dtype=torch.uint8))
+        self.dev.copy_(self.ring[i], non_blocking=True)
+        ev = self.events[i] or torch.cuda.Event()
+        ev.record()
+        self.events[i] = ev
+
+
+CAPTURE = [None]          # the CaptureScalars of the step being captured, else None
+
+
+
 class DropoutFn(torch.autograd.Function):
     """nn.Dropout, training mode (resnet.py:105).  Keep pattern = hash(torch.initial_seed(), call
     counter, element index): reproducible under torch.manual_seed, not torch's Philox stream."""
@@ -792,8 +842,15 @@ class DropoutFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mask = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
         _dropout_calls[0] += 1
-        check(lib.cnk_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p),
-                                  torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_calls[0], _stream()))
+        cap = CAPTURE[0]
+        if cap is None:
+            check(lib.cnk_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p),
+                                      torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_calls[0], _stream()))
+        else:        # captured step: counter = (calls before this step, from device memory) + index inside the step
+            cap.dropout_calls += 1
+            check(lib.cnk_dropout_fwd_dev(_p(x), _p(y), _p(mask), x.numel(), float(p),
+                                          torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, cap.dropout_calls,
+                                          cap.dropout_ptr, _stream()))
         ctx.save_for_backward(mask)
         ctx.p = float(p)
         ctx.fmt = CL if (x.dim() == 4 and not x.is_contiguous()) else torch.contiguous_format

@@ -69,12 +69,23 @@ class FlatAdam:
         g = self.param_groups[0]
         self.step_count += 1
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(_lib.load().cnk_adam_step(
-            ctypes.c_void_p(self.flat_p.data_ptr()), ctypes.c_void_p(self.flat_g.data_ptr()),
-            ctypes.c_void_p(self.exp_avg.data_ptr()), ctypes.c_void_p(self.exp_avg_sq.data_ptr()),
-            self.numel, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'],
-            self.step_count, s))
+        arenas = (ctypes.c_void_p(self.flat_p.data_ptr()), ctypes.c_void_p(self.flat_g.data_ptr()),
+                  ctypes.c_void_p(self.exp_avg.data_ptr()), ctypes.c_void_p(self.exp_avg_sq.data_ptr()))
+        cap = ops.CAPTURE[0]
+        if cap is None:
+            check(_lib.load().cnk_adam_step(*arenas, self.numel, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                                            g['weight_decay'], self.step_count, s))
+        else:       # hipGraph capture: the bias corrections of the replayed step come from device memory
+            check(_lib.load().cnk_adam_step_dev(*arenas, self.numel, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                                                g['weight_decay'], cap.bias_ptr, s))
         ops.bump_weights_epoch()
+
+    def bias_corrections(self, step):
+        """(1 - beta1^step, sqrt(1 - beta2^step)) exactly as cnk_adam_step computes them."""
+        out = (ctypes.c_float * 2)()
+        g = self.param_groups[0]
+        _lib.load().cnk_adam_bias_corrections(g['betas'][0], g['betas'][1], int(step), out)
+        return float(out[0]), float(out[1])
 
     @torch.no_grad()
     def clip_grad_norm(self, max_norm):

@@ -234,6 +234,13 @@ int cnk_input_pipeline(const uint8_t* x, void* y, const int32_t* crop_yx, const 
  * `step` is the 1-based step count t. */
 int cnk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* hipGraph-captured training step (BASELINE config 5): a captured launch replays with the kernel arguments of
+ * capture time, so the step-varying scalars are read from device memory that the host refreshes before every
+ * replay.  bias_dev = {1 - beta1^t, sqrt(1 - beta2^t)} of the replayed step t, computed by
+ * cnk_adam_bias_corrections (host, the same arithmetic as cnk_adam_step => bitwise-identical updates). */
+void cnk_adam_bias_corrections(float beta1, float beta2, int32_t step, float* out2);
+int cnk_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, const float* bias_dev, void* stream);
 
 /* ---- depthwise convolution ------------------------------------------------------
  * conv2d_depthwise of the layer factory (basemodel.py:981-997): nn.Conv2d(C, C, groups=C, ...), the
@@ -289,6 +296,9 @@ int cnk_softmax_ce_sum(const float* logits, const int64_t* target, float* loss, 
  * It does not reproduce torch's Philox stream: parity runs use dropout_rate = 0. */
 int cnk_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
                     uint64_t offset, void* stream);
+/* Same with the call counter = offset + *offset_dev (device memory, refreshed per replay of a captured step). */
+int cnk_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                        uint64_t offset, const uint64_t* offset_dev, void* stream);
 int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
 
 /* Squeeze-and-excitation unit (SEUnit, senet.py:215-254 / se_resnet.py:216-255): nn.Sigmoid on the fp32 [N][C]

@@ -397,3 +397,55 @@ def test_training_trajectory_tracks_the_oracle(mixed):
     assert last_r < 0.35 * first_r, 'the problem must be learnable by the oracle'
     assert last_h < 0.35 * first_h
     assert abs(last_h - last_r) < (0.15 if not mixed else 0.3) * first_r      # same trajectory, not just "decreasing"
+
+
+@pytest.mark.parametrize('mixed', [False, True], ids=['f32', 'bf16'])
+def test_graphed_step_equals_eager_step(mixed):
+    """convnets_amd.GraphedTrainStep (hipGraph capture of one loop iteration, basemodel.py:245-288): N replays
+    leave the model exactly where N eager steps leave it -- same losses, scores, parameters, Adam moments, BN
+    running statistics -- with dropout ON (the call counter of each replay comes from device memory) and the
+    bias corrections of each step read from device memory.  Constructing the graph must not advance training."""
+    import convnets_amd as ca
+    from convnets_amd import ops
+
+    def make():
+        torch.manual_seed(5)
+        s = ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, batch_size=8, batch_norm=True,
+                        mixed_precision=mixed, dropout_rate=0.3, seed=5)
+        m = ca.MODELS['resnet'](s).cuda()
+        m.init_optimizer()
+        m.train()
+        return m
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(8, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (8,), generator=g).cuda()) for _ in range(4)]
+    ops._dropout_calls[0] = 0
+    eager = make()
+    e_out = [eager.train_batch(b) for b in batches]
+    e_out = [(float(l), int(c)) for l, c in e_out]
+    ops._dropout_calls[0] = 0
+    graphed = make()
+    p0 = graphed.optimizer.flat_p.clone()
+    step = ca.GraphedTrainStep(graphed, batches[0])
+    assert torch.equal(graphed.optimizer.flat_p, p0) and graphed.optimizer.step_count == 0 and ops._dropout_calls[0] == 0
+    g_out = []
+    for b in batches:
+        l, c = step.replay(b)
+        g_out.append((float(l), int(c)))
+    torch.cuda.synchronize()
+    assert g_out == e_out
+    assert graphed.optimizer.step_count == eager.optimizer.step_count == 4
+    assert torch.equal(graphed.optimizer.flat_p, eager.optimizer.flat_p)
+    assert torch.equal(graphed.optimizer.exp_avg_sq, eager.optimizer.exp_avg_sq)
+    for (k, a), (_, b) in zip(graphed.named_buffers(), eager.named_buffers()):
+        assert torch.equal(a, b), k
+    # an eager step after the replays continues from the same state (host counters were advanced)
+    calls = ops._dropout_calls[0]
+    assert calls == 4                                   # one dropout launch per step, four replays
+    l1, _ = graphed.train_batch(batches[1])
+    ops._dropout_calls[0] = calls                       # (the dropout counter is process-global)
+    l2, _ = eager.train_batch(batches[1])
+    assert float(l1) == float(l2)
+    # evaluation sees the replayed weights (folded-conv caches are invalidated by the replays)
+    graphed.eval(); eager.eval()
+    with torch.no_grad():
+        assert torch.equal(graphed(batches[2][0]), eager(batches[2][0]))

@@ -12,12 +12,13 @@ if dist_on:
     torch.cuda.set_device(0)
     dist.init_process_group(os.environ.get('CNK_DIST_BACKEND', 'nccl'), device_id=torch.device('cuda', 0))
 torch.manual_seed(21)
-s = ca.Settings(kind=50, input_size=(3, 224, 224), num_classes=1000, batch_size=256, mixed_precision=True)
+KIND = int(os.environ.get('KIND', 50)); BS = int(os.environ.get('BS', 256))
+s = ca.Settings(kind=KIND, input_size=(3, 224, 224), num_classes=1000, batch_size=BS, mixed_precision=True)
 m = ca.MODELS['resnet'](s).cuda(); m.init_optimizer()
 if dist_on or os.environ.get('CNK_DP_FORCE') == '1':
     dp.attach(m)
 m.train()
-x = torch.randn(256, 3, 224, 224, device='cuda'); y = torch.randint(0, 1000, (256,), device='cuda')
+x = torch.randn(BS, 3, 224, 224, device='cuda'); y = torch.randint(0, 1000, (BS,), device='cuda')
 for _ in range(3): m.train_batch((x, y))
 torch.cuda.synchronize()
 host = []
