@@ -110,6 +110,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-class kernel time table to stderr')
+    ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the step (convnets_amd.GraphedTrainStep); '
+                    'the roofline launch durations then come from extra eager steps after the timed region')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -180,13 +182,30 @@ def main():
             print('  %-14s n=%4d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)' %
                   (name, n, ms, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0), file=sys.stderr)
 
-    lib.cnk_prof_begin(dom_mask)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = model.train_batch(batch)
-    sync()
-    elapsed = time.perf_counter() - t0
+    if args.graph:
+        # one captured hipGraph launch per step; per-kernel events cannot be read inside a replay, so the
+        # dominant kernel's launch durations are measured on eager steps AFTER the timed region
+        graphed = ca.GraphedTrainStep(model, batch)
+        for _ in range(2):
+            graphed.replay()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = graphed.replay()
+        sync()
+        elapsed = time.perf_counter() - t0
+        lib.cnk_prof_begin(dom_mask)
+        for _ in range(min(args.steps, 5)):
+            model.train_batch(batch)
+        torch.cuda.synchronize()
+    else:
+        lib.cnk_prof_begin(dom_mask)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = model.train_batch(batch)
+        sync()
+        elapsed = time.perf_counter() - t0
     n_l, ms_l, fl_l, by_l = prof_collect(lib, dom_mask)
     lib.cnk_prof_end()
     if distributed:
@@ -223,6 +242,7 @@ def main():
                          'avg_launch_gflop': round(fl_l / n_l / 1e9, 3) if n_l else None,
                          'avg_launch_alg_mbytes': round(by_l / n_l / 1e6, 2) if n_l else None,
                          'two_stream_backward': bool(_ops.WGRAD_STREAM and args.dtype == 'bf16'),
+                         'hipgraph_step': bool(args.graph),
                          'serial_step_ms_by_family': {k.split(' ')[0]: round(sum(table[c][1] for c in KERNELS[k]), 3) for k in KERNELS},
                          'serial_conv_tflops_by_class': {c: round(table[c][2] / table[c][1] / 1e9, 1) for c in CONV_CLASSES if table[c][1] > 0}},
         }

@@ -95,6 +95,8 @@ class GradReducer:
             streams = {st.cuda_stream: st for st in [torch.cuda.current_stream(dev), self._compute_stream] + ops.side_streams(dev)
                        if st is not None}
             for st in streams.values():
+                if ops.CAPTURE[0] is not None and not ops._is_capturing(st):
+                    continue          # hipGraph capture: that stream carries none of the captured step's work
                 ev = torch.cuda.Event()
                 ev.record(st)
                 self.side.wait_event(ev)

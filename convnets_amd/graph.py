@@ -12,7 +12,8 @@ What makes the step capturable:
     device memory that the host refreshes before each replay (ops.CaptureScalars, cnk_adam_step_dev,
     cnk_dropout_fwd_dev), so a replay computes exactly what the eager step would have computed;
   * the weight-gradient side stream forks from and re-joins the capturing stream through events, so it is part of
-    the captured graph (two branches that the runtime may run concurrently, as in the eager step).
+    the captured graph (two branches that the runtime may run concurrently, as in the eager step); the
+    data-parallel reducer's stream and the RCCL all-reduces it issues (convnets_amd/dp.py) join the same way.
 The learning rate is a kernel argument: `replay` re-captures when the scheduler (src/basemodel.py:69-76) changes it.
 """
 import torch
@@ -28,9 +29,6 @@ class GraphedTrainStep:
         advance training."""
         if model.optimizer is None:
             model.init_optimizer()
-        if getattr(model, 'grad_reducer', None) is not None:
-            raise NotImplementedError('GraphedTrainStep: a data-parallel gradient reducer is attached; capture of the '
-                                      'RCCL all-reduce is not supported yet -- run the eager step under dp.attach')
         x, y = example_batch
         if not (x.is_cuda and y.is_cuda):
             raise ValueError('GraphedTrainStep: the example batch must live on the GPU')

@@ -95,3 +95,42 @@ def test_two_ranks_equal_one_process_on_concatenated_batch(tmp_path):
     # ResNet-18: local BN statistics differ from global-batch statistics by design; the summed
     # loss of the two shards must still be close to a plausible value and finite
     assert all(l == l and l > 0 for l in r0['resnet18']['losses'] + r1['resnet18']['losses'])
+
+
+def _graph_worker(rank, world, port, out):
+    """One rank on RCCL (backend "nccl") with the collective forced (CNK_DP_FORCE): the bucketed all-reduces are
+    captured into the hipGraph together with the step and replayed."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', CNK_DP_FORCE='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    sys.path.insert(0, ROOT)
+    import convnets_amd as ca
+    from convnets_amd import dp
+    from oracle import torch_ref as tr
+    x, y = tr.synthetic_batch(8, (3, 32, 32), 10, seed=5)
+    x, y = x.cuda(), y.cuda()
+    res = {}
+    for mode in ('eager', 'graph'):
+        m = _make('resnet', 18, (3, 32, 32), True, mixed=True)
+        red = dp.attach(m, bucket_bytes=256 << 10)
+        assert len(red.buckets) >= 2 and red.force
+        if mode == 'eager':
+            losses = [float(m.train_batch((x, y))[0]) for _ in range(3)]
+        else:
+            step = ca.GraphedTrainStep(m, (x, y))
+            losses = [float(step.replay()[0]) for _ in range(3)]
+        torch.cuda.synchronize()
+        res[mode] = dict(flat_p=m.optimizer.flat_p.cpu().clone(), losses=losses)
+        red.remove()
+    torch.save(res, out % rank)
+    dist.destroy_process_group()
+
+
+def test_graphed_dp_step_with_rccl_allreduce_equals_eager(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'g%d.pt')
+    mp.start_processes(_graph_worker, args=(1, _free_port(), out), nprocs=1, join=True, start_method='spawn')
+    r = torch.load(out % 0)
+    assert r['graph']['losses'] == r['eager']['losses']
+    assert torch.equal(r['graph']['flat_p'], r['eager']['flat_p'])

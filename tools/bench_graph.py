@@ -8,6 +8,12 @@ family, kind, size, classes, bs, dt = sys.argv[1], (int(sys.argv[2]) if sys.argv
 torch.manual_seed(21)
 s = ca.Settings(kind=kind, input_size=(3, size, size), num_classes=classes, batch_size=bs, mixed_precision=dt == 'bf16')
 m = ca.MODELS[family](s).cuda(); m.init_optimizer(); m.train()
+if 'RANK' in os.environ:            # python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 tools/bench_graph.py ...
+    import torch.distributed as dist
+    from convnets_amd import dp
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    dp.attach(m)
 x = torch.randn(bs, 3, size, size, device='cuda'); y = torch.randint(0, classes, (bs,), device='cuda')
 n = int(os.environ.get('STEPS', 10))
 
