@@ -62,7 +62,15 @@ def _require_gpu(t):
                            'there is no CPU fallback' % t.device)
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    # raw handle of the current stream of the current device (torch.cuda.current_stream() costs ~1 us of Python
+    # per call, a tenth of the host time of a ResNet-50 step)
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -80,7 +88,8 @@ _workspaces = {}
 def workspace(nbytes, device):
     """One grow-only scratch buffer per (device, stream); kernels are stream-ordered on the caller's
     stream, so successive ops on one stream can share it (the library itself never allocates)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _raw_stream(device.index) if (_raw_stream is not None and device.index is not None)
+           else torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
