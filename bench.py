@@ -21,7 +21,7 @@ import time
 # The step uses four HIP streams (compute, weight gradients, gradient all-reduce, RCCL's own); the runtime
 # multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue
 # serialise.  Must be set before the HIP runtime initialises.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 import torch
 
@@ -110,8 +110,11 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-class kernel time table to stderr')
-    ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the step (convnets_amd.GraphedTrainStep); '
-                    'the roofline launch durations then come from extra eager steps after the timed region')
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
+                    help='time hipGraph replays of the step (convnets_amd.GraphedTrainStep: one launch per step) or the '
+                    'eager step.  auto = on for a single process, off under torch.distributed (the captured RCCL '
+                    'all-reduce is verified on one rank only).  Per-kernel HIP events cannot be read inside a replay, '
+                    'so with the graph the roofline launch durations come from eager steps after the timed region')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -182,10 +185,20 @@ def main():
             print('  %-14s n=%4d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)' %
                   (name, n, ms, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0), file=sys.stderr)
 
-    if args.graph:
+    graphed = None
+    if args.graph == 'on' or (args.graph == 'auto' and not distributed):
+        try:
+            graphed = ca.GraphedTrainStep(model, batch)
+        except Exception as e:                      # capture refused: time the eager step (every rank must agree)
+            print('bench: hipGraph capture failed (%s: %s); timing the eager step' % (type(e).__name__, e), file=sys.stderr)
+        if distributed:
+            ok = torch.tensor([1 if graphed is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graphed = None
+    if graphed is not None:
         # one captured hipGraph launch per step; per-kernel events cannot be read inside a replay, so the
         # dominant kernel's launch durations are measured on eager steps AFTER the timed region
-        graphed = ca.GraphedTrainStep(model, batch)
         for _ in range(2):
             graphed.replay()
         sync()
@@ -242,7 +255,8 @@ def main():
                          'avg_launch_gflop': round(fl_l / n_l / 1e9, 3) if n_l else None,
                          'avg_launch_alg_mbytes': round(by_l / n_l / 1e6, 2) if n_l else None,
                          'two_stream_backward': bool(_ops.WGRAD_STREAM and args.dtype == 'bf16'),
-                         'hipgraph_step': bool(args.graph),
+                         'hipgraph_step': graphed is not None,
+                         'launch_durations_from': 'eager steps after the timed region' if graphed is not None else 'the timed region',
                          'serial_step_ms_by_family': {k.split(' ')[0]: round(sum(table[c][1] for c in KERNELS[k]), 3) for k in KERNELS},
                          'serial_conv_tflops_by_class': {c: round(table[c][2] / table[c][1] / 1e9, 1) for c in CONV_CLASSES if table[c][1] > 0}},
         }

@@ -7,7 +7,7 @@ import os as _os
 # compute / weight-gradient / all-reduce / RCCL streams each need their own hardware queue (the HIP runtime
 # maps streams onto GPU_MAX_HW_QUEUES queues, default 4, and streams sharing a queue serialise); effective
 # only if this import happens before the first HIP call of the process
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 from .settings import Settings, DeviceMngr                      # noqa: F401
 from .basemodel import MultiClassBaseModel                      # noqa: F401

@@ -14,6 +14,8 @@ the compute stream waits for all buckets only before the optimizer step.  xGMI i
 (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so buckets are large
 (default 32 MiB, ~4 for ResNet-50's 102 MB of fp32 gradients) rather than NVSwitch-sized.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -129,6 +131,9 @@ class GradReducer:
 def attach(model, bucket_bytes=32 << 20, process_group=None):
     """Wires a GradReducer to a model whose init_optimizer() has built the flat arena."""
     opt = model.optimizer
+    import os
+    if os.environ.get('CNK_DP_BUCKET_MB'):
+        bucket_bytes = int(float(os.environ['CNK_DP_BUCKET_MB']) * (1 << 20))
     model.grad_reducer = GradReducer(opt.params, opt.flat_g, opt.offsets, bucket_bytes,
                                      process_group, flat_param=opt.flat_p)
     return model.grad_reducer

@@ -77,8 +77,12 @@ class GraphedTrainStep:
         self.scalars.dropout_calls = 0
         self.graph = torch.cuda.CUDAGraph()
         ops.CAPTURE[0] = self.scalars
+        # every eager collective / kernel issued so far has completed, and the capture checks only THIS thread:
+        # the RCCL watchdog thread polls the events of eager collectives, a HIP call that a process-wide
+        # ("global") capture would reject and abort the process on
+        torch.cuda.synchronize()
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self.loss, self.score = self.model.train_batch((self.x, self.y))
         finally:
             ops.CAPTURE[0] = None
