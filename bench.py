@@ -36,11 +36,12 @@ CONV_CLASSES = ['conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'conv1x1_fwd', 
 # igemm_gather_kernel; both serve the forward AND the data gradient.  The dominant family of the step
 # (largest summed launch time) is the one the roofline object describes, priced against the roofline that
 # binds it: MFMA if flops/peak_flops > bytes/peak_bytes for its launches, else HBM.
-KERNELS = {'igemm_halo3x3_kernel (3x3 conv fwd+dgrad; stride-2 layers in igemm_gather_kernel)': ['conv3x3_fwd', 'conv3x3_dgrad'],
-           'igemm_gather_kernel (1x1 conv fwd+dgrad)': ['conv1x1_fwd', 'conv1x1_dgrad'],
-           'wgrad_mfma_kernel (conv wgrad, 3x3 and 1x1)': ['conv3x3_wgrad', 'conv1x1_wgrad'],
-           'bn_apply_kernel (+bn_finalize: BN training forward)': ['bn_fwd'],
-           'bn_bwd_apply_kernel (+bn_bwd_reduce/final: BN backward)': ['bn_bwd']}
+# kernel families timed per LAUNCH (libcnk's kernel-level scopes) -> what each one runs in a training step
+KERNEL_NOTE = {'igemm_gather_kernel': '1x1 conv fwd+dgrad, strided 3x3 convs',
+               'igemm_halo3x3_kernel': 'stride-1 3x3 conv fwd+dgrad (plain and weight-prefetching variant)',
+               'wgrad_mfma_kernel': 'conv weight gradients, 3x3 and 1x1',
+               'bn_apply_kernel': 'BN training forward apply (+ReLU, +residual)',
+               'bn_bwd_apply_kernel': 'BN backward apply'}
 PEAK_HBM_GBPS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec bandwidth
 MODEL_CFG = {
     'resnet50': ('resnet', 50, (3, 224, 224), 1000, 256),
@@ -169,20 +170,19 @@ def main():
         if last:
             torch.cuda.synchronize()
             overlap, _ops.WGRAD_STREAM = _ops.WGRAD_STREAM, False
-            lib.cnk_prof_begin(0x1FF)
+            lib.cnk_prof_begin(0x1FF | sum(_lib.KF.values()))
         loss, _ = model.train_batch(batch)
         if last:
             torch.cuda.synchronize()
             table = {name: prof_collect(lib, _lib.CLS[name]) for name in _lib.CLS}
+            ktable = {name: prof_collect(lib, bit) for name, bit in _lib.KF.items()}
             lib.cnk_prof_end()
             _ops.WGRAD_STREAM = overlap
-    dom_kernel = max(KERNELS, key=lambda k: sum(table[c][1] for c in KERNELS[k]))
-    dom_mask = 0
-    for c in KERNELS[dom_kernel]:
-        dom_mask |= _lib.CLS[c]
+    dom_kernel = max(ktable, key=lambda k: ktable[k][1])        # the kernel with the largest share of the step
+    dom_mask = _lib.KF[dom_kernel]
     if args.breakdown and rank == 0:
-        for name, (n, ms, fl, by) in sorted(table.items(), key=lambda kv: -kv[1][1]):
-            print('  %-14s n=%4d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)' %
+        for name, (n, ms, fl, by) in sorted(list(table.items()) + list(ktable.items()), key=lambda kv: -kv[1][1]):
+            print('  %-22s n=%4d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)' %
                   (name, n, ms, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0), file=sys.stderr)
 
     graphed = None
@@ -248,7 +248,7 @@ def main():
                                    % (args.model, in_size[1], in_size[2], bs),
                        'global_batch': world * bs, 'parallelism': 'dp%d' % world,
                        'final_loss': round(loss_val, 4)},
-            'roofline': {'bound': bound, 'kernel': dom_kernel, 'achieved': round(achieved, 2), 'peak': peak,
+            'roofline': {'bound': bound, 'kernel': dom_kernel, 'kernel_runs': KERNEL_NOTE[dom_kernel], 'achieved': round(achieved, 2), 'peak': peak,
                          'unit': unit, 'frac': round(achieved / peak, 4),
                          'traffic': pmc_traffic(dom_kernel),
                          'launches': n_l, 'avg_launch_ms': round(ms_l / n_l, 4) if n_l else None,
@@ -257,7 +257,8 @@ def main():
                          'two_stream_backward': bool(_ops.WGRAD_STREAM and args.dtype == 'bf16'),
                          'hipgraph_step': graphed is not None,
                          'launch_durations_from': 'eager steps after the timed region' if graphed is not None else 'the timed region',
-                         'serial_step_ms_by_family': {k.split(' ')[0]: round(sum(table[c][1] for c in KERNELS[k]), 3) for k in KERNELS},
+                         'serial_step_ms_by_kernel': {k: round(ktable[k][1], 3) for k in ktable},
+                         'serial_launches_by_kernel': {k: ktable[k][0] for k in ktable},
                          'serial_conv_tflops_by_class': {c: round(table[c][2] / table[c][1] / 1e9, 1) for c in CONV_CLASSES if table[c][1] > 0}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -11,6 +11,9 @@ LIB_PATH = os.path.join(HERE, 'libcnk.so')
 
 CNK_F32, CNK_BF16 = 0, 1
 PASS_FWD, PASS_DGRAD, PASS_WGRAD = 0, 1, 2
+# kernel-level scopes (csrc/common.h CNK_KF_*): one record per launch of that kernel family
+KF = dict(igemm_gather_kernel=1 << 16, igemm_halo3x3_kernel=1 << 17, wgrad_mfma_kernel=1 << 18,
+          bn_apply_kernel=1 << 19, bn_bwd_apply_kernel=1 << 20)
 CLS = dict(conv3x3_fwd=1, conv3x3_dgrad=2, conv3x3_wgrad=4, conv1x1_fwd=8, conv1x1_dgrad=16,
            conv1x1_wgrad=32, bn_fwd=64, bn_bwd=128, other=256)
 

@@ -681,6 +681,7 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC, R, A, W>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
                        (T*)y, scale, shift, mask, M, C, g)
     const int key = (res ? 4 : 0) | (relu ? 2 : 0) | (mask ? 1 : 0);
+    ProfScope kscope(CNK_KF_BN_APPLY, s, 0.0, (double)M * C * sizeof(T) * (res ? 3 : 2) + (mask ? (double)M * C / 8 : 0.0));
     switch (key) {
         case 0: CNK_BN_APPLY(false, false, false); break;
         case 1: CNK_BN_APPLY(false, false, true); break;
@@ -768,6 +769,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
 #define CNK_BN_BAPP(A, W)                                                                                     \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, A, W>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \
                        (const T*)y, (T*)dx, (T*)dres, mask, beta, sm, si, coefA, coefB1, coefB2, M, C, g)
+    ProfScope kscope(CNK_KF_BN_BWD_APPLY, s, 0.0, (double)M * C * sizeof(T) * (dres ? 4 : 3));
     switch (act * 2 + (dres ? 1 : 0)) {
         case ACT_NONE * 2: CNK_BN_BAPP(ACT_NONE, false); break;
         case ACT_NONE * 2 + 1: CNK_BN_BAPP(ACT_NONE, true); break;

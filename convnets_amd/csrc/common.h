@@ -48,6 +48,14 @@ struct ProfScope {
     ~ProfScope() { cnk_prof_stop(cls, s); }
 };
 
+// Kernel-level scopes: exactly one launch of the named kernel family between the two events (the class scopes
+// above bracket a whole C-ABI call, which may issue several kernels).  Same record store, higher class bits.
+#define CNK_KF_GATHER (1 << 16)        /* igemm_gather_kernel */
+#define CNK_KF_HALO (1 << 17)          /* igemm_halo3x3_kernel, igemm_halo3x3_pf_kernel */
+#define CNK_KF_WGRAD (1 << 18)         /* wgrad_mfma_kernel */
+#define CNK_KF_BN_APPLY (1 << 19)      /* bn_apply_kernel */
+#define CNK_KF_BN_BWD_APPLY (1 << 20)  /* bn_bwd_apply_kernel */
+
 // ---- division by a run-time constant (valid for dividends < 2^31) -----------------------------
 struct FastDiv {
     uint32_t mul, shr, d, pad;

@@ -714,12 +714,24 @@ __global__ __launch_bounds__(256, 2) void igemm_halo3x3_pf_kernel(const GatherPa
     igemm_epilogue<T, BN>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
 
+// algorithmic cost of ONE launch: the source tensor and the weight image read once, the output written once,
+// plus the fused side operands (gradient addend, the BN layer's input for its backward reduction)
+static double gather_flops(const GatherParams& p) { return 2.0 * p.M * p.Nout * (double)p.C * p.ntaps; }
+static double gather_bytes(const GatherParams& p, size_t esz) {
+    double out = (double)p.M * p.Nout;
+    double e = (double)p.N * p.IH * p.IW * p.C + out + (double)p.Nout * p.ntaps * p.C;
+    if (p.addend) e += out;
+    if (p.bnf_x) e += out;
+    return e * esz;
+}
+
 template <typename T, int BN, bool EDGE = false> int launch_gather(const GatherParams& p, hipStream_t s) {
     size_t pipe = BM * 128 + BN * 128;
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
     size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);     // aliases the staged tile
     if (red > epi) epi = red;
     size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
+    ProfScope kscope(CNK_KF_GATHER, s, gather_flops(p), gather_bytes(p, sizeof(T)));
     hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
@@ -775,6 +787,7 @@ static bool halo_shape(const GatherParams& p) {
 
 template <typename T, int BN> int launch_halo(const GatherParams& p, hipStream_t s) {
     const size_t lds = halo_lds<T, BN>(p);
+    ProfScope kscope(CNK_KF_HALO, s, gather_flops(p), gather_bytes(p, sizeof(T)));
     if (igemm_halo_pf(p.tiles_total, BN))
         hipLaunchKernelGGL((igemm_halo3x3_pf_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
     else

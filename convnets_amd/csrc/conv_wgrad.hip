@@ -266,6 +266,9 @@ template <typename T, int BMW, int BNW> int launch_wgrad(const WgradParams& p, h
     constexpr int KP = WgCfg<T>::KP;
     size_t lds = 2 * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));   // double-buffered
     int grid = p.splits * p.tiles_co * p.ntaps * p.tiles_ci;
+    ProfScope kscope(CNK_KF_WGRAD, s, 2.0 * p.M * p.Cout * (double)(p.diag ? BNW : p.Cin) * p.ntaps,
+                     ((double)p.M * p.Cout + (double)p.N * p.H * p.W * p.Cin) * sizeof(T) +
+                         (double)p.splits * p.Cout * p.ntaps * (p.diag ? BNW : p.Cin) * sizeof(float));
     hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2>), dim3(grid), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("wgrad_mfma");
     return 0;
