@@ -150,13 +150,24 @@ class MultiClassBaseModel(nn.Module):
         epoch_loss = torch.zeros((), dtype=torch.float64, device=self.setting.device.device)
         epoch_score = torch.zeros((), dtype=torch.int64, device=self.setting.device.device)
         for batch in dataloader:
-            loss, score = self.train_batch(batch)
+            loss, score = self._graphed_batch(batch) if self.setting.hipgraph else self.train_batch(batch)
             epoch_loss += loss.double()
             epoch_score += score
             if self.setting.sanity_check:
                 break
         n = len(dataloader.dataset)
         return epoch_loss.item() / n, epoch_score.item() / n
+
+    def _graphed_batch(self, batch):
+        """setting.hipgraph: the loop body as one hipGraph launch (convnets_amd/graph.py), one captured graph per
+        batch shape (the last, smaller batch of an epoch gets its own)."""
+        from .graph import GraphedTrainStep
+        x, y = self.setting.device.move(batch)
+        steps = self.__dict__.setdefault('_graphed_steps', {})
+        key = (tuple(x.shape), x.dtype, tuple(y.shape))
+        if key not in steps:
+            steps[key] = GraphedTrainStep(self, (x, y))
+        return steps[key].replay((x, y))
 
     @torch.no_grad()
     def valid_model(self, dataloader):

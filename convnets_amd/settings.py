@@ -30,7 +30,8 @@ class Settings:
                lr_patience=10, weight_decay=1e-4, dropout_rate=0.5, loss_optim=False,
                grad_clip_norm=False, gc_max_norm=1, grad_clip_value=False, gc_value=1,
                init_params=True, sanity_check=False, debug=False, mixed_precision=True, seed=21,
-               test_sample_size=90)
+               test_sample_size=90,
+               hipgraph=False)     # (not a reference field) train_model replays a captured hipGraph per batch shape
 
     def __init__(self, kind, input_size, num_classes, device=None, **kwargs):
         self.kind = kind

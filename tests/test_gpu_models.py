@@ -449,3 +449,28 @@ def test_graphed_step_equals_eager_step(mixed):
     graphed.eval(); eager.eval()
     with torch.no_grad():
         assert torch.equal(graphed(batches[2][0]), eager(batches[2][0]))
+
+
+def test_train_model_with_hipgraph_setting_equals_eager_epoch():
+    """setting.hipgraph: train_model (basemodel.py:231-302) replays one captured graph per batch shape -- an epoch
+    with a ragged last batch returns the same (loss, accuracy) and leaves the same weights as the eager epoch."""
+    import convnets_amd as ca
+    from convnets_amd import ops
+    from torch.utils.data import DataLoader, TensorDataset
+    g = torch.Generator().manual_seed(3)
+    ds = TensorDataset(torch.randn(28, 3, 32, 32, generator=g), torch.randint(0, 10, (28,), generator=g))
+
+    def epoch(hipgraph):
+        torch.manual_seed(5)
+        ops._dropout_calls[0] = 0
+        s = ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, batch_size=8, mixed_precision=True,
+                        dropout_rate=0.2, seed=5, hipgraph=hipgraph)
+        m = ca.MODELS['resnet'](s).cuda()
+        m.init_optimizer()
+        out = [m.train_model(DataLoader(ds, batch_size=8, shuffle=False)) for _ in range(2)]   # 8, 8, 8, 4 per epoch
+        return out, m.optimizer.flat_p.clone(), m
+    e_out, e_p, _ = epoch(False)
+    g_out, g_p, gm = epoch(True)
+    assert len(gm._graphed_steps) == 2                     # one graph per batch shape
+    assert g_out == e_out
+    assert torch.equal(g_p, e_p)
