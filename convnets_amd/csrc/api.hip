@@ -261,6 +261,7 @@ int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, vo
     auto add = [&](void* out, int ntaps, const signed char* kh, const signed char* kw, int transpose) {
         if (ntaps == 0) return true;
         if (n >= max_jobs || ntaps > 32) return false;
+        if ((uint64_t)d->Cout * d->Cin * (uint64_t)ntaps >= (1ull << 31)) return false;   // pack_batch_kernel indexes in 32 bits
         cnk_pack_job& j = jobs[n++];
         memset(&j, 0, sizeof(j));
         j.w = w; j.out = out; j.Cout = d->Cout; j.Cin = d->Cin; j.KH = d->kh; j.KW = d->kw;

@@ -170,15 +170,18 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const cnk_pack_job* __r
     const int2 bm = block_map[blockIdx.x];
     const cnk_pack_job& j = jobs[bm.x];
     const int R = j.transpose ? j.Cin : j.Cout, Cred = j.transpose ? j.Cout : j.Cin;
-    const size_t total = (size_t)R * j.ntaps * Cred;
-    const size_t base = (size_t)(blockIdx.x - bm.y) * 1024;
+    // (one conv image has < 2^32 elements: 32-bit index arithmetic -- the 64-bit divisions were most of this kernel)
+    const uint32_t total = (uint32_t)R * (uint32_t)j.ntaps * (uint32_t)Cred;
+    const uint32_t base = (uint32_t)(blockIdx.x - bm.y) * 1024u;
+    const uint32_t ucred = (uint32_t)Cred, utaps = (uint32_t)j.ntaps;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const size_t i = base + u * 256 + threadIdx.x;
+        const uint32_t i = base + u * 256 + threadIdx.x;
         if (i < total) {
-            int c = (int)(i % Cred);
-            size_t q = i / Cred;
-            int t = (int)(q % j.ntaps), r = (int)(q / j.ntaps);
+            const uint32_t q = i / ucred;
+            const int c = (int)(i - q * ucred);
+            const uint32_t rr = q / utaps;
+            const int t = (int)(q - rr * utaps), r = (int)rr;
             int co = j.transpose ? c : r, ci = j.transpose ? r : c;
             float v = master_w(j.w, co, ci, j.Cout, j.Cin, j.KH, j.KW, j.kh[t], j.kw[t], j.groups);
             if (j.dtype == CNK_BF16) ((bf16*)j.out)[i] = (bf16)v;
