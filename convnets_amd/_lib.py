@@ -33,7 +33,7 @@ class BnBwdFuse(ctypes.Structure):
 class PackJob(ctypes.Structure):
     _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ('Cout', 'Cin', 'KH', 'KW', 'ntaps', 'transpose', 'dtype', 'groups')] + \
-               [('kh', ctypes.c_int8 * 32), ('kw', ctypes.c_int8 * 32)]
+               [('kh', ctypes.c_int8 * 32), ('kw', ctypes.c_int8 * 32), ('nblocks', ctypes.c_int32), ('pad_', ctypes.c_int32)]
 
 
 _vp, _i32, _i64, _f32, _sz = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,

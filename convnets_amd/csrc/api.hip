@@ -76,6 +76,7 @@ int smallc_dgrad(const cnk_conv_desc* d, const void* dy, const void* wpk, void* 
 size_t smallc_wgrad_workspace(const cnk_conv_desc* d);
 int smallc_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int nblocks, hipStream_t s);
+int pack_job_blocks(const cnk_pack_job& j);
 size_t bn_workspace_bytes(int64_t M, int C);
 size_t bn_mask_bytes(int64_t M, int C, int dtype);
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
@@ -267,6 +268,7 @@ int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, vo
         j.w = w; j.out = out; j.Cout = d->Cout; j.Cin = d->Cin; j.KH = d->kh; j.KW = d->kw;
         j.ntaps = ntaps; j.transpose = transpose; j.dtype = d->dtype; j.groups = conv_groups(d);
         for (int t = 0; t < ntaps; ++t) { j.kh[t] = kh[t]; j.kw[t] = kw[t]; }
+        j.nblocks = pack_job_blocks(j);
         return true;
     };
     if (w_fwd) {

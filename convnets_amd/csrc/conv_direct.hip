@@ -165,14 +165,93 @@ __global__ void pack_direct_kernel(const float* __restrict__ w, float* __restric
 
 // Multi-tensor form: one launch re-lays every conv weight of the model.  jobs[] and the
 // block -> (job, first block of the job) table live in device memory (built once by the host).
+// Block decomposition (cnk_pack_job::nblocks, pack_job_blocks below):
+//  * 1x1 forward images ([co][ci], the master's own order) and grouped / large-kernel jobs: 1024 consecutive
+//    outputs per block, element-wise;
+//  * k x k forward images ([co][t][ci]): one co row x 256 ci per block, the contiguous 256*k*k-float segment of
+//    the master goes through LDS and comes out tap-major;
+//  * data-gradient images ([ci][t][co]) swap the two channel axes: an LDS tile of 64 co x 16 ci (64 for 1x1)
+//    x all KH*KW taps -- each co row of the tile is ONE contiguous segment of the master -- written with co
+//    contiguous.  (The element-wise form read a different cache line per lane: 1.2 GB of HBM
+//    fetches per launch for 0.1 GB of weights, rocprofv3 FETCH_SIZE, profiles/pmc_traffic.json r01e.)
+constexpr int PACK_CO = 64, PACK_KK = 9, PACK_ROW = 144;       // LDS tile: 64 co rows of <= 144 floats (+1 pad)
+constexpr int PACK_FWD_CI = 256;                                // forward tile: 1 co x 256 ci x KH*KW taps
+
+// data-gradient image, dense conv, KH*KW <= 9: tile of 64 co x (64 ci for 1x1, 16 ci otherwise)
+__host__ __device__ inline bool pack_job_tiled(const cnk_pack_job& j) {
+    return j.transpose && j.groups <= 1 && j.KH * j.KW <= PACK_KK;
+}
+__host__ __device__ inline int pack_tile_ci(const cnk_pack_job& j) { return j.KH * j.KW == 1 ? 64 : 16; }
+// forward image of a dense k x k conv (k > 1): one co row, 256 ci per block, taps re-ordered through LDS
+__host__ __device__ inline bool pack_job_fwd_rows(const cnk_pack_job& j) {
+    return !j.transpose && j.groups <= 1 && j.KH * j.KW > 1 && j.KH * j.KW <= PACK_KK;
+}
+
 __global__ __launch_bounds__(256) void pack_batch_kernel(const cnk_pack_job* __restrict__ jobs,
                                                          const int2* __restrict__ block_map) {
+    __shared__ float tile[PACK_CO][PACK_ROW + 1];
     const int2 bm = block_map[blockIdx.x];
-    const cnk_pack_job& j = jobs[bm.x];
+    // the job record in LDS: read through the global pointer, every field (and tap) would be re-loaded after each
+    // store to `out`, which the compiler must assume may alias it
+    __shared__ cnk_pack_job sj;
+    {
+        static_assert(sizeof(cnk_pack_job) % 4 == 0, "cnk_pack_job is copied in dwords");
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(jobs + bm.x);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&sj);
+        if (threadIdx.x < sizeof(cnk_pack_job) / 4) dst[threadIdx.x] = src[threadIdx.x];
+    }
+    __syncthreads();
+    const cnk_pack_job& j = sj;
+    const int lb = blockIdx.x - bm.y;
+    const int KK = j.KH * j.KW;
+    if (pack_job_tiled(j)) {
+        const int TCI = pack_tile_ci(j), tiles_co = (j.Cout + PACK_CO - 1) / PACK_CO;
+        const int co0 = (lb % tiles_co) * PACK_CO, ci0 = (lb / tiles_co) * TCI;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int nci = min(TCI, j.Cin - ci0), seg = nci * KK;               // contiguous floats per co row
+        for (int r = wave; r < PACK_CO; r += 4) {
+            const int co = co0 + r;
+            if (co < j.Cout) {
+                const float* src = j.w + ((size_t)co * j.Cin + ci0) * KK;
+                for (int k = lane; k < seg; k += 64) tile[r][k] = src[k];
+            }
+        }
+        __syncthreads();
+        const int co = co0 + lane;
+        const int pairs = nci * j.ntaps;                                      // (ci, tap) rows of the image
+        for (int q = wave; q < pairs; q += 4) {
+            const int ci = q / j.ntaps, t = q - ci * j.ntaps;
+            if (co < j.Cout) {
+                const float v = tile[lane][ci * KK + j.kh[t] * j.KW + j.kw[t]];
+                const size_t o = ((size_t)(ci0 + ci) * j.ntaps + t) * j.Cout + co;
+                if (j.dtype == CNK_BF16) ((bf16*)j.out)[o] = (bf16)v;
+                else ((float*)j.out)[o] = v;
+            }
+        }
+        return;
+    }
+    if (pack_job_fwd_rows(j)) {
+        float* row = &tile[0][0];                                             // 256 * 9 floats fit the tile
+        const int chunks = (j.Cin + PACK_FWD_CI - 1) / PACK_FWD_CI;
+        const int co = lb / chunks, ci0 = (lb - co * chunks) * PACK_FWD_CI;
+        const int nci = min(PACK_FWD_CI, j.Cin - ci0), seg = nci * KK;
+        const float* src = j.w + ((size_t)co * j.Cin + ci0) * KK;
+        for (int k = threadIdx.x; k < seg; k += 256) row[k] = src[k];
+        __syncthreads();
+        const int ci = threadIdx.x;
+        if (ci < nci)
+            for (int t = 0; t < j.ntaps; ++t) {
+                const float v = row[ci * KK + j.kh[t] * j.KW + j.kw[t]];
+                const size_t o = ((size_t)co * j.ntaps + t) * j.Cin + ci0 + ci;
+                if (j.dtype == CNK_BF16) ((bf16*)j.out)[o] = (bf16)v;
+                else ((float*)j.out)[o] = v;
+            }
+        return;
+    }
     const int R = j.transpose ? j.Cin : j.Cout, Cred = j.transpose ? j.Cout : j.Cin;
-    // (one conv image has < 2^32 elements: 32-bit index arithmetic -- the 64-bit divisions were most of this kernel)
+    // (one conv image has < 2^31 elements: 32-bit index arithmetic)
     const uint32_t total = (uint32_t)R * (uint32_t)j.ntaps * (uint32_t)Cred;
-    const uint32_t base = (uint32_t)(blockIdx.x - bm.y) * 1024u;
+    const uint32_t base = (uint32_t)lb * 1024u;
     const uint32_t ucred = (uint32_t)Cred, utaps = (uint32_t)j.ntaps;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -200,6 +279,12 @@ DirectParams make_params(const cnk_conv_desc* d) {
 }
 
 }  // namespace
+
+int pack_job_blocks(const cnk_pack_job& j) {
+    if (pack_job_tiled(j)) return ceil_div(j.Cout, PACK_CO) * ceil_div(j.Cin, pack_tile_ci(j));
+    if (pack_job_fwd_rows(j)) return j.Cout * ceil_div(j.Cin, PACK_FWD_CI);
+    return (int)(((size_t)j.Cout * j.Cin * j.ntaps + 1023) / 1024);
+}
 
 int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_stride, int Cout,
                         int Cin, int ntaps, size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci,

@@ -253,9 +253,8 @@ class WeightPacker:
             for k in range(n):
                 j = _lib.PackJob()
                 ctypes.memmove(ctypes.byref(j), ctypes.byref(buf[k]), ctypes.sizeof(j))
-                total = (j.Cin if j.transpose else j.Cout) * j.ntaps * (j.Cout if j.transpose else j.Cin)
                 first = len(blocks)
-                blocks += [(len(jobs), first)] * ((total + 1023) // 1024)
+                blocks += [(len(jobs), first)] * j.nblocks
                 jobs.append(j)
         dev = entries[0].weight.device
         raw = b''.join(bytes(j) for j in jobs)

@@ -79,6 +79,8 @@ typedef struct cnk_pack_job {
     void* out;                 /* image: [R][ntaps][Cred], R/Cred = Cout/Cin or swapped */
     int32_t Cout, Cin, KH, KW, ntaps, transpose, dtype, groups;   /* groups <= 1: dense */
     int8_t kh[32], kw[32];     /* tap list                                      */
+    int32_t nblocks;           /* workgroups this job takes in cnk_pack_batch (filled by cnk_conv2d_pack_jobs) */
+    int32_t pad_;
 } cnk_pack_job;
 int cnk_conv2d_pack_jobs(const cnk_conv_desc* d, const float* w, void* w_fwd, void* w_dgrad,
                          cnk_pack_job* jobs, int32_t max_jobs);
