@@ -103,6 +103,8 @@ SIGNATURES = {
                                                 ctypes.c_size_t, _vp]),
     'cnk_sk_maps_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, ctypes.c_int, _vp]),
     'cnk_input_pipeline': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 7 + [ctypes.c_int, _vp]),
+    'cnk_input_pipeline_affine': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 7 + [ctypes.c_int, _vp]),
+    'cnk_affine_fixed_coeffs': (ctypes.c_int, [ctypes.c_double] * 6 + [_i32, _i32, ctypes.POINTER(ctypes.c_int32)]),
     'cnk_grad_clip_workspace_bytes': (_sz, []),
     'cnk_grad_clip_norm': (ctypes.c_int, [_vp, _i64, _f32, _vp, _vp, _sz, _vp]),
     'cnk_grad_clip_value': (ctypes.c_int, [_vp, _i64, _f32, _vp]),

@@ -40,7 +40,8 @@ int sk_pool_fwd(const void* const* u, int P, float* pooled, int N, int HW, int C
 int sk_select_fwd(const void* const* u, const float* const* logits, int P, float* attn, void* out, int N, int HW, int C, int dtype, hipStream_t s);
 int sk_select_bwd_logits(const void* const* u, const float* attn, const void* dout, float* const* dlogits, int P, int N, int HW, int C, int dtype, float* ws, hipStream_t s);
 int sk_maps_bwd(const void* dout, const float* attn, const float* dpooled, void* const* du, int P, int N, int HW, int C, int dtype, hipStream_t s);
-int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const float* mean, const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype, hipStream_t s);
+int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const int* affine_fix, const float* mean, const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype, hipStream_t s);
+void affine_fixed_coeffs(double angle, double tx, double ty, double scale, double shear_x, double shear_y, int W, int H, int* out6);
 int grouped_expand(const float* w, float* wd, int Cout, int Cin, int groups, int T, hipStream_t s);
 int grouped_extract(const float* dwd, float* dw, int Cout, int Cin, int groups, int T, hipStream_t s);
 int channel_shuffle(const void* x, void* y, int64_t pixels, int C, int groups, int dtype, hipStream_t s);
@@ -655,7 +656,18 @@ int cnk_sk_maps_bwd(const void* dout, const float* attn, const float* dpooled, v
 int cnk_input_pipeline(const uint8_t* x, void* y, const int32_t* crop_yx, const uint8_t* flip, const float* mean, const float* std, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t pad, int dtype, void* stream) {
     CNK_CHECK_ARG(x && y && mean && std && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && pad >= 0, "cnk_input_pipeline: bad arguments");
     CNK_CHECK_ARG(Ho <= H + 2 * pad && Wo <= W + 2 * pad, "cnk_input_pipeline: crop larger than the padded image");
-    return input_pipeline(x, y, crop_yx, flip, mean, std, N, H, W, C, Ho, Wo, pad, dtype, S(stream));
+    return input_pipeline(x, y, crop_yx, flip, nullptr, mean, std, N, H, W, C, Ho, Wo, pad, dtype, S(stream));
+}
+int cnk_input_pipeline_affine(const uint8_t* x, void* y, const int32_t* crop_yx, const uint8_t* flip, const int32_t* affine_fix, const float* mean, const float* std, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t pad, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y && mean && std && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && pad >= 0, "cnk_input_pipeline_affine: bad arguments");
+    CNK_CHECK_ARG(Ho <= H + 2 * pad && Wo <= W + 2 * pad, "cnk_input_pipeline_affine: crop larger than the padded image");
+    CNK_CHECK_ARG(Ho < 16384 && Wo < 16384, "cnk_input_pipeline_affine: image too large for 16.16 fixed-point coordinates");
+    return input_pipeline(x, y, crop_yx, flip, affine_fix, mean, std, N, H, W, C, Ho, Wo, pad, dtype, S(stream));
+}
+int cnk_affine_fixed_coeffs(double angle_deg, double translate_x, double translate_y, double scale, double shear_x_deg, double shear_y_deg, int32_t W, int32_t H, int32_t* out6) {
+    CNK_CHECK_ARG(out6 && W > 0 && H > 0 && scale > 0.0, "cnk_affine_fixed_coeffs: bad arguments");
+    affine_fixed_coeffs(angle_deg, translate_x, translate_y, scale, shear_x_deg, shear_y_deg, W, H, out6);
+    return 0;
 }
 
 size_t cnk_grad_clip_workspace_bytes(void) { return grad_clip_workspace_bytes(); }

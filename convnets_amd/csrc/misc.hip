@@ -255,6 +255,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void input_pipeline_kernel(const unsigned char* __restrict__ x, T* __restrict__ y,
                                                              const int* __restrict__ crop_yx, const unsigned char* __restrict__ flip,
+                                                             const int* __restrict__ affine_fix,
                                                              const float* __restrict__ mean, const float* __restrict__ stdv,
                                                              int N, int H, int W, int C, int Ho, int Wo, int pad) {
     const int64_t total = (int64_t)N * Ho * Wo * C;
@@ -264,11 +265,22 @@ __global__ __launch_bounds__(256) void input_pipeline_kernel(const unsigned char
         const int w = (int)(q % Wo);
         q /= Wo;
         const int h = (int)(q % Ho), n = (int)(q / Ho);
+        // RandomAffine, the LAST geometric transform of the reference's list, so the first one seen from the output:
+        // PIL's nearest-neighbour affine in 16.16 fixed point (Geometry.c affine_fixed): source pixel of output (w, h)
+        // is (xx >> 16, yy >> 16) with xx = a2 + w*a0 + h*a1, yy = a5 + w*a3 + h*a4; outside the image -> fill 0
+        int hh = h, ww = w;
+        bool inside = true;
+        if (affine_fix) {
+            const int* a = affine_fix + 6 * n;
+            ww = (a[2] + w * a[0] + h * a[1]) >> 16;
+            hh = (a[5] + w * a[3] + h * a[4]) >> 16;
+            inside = (unsigned)ww < (unsigned)Wo && (unsigned)hh < (unsigned)Ho;
+        }
         const int oy = crop_yx ? crop_yx[2 * n] : pad, ox = crop_yx ? crop_yx[2 * n + 1] : pad;
-        const int ws = (flip && flip[n]) ? Wo - 1 - w : w;
-        const int sy = h + oy - pad, sx = ws + ox - pad;
+        const int ws = (flip && flip[n]) ? Wo - 1 - ww : ww;
+        const int sy = hh + oy - pad, sx = ws + ox - pad;
         float v = 0.f;
-        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) v = (float)x[(((size_t)n * H + sy) * W + sx) * C + c] * (1.f / 255.f);
+        if (inside && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) v = (float)x[(((size_t)n * H + sy) * W + sx) * C + c] * (1.f / 255.f);
         y[i] = from_f32<T>((v - mean[c]) / stdv[c]);
     }
 }
@@ -542,14 +554,39 @@ int grad_clip_value(float* g, int64_t n, float c, hipStream_t s) {
     return 0;
 }
 
-int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const float* mean,
-                   const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype, hipStream_t s) {
+// torchvision.transforms.functional._get_inverse_affine_matrix (the matrix RandomAffine hands to PIL's
+// Image.transform(AFFINE); torchvision is a dependency of the reference, mngrdata.py:148, not vendored in it) followed
+// by PIL's conversion to 16.16 fixed point (Geometry.c: FIX(v) = floor(v * 65536 + 0.5), half-pixel offset folded
+// into the constant terms).  Centre of rotation = (W/2, H/2), angles in degrees.
+void affine_fixed_coeffs(double angle, double tx, double ty, double scale, double shear_x, double shear_y, int W, int H,
+                         int* out6) {
+    const double rad = 3.14159265358979323846 / 180.0;
+    const double rot = angle * rad, sx = shear_x * rad, sy = shear_y * rad;
+    const double cx = W * 0.5, cy = H * 0.5;
+    const double a = cos(rot - sy) / cos(sy);
+    const double b = -cos(rot - sy) * tan(sx) / cos(sy) - sin(rot);
+    const double c = sin(rot - sy) / cos(sy);
+    const double d = -sin(rot - sy) * tan(sx) / cos(sy) + cos(rot);
+    double m[6] = {d / scale, -b / scale, 0.0, -c / scale, a / scale, 0.0};
+    m[2] += m[0] * (-cx - tx) + m[1] * (-cy - ty);
+    m[5] += m[3] * (-cx - tx) + m[4] * (-cy - ty);
+    m[2] += cx;
+    m[5] += cy;
+    auto fix = [](double v) { return (int)floor(v * 65536.0 + 0.5); };
+    out6[0] = fix(m[0]); out6[1] = fix(m[1]); out6[3] = fix(m[3]); out6[4] = fix(m[4]);
+    out6[2] = fix(m[2] + m[0] * 0.5 + m[1] * 0.5);
+    out6[5] = fix(m[5] + m[3] * 0.5 + m[4] * 0.5);
+}
+
+int input_pipeline(const unsigned char* x, void* y, const int* crop_yx, const unsigned char* flip, const int* affine_fix,
+                   const float* mean, const float* stdv, int N, int H, int W, int C, int Ho, int Wo, int pad, int dtype,
+                   hipStream_t s) {
     const int64_t total = (int64_t)N * Ho * Wo * C;
     if (total == 0) return 0;
     if (dtype == CNK_BF16)
-        hipLaunchKernelGGL(input_pipeline_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16*)y, crop_yx, flip, mean, stdv, N, H, W, C, Ho, Wo, pad);
+        hipLaunchKernelGGL(input_pipeline_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16*)y, crop_yx, flip, affine_fix, mean, stdv, N, H, W, C, Ho, Wo, pad);
     else
-        hipLaunchKernelGGL(input_pipeline_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, crop_yx, flip, mean, stdv, N, H, W, C, Ho, Wo, pad);
+        hipLaunchKernelGGL(input_pipeline_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, crop_yx, flip, affine_fix, mean, stdv, N, H, W, C, Ho, Wo, pad);
     CNK_CHECK_LAUNCH("input_pipeline");
     return 0;
 }

@@ -1195,11 +1195,22 @@ class SKSelectFn(torch.autograd.Function):
         return (None, None) + tuple(du) + tuple(dlogits)
 
 
-def input_pipeline(images_u8, mean, std, dtype, crop_size=None, padding=0, crop_yx=None, flip=None):
+def affine_fixed_coeffs(angle, scale, shear_x, width, height, translate=(0.0, 0.0), shear_y=0.0):
+    """The six 16.16 fixed-point coefficients PIL's nearest-neighbour Image.transform(AFFINE) uses for the inverse
+    matrix torchvision's RandomAffine builds from one draw (angles in degrees) -- cnk_affine_fixed_coeffs."""
+    out = (ctypes.c_int32 * 6)()
+    check(_lib.load().cnk_affine_fixed_coeffs(float(angle), float(translate[0]), float(translate[1]), float(scale),
+                                              float(shear_x), float(shear_y), int(width), int(height), out))
+    return list(out)
+
+
+def input_pipeline(images_u8, mean, std, dtype, crop_size=None, padding=0, crop_yx=None, flip=None, affine=None):
     """The reference's train/valid transforms (mngrdata.py:139-165) on the device in one pass: RandomCrop(crop_size,
-    padding) + RandomHorizontalFlip + ToTensor + Normalize(mean, std), uint8 [N, H, W, C] -> NHWC `dtype` tensor
-    [N, C, Ho, Wo] (channels_last) that the model forward takes as is.  crop_yx (int32 [N, 2]) and flip (uint8/bool
-    [N]) are the caller's random draws; None = centre crop / no flip.  No autograd (data)."""
+    padding) + RandomHorizontalFlip + RandomAffine + ToTensor + Normalize(mean, std), uint8 [N, H, W, C] -> NHWC
+    `dtype` tensor [N, C, Ho, Wo] (channels_last) that the model forward takes as is.  crop_yx (int32 [N, 2]), flip
+    (uint8/bool [N]) and affine (float [N, 3]: angle in degrees, scale, x-shear in degrees -- what
+    RandomAffine(degrees, shear, scale).get_params draws) are the caller's random draws; None = centre crop / no
+    flip / no affine.  No autograd (data)."""
     _require_gpu(images_u8)
     if images_u8.dtype != torch.uint8 or images_u8.dim() != 4:
         raise ValueError('input_pipeline: expected uint8 images [N, H, W, C]')
@@ -1213,9 +1224,15 @@ def input_pipeline(images_u8, mean, std, dtype, crop_size=None, padding=0, crop_
         crop_yx = crop_yx.to(device=dev, dtype=torch.int32).contiguous()
     if flip is not None:
         flip = flip.to(device=dev, dtype=torch.uint8).contiguous()
+    fix = None
+    if affine is not None:
+        draws = torch.as_tensor(affine, dtype=torch.float64).reshape(-1, 3).tolist()
+        if len(draws) != N:
+            raise ValueError('input_pipeline: affine needs one (angle, scale, shear_x) row per image')
+        fix = torch.tensor([affine_fixed_coeffs(a, sc, sh, Wo, Ho) for a, sc, sh in draws], dtype=torch.int32).to(dev)
     y = torch.empty((N, C, Ho, Wo), dtype=dtype, device=dev, memory_format=CL)
-    check(_lib.load().cnk_input_pipeline(_p(x), _p(y), _p(crop_yx), _p(flip), _p(mean_t), _p(std_t), N, H, W, C, Ho, Wo,
-                                         int(padding), _dtype_code(y), _stream()))
+    check(_lib.load().cnk_input_pipeline_affine(_p(x), _p(y), _p(crop_yx), _p(flip), _p(fix), _p(mean_t), _p(std_t), N, H,
+                                                W, C, Ho, Wo, int(padding), _dtype_code(y), _stream()))
     return y
 
 

@@ -225,10 +225,22 @@ int cnk_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, int32_t N, int32_t C, in
  * RandomHorizontalFlip + ToTensor + Normalize(mean, std), from uint8 images x[N][H][W][C] (HWC, as decoded) straight
  * to the NHWC `dtype` tensor the convs consume.  The random draws are the caller's: crop_yx (int32 [N][2], origin of
  * the crop in the zero-padded image, 0 <= oy <= H + 2*pad - Ho; NULL: centred at `pad`) and flip (uint8 [N]; NULL: none).
- * mean / std: fp32 [C].  RandomAffine (mngrdata.py:147) is not implemented. */
+ * mean / std: fp32 [C]. */
 int cnk_input_pipeline(const uint8_t* x, void* y, const int32_t* crop_yx, const uint8_t* flip, const float* mean,
                        const float* std, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                        int32_t pad, int dtype, void* stream);
+
+/* The same pass with RandomAffine(degrees, shear, scale) (mngrdata.py:148) as the last geometric transform, i.e. applied
+ * to the cropped and flipped Ho x Wo image about its centre, nearest neighbour, fill 0 -- exactly what
+ * torchvision hands to PIL: affine_fix (int32 [N][6], NULL: none) holds per image the six 16.16 fixed-point
+ * coefficients of PIL's Image.transform(AFFINE, NEAREST) for the inverse matrix torchvision builds from the drawn
+ * (angle, translate, scale, shear); cnk_affine_fixed_coeffs computes them on the host (angles in degrees; torchvision's
+ * RandomAffine(shear=s) draws shear_x in (-s, s) and leaves shear_y = 0).  Bit-exact with PIL for uint8 images. */
+int cnk_input_pipeline_affine(const uint8_t* x, void* y, const int32_t* crop_yx, const uint8_t* flip,
+                              const int32_t* affine_fix, const float* mean, const float* std, int32_t N, int32_t H,
+                              int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t pad, int dtype, void* stream);
+int cnk_affine_fixed_coeffs(double angle_deg, double translate_x, double translate_y, double scale,
+                            double shear_x_deg, double shear_y_deg, int32_t W, int32_t H, int32_t* out6);
 
 /* optim.Adam with L2 weight decay as the reference configures it (basemodel.py:64-67; betas
  * (0.9,0.999), eps 1e-8), over one flat fp32 arena holding every parameter:

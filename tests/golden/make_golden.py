@@ -344,6 +344,30 @@ def make_dwblocks(settings, basemodel):
     print('dwblocks.npz', len(out), 'arrays')
 
 
+def make_affine():
+    """RandomAffine(degrees=15, shear=15, scale=(0.75, 1.25)) of src/mngrdata.py:148 on PIL images, as torchvision
+    applies it: Image.transform(size, AFFINE, matrix, NEAREST, fillcolor=0) -- the expected outputs below come from
+    Pillow itself; the matrix from the restatement of torchvision's _get_inverse_affine_matrix (torchvision is not
+    installed here), stored next to them."""
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import transforms_ref as tf
+    rng = np.random.RandomState(21)
+    out = meta()
+    out['pillow_version'] = np.array(__import__('PIL').__version__)
+    sizes = [(32, 32)] * 10 + [(24, 40), (40, 24), (17, 33), (64, 64), (7, 5), (224, 224)]
+    for i, (H, W) in enumerate(sizes):
+        img = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        angle, scale, shear = rng.uniform(-15, 15), rng.uniform(0.75, 1.25), rng.uniform(-15, 15)
+        m = tf.tv_inverse_affine_matrix([W * 0.5, H * 0.5], angle, [0.0, 0.0], scale, [shear, 0.0])
+        ref = np.asarray(Image.fromarray(img).transform((W, H), Image.AFFINE, m, Image.NEAREST, fillcolor=0))
+        out[f'case{i}/img'], out[f'case{i}/draw'], out[f'case{i}/matrix'] = img, np.array([angle, scale, shear]), np.array(m)
+        out[f'case{i}/out'] = ref
+    out['n_cases'] = np.array(len(sizes))
+    np.savez_compressed(os.path.join(HERE, 'affine.npz'), **out)
+    print('affine.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     settings, basemodel, resnet, vggnet = import_reference()
@@ -351,3 +375,4 @@ if __name__ == '__main__':
     make_resblocks(settings, resnet)
     make_models(settings, basemodel, resnet, vggnet)
     make_dwblocks(settings, basemodel)
+    make_affine()

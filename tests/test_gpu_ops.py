@@ -876,3 +876,32 @@ def test_batchnorm_random_shapes_vs_torch(case, dtype):
     assert rel_l2(db, br.grad.numpy()) < (1e-4 if dtype == torch.float32 else 3e-2), 'dbeta'
     if res is not None:
         assert rel_l2(dres, rr.grad.numpy()) < t, 'dres'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_input_pipeline_with_random_affine_vs_pillow_golden(dtype):
+    """The full train transform list of src/mngrdata.py:146-153 -- RandomCrop(32, padding=4), RandomHorizontalFlip,
+    RandomAffine(degrees=15, shear=15, scale=(0.75, 1.25)), ToTensor, Normalize -- in one HIP pass.  (1) The affine stage
+    alone reproduces Pillow's outputs (tests/golden/affine.npz) bit for bit; (2) the whole list equals the CPU
+    restatement (oracle/transforms_ref.py, itself pinned by the same fixture) on random draws."""
+    from convnets_amd import ops
+    from oracle import transforms_ref as tf
+    A = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'affine.npz'))
+    for i in range(int(A['n_cases'])):
+        img, draw, want = A[f'case{i}/img'], A[f'case{i}/draw'], A[f'case{i}/out']
+        out = ops.input_pipeline(torch.from_numpy(img[None]).cuda(), [0.0] * 3, [1.0 / 255.0] * 3, torch.float32,
+                                 affine=draw[None])
+        got = host(out)[0].transpose(1, 2, 0)                                  # (v/255 - 0) / (1/255) = v
+        assert np.array_equal(np.rint(got).astype(np.uint8), want) and np.abs(got - want).max() < 1e-3, i
+    rng = np.random.RandomState(4)
+    N, pad, size = 8, 4, 32
+    imgs = rng.randint(0, 256, (N, 32, 32, 3)).astype(np.uint8)
+    mean, std = [0.478, 0.472, 0.430], [0.242, 0.238, 0.258]
+    yx = rng.randint(0, 2 * pad + 1, (N, 2))
+    flip = rng.randint(0, 2, N).astype(bool)
+    aff = np.stack([rng.uniform(-15, 15, N), rng.uniform(0.75, 1.25, N), rng.uniform(-15, 15, N)], axis=1)
+    out = ops.input_pipeline(torch.from_numpy(imgs).cuda(), mean, std, dtype, crop_size=size, padding=pad,
+                             crop_yx=torch.from_numpy(yx), flip=torch.from_numpy(flip), affine=aff)
+    ref = tf.train_transform(imgs, mean, std, size, pad, yx, flip, aff)
+    assert out.is_contiguous(memory_format=CL)
+    assert np.abs(host(out) - ref).max() < (2e-6 if dtype == torch.float32 else 2e-2)

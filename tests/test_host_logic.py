@@ -148,3 +148,16 @@ def test_init_params_reproduces_reference_weights_and_deepcopy():
     s = ca.Settings(kind=26, input_size=(3, 32, 32), num_classes=10, device='cpu')
     assert (s.batch_size, s.learning_rate, s.weight_decay, s.dropout_rate, s.seed) == (256, 0.01, 1e-4, 0.5, 21)
     assert s.compute_dtype == torch.bfloat16 and ca.Settings(kind=0, input_size=(1, 1, 1), num_classes=2, mixed_precision=False, device='cpu').compute_dtype == torch.float32
+
+
+def test_affine_fixed_coeffs_host_helper_matches_oracle():
+    """cnk_affine_fixed_coeffs is a pure host function (no GPU): torchvision's inverse affine matrix + Pillow's 16.16
+    fixed-point conversion, identical integers to the restatement that tests/golden/affine.npz pins."""
+    from convnets_amd import ops
+    from oracle import transforms_ref as tf
+    rng = np.random.RandomState(0)
+    for _ in range(300):
+        W, H = int(rng.randint(1, 300)), int(rng.randint(1, 300))
+        a, sc, sh = rng.uniform(-180, 180), rng.uniform(0.2, 3), rng.uniform(-60, 60)
+        m = tf.tv_inverse_affine_matrix([W * 0.5, H * 0.5], a, [0, 0], sc, [sh, 0.0])
+        assert ops.affine_fixed_coeffs(a, sc, sh, W, H) == tf.pil_fixed_coeffs_abi_order(m)

@@ -152,3 +152,16 @@ def test_torch_restatement_depthwise_block_matches_reference(name):
     for k, b in blk.named_buffers():
         if 'running' in k:
             assert np.array_equal(b.numpy(), DWB[f'{name}/buf/{k}']), k
+
+
+def test_affine_restatement_matches_pillow_golden():
+    """oracle/transforms_ref.py (torchvision's inverse affine matrix + Pillow's fixed-point nearest-neighbour
+    transform, the path of transforms.RandomAffine at src/mngrdata.py:148) against outputs produced by Pillow."""
+    from oracle import transforms_ref as tf
+    A = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'affine.npz'))
+    for i in range(int(A['n_cases'])):
+        img, (angle, scale, shear) = A[f'case{i}/img'], A[f'case{i}/draw']
+        H, W = img.shape[:2]
+        m = tf.tv_inverse_affine_matrix([W * 0.5, H * 0.5], angle, [0.0, 0.0], scale, [shear, 0.0])
+        assert np.allclose(m, A[f'case{i}/matrix'], rtol=0, atol=0)
+        assert np.array_equal(tf.random_affine(img, angle, scale, shear), A[f'case{i}/out']), i
