@@ -89,9 +89,8 @@ SIGNATURES = {
     'cnk_linear_dgrad': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     'cnk_linear_wgrad': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _i32, _i32, _i32, _vp, _sz, _vp]),
     'cnk_softmax_ce_sum': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
-    'cnk_dropout_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_uint64, ctypes.c_uint64, _vp]),
-    'cnk_dropout_fwd_dev': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
-    'cnk_dropout_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    'cnk_dropout_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_uint64, ctypes.c_uint64, _vp, ctypes.c_int, _vp]),
+    'cnk_dropout_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f32, ctypes.c_int, _vp]),
     'cnk_sigmoid_fwd': (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     'cnk_sigmoid_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
     'cnk_channel_scale_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),

@@ -27,8 +27,8 @@ int linear_fwd(const float* x, const float* w, const float* bias, float* y, int 
 int linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, float* ws, size_t ws_bytes, hipStream_t s);
 int linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t* argmax, float* row_loss_ws, int B, int N, hipStream_t s);
-int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hipStream_t s);
-int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s);
+int dropout_fwd(const void* x, void* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype, hipStream_t s);
+int dropout_bwd(const void* dy, const unsigned char* mask, void* dx, int64_t n, float p, int dtype, hipStream_t s);
 int avgpool_dispatch(bool bwd, const void* a, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 int sigmoid_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 int sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, hipStream_t s);
@@ -584,21 +584,20 @@ int cnk_softmax_ce_sum(const float* logits, const int64_t* target, float* loss, 
     return softmax_ce_sum(logits, target, loss, dlogits, argmax, (float*)workspace, B, N, S(stream));
 }
 
-int cnk_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
-    CNK_CHECK_ARG(x && y && mask && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_fwd: bad arguments (0 <= p < 1)");
+int cnk_dropout_fwd(const void* x, void* y, uint8_t* mask_bits, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && y && mask_bits && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_fwd: bad arguments (0 <= p < 1)");
+    CNK_CHECK_ARG(dtype == CNK_F32 || dtype == CNK_BF16, "cnk_dropout_fwd: bad dtype %d", dtype);
+    CNK_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "cnk_dropout_fwd: tensors must be 16-byte aligned");
     if (n == 0) return 0;
-    return dropout_fwd(x, y, mask, n, p, seed, offset, nullptr, S(stream));
-}
-int cnk_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
-    CNK_CHECK_ARG(x && y && mask && offset_dev && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_fwd_dev: bad arguments (0 <= p < 1)");
-    if (n == 0) return 0;
-    return dropout_fwd(x, y, mask, n, p, seed, offset, offset_dev, S(stream));
+    return dropout_fwd(x, y, mask_bits, n, p, seed, offset, offset_dev, dtype, S(stream));
 }
 
-int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
-    CNK_CHECK_ARG(dy && mask && dx && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_bwd: bad arguments (0 <= p < 1)");
+int cnk_dropout_bwd(const void* dy, const uint8_t* mask_bits, void* dx, int64_t n, float p, int dtype, void* stream) {
+    CNK_CHECK_ARG(dy && mask_bits && dx && n >= 0 && p >= 0.f && p < 1.f, "cnk_dropout_bwd: bad arguments (0 <= p < 1)");
+    CNK_CHECK_ARG(dtype == CNK_F32 || dtype == CNK_BF16, "cnk_dropout_bwd: bad dtype %d", dtype);
+    CNK_CHECK_ARG((uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0, "cnk_dropout_bwd: tensors must be 16-byte aligned");
     if (n == 0) return 0;
-    return dropout_bwd(dy, mask, dx, n, p, S(stream));
+    return dropout_bwd(dy, mask_bits, dx, n, p, dtype, S(stream));
 }
 
 int cnk_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) {

@@ -202,9 +202,39 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
     if (threadIdx.x == 0) *out = t;
 }
 
+// eight consecutive elements as floats (one 16-byte vector of bf16, two of fp32)
+template <typename T> struct VL8;
+template <> struct VL8<float> {
+    float f[8];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+        *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+template <> struct VL8<bf16> {
+    float f[8];
+    __device__ __forceinline__ void load(const bf16* p) {
+        const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (float)v[k];
+    }
+    __device__ __forceinline__ void store(bf16* p) const {
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (bf16)f[k];
+        *(bf16x8*)p = v;
+    }
+};
+
 // ---- dropout ------------------------------------------------------------------------------------------
 // Counter-based: element i of call `offset` under `seed` keeps iff hash(seed, offset, i) >= p*2^32; kept
-// values are scaled by 1/(1-p) (nn.Dropout training semantics).  The keep mask is saved as bytes.
+// values are scaled by 1/(1-p) (nn.Dropout training semantics).  The keep mask is saved bit-packed, (n+7)/8 bytes.
+// fp32 (the classifier head) or bf16 (feature-map dropout: DenseNet's dense layers, SqueezeNet's head), in place of
+// memory order -- the tensor layout does not matter.
 __device__ __forceinline__ uint32_t mix32(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -212,23 +242,56 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {
     return (uint32_t)((z ^ (z >> 31)) >> 16);
 }
 
-__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+// One thread handles 8 consecutive elements (memory order) and one byte of the bit-packed keep mask.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           unsigned char* __restrict__ mask, int64_t n,
                                                           uint32_t thresh, float scale, uint64_t seed, uint64_t offset,
                                                           const uint64_t* __restrict__ offset_dev) {
     if (offset_dev) offset += *offset_dev;        // hipGraph-captured step: the call counter of THIS replay
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = mix32(seed * 0xD1342543DE82EF95ull + offset * 0x2545F4914F6CDD1Dull + (uint64_t)i);
-        const bool keep = r >= thresh;
-        y[i] = keep ? x[i] * scale : 0.f;
-        mask[i] = keep ? 1 : 0;
+    const uint64_t key = seed * 0xD1342543DE82EF95ull + offset * 0x2545F4914F6CDD1Dull;
+    const int64_t groups = (n + 7) >> 3;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = g << 3;
+        unsigned bits = 0;
+        if (base + 8 <= n) {
+            VL8<T> v;
+            v.load(x + base);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool keep = mix32(key + (uint64_t)(base + k)) >= thresh;
+                bits |= (unsigned)keep << k;
+                v.f[k] = keep ? v.f[k] * scale : 0.f;
+            }
+            v.store(y + base);
+        } else {
+            for (int k = 0; base + k < n; ++k) {
+                const bool keep = mix32(key + (uint64_t)(base + k)) >= thresh;
+                bits |= (unsigned)keep << k;
+                y[base + k] = from_f32<T>(keep ? to_f32(x[base + k]) * scale : 0.f);
+            }
+        }
+        mask[g] = (unsigned char)bits;
     }
 }
 
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask,
-                                                          float* __restrict__ dx, int64_t n, float scale) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dx[i] = mask[i] ? dy[i] * scale : 0.f;
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                          T* __restrict__ dx, int64_t n, float scale) {
+    const int64_t groups = (n + 7) >> 3;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = g << 3;
+        const unsigned bits = mask[g];
+        if (base + 8 <= n) {
+            VL8<T> v;
+            v.load(dy + base);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v.f[k] = (bits >> k) & 1u ? v.f[k] * scale : 0.f;
+            v.store(dx + base);
+        } else {
+            for (int k = 0; base + k < n; ++k) dx[base + k] = from_f32<T>((bits >> k) & 1u ? to_f32(dy[base + k]) * scale : 0.f);
+        }
+    }
 }
 
 // ---- squeeze-and-excitation unit (src/senet.py:215-254, src/se_resnet.py:216-255) -----------------------
@@ -362,18 +425,27 @@ int softmax_ce_sum(const float* logits, const int64_t* target, float* loss, floa
     return 0;
 }
 
-int dropout_fwd(const float* x, float* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
-                const uint64_t* offset_dev, hipStream_t s) {
+int dropout_fwd(const void* x, void* y, unsigned char* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                const uint64_t* offset_dev, int dtype, hipStream_t s) {
     double t = (double)p * 4294967296.0;
     uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, y, mask, n, thresh, 1.f / (1.f - p),
-                       seed, offset, offset_dev);
+    const int grid = grid1d((n + 7) / 8);
+    if (dtype == CNK_BF16)
+        hipLaunchKernelGGL(dropout_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, mask, n, thresh,
+                           1.f / (1.f - p), seed, offset, offset_dev);
+    else
+        hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, mask, n, thresh,
+                           1.f / (1.f - p), seed, offset, offset_dev);
     CNK_CHECK_LAUNCH("dropout_fwd");
     return 0;
 }
 
-int dropout_bwd(const float* dy, const unsigned char* mask, float* dx, int64_t n, float p, hipStream_t s) {
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, dy, mask, dx, n, 1.f / (1.f - p));
+int dropout_bwd(const void* dy, const unsigned char* mask, void* dx, int64_t n, float p, int dtype, hipStream_t s) {
+    const int grid = grid1d((n + 7) / 8);
+    if (dtype == CNK_BF16)
+        hipLaunchKernelGGL(dropout_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, mask, (bf16*)dx, n, 1.f / (1.f - p));
+    else
+        hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, mask, (float*)dx, n, 1.f / (1.f - p));
     CNK_CHECK_LAUNCH("dropout_bwd");
     return 0;
 }

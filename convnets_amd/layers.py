@@ -155,9 +155,7 @@ class Dropout(nn.Dropout):
             return x
         if self.p >= 1.0:
             return x * 0.0
-        if x.dtype != torch.float32:              # feature-map dropout (SqueezeNet's head): kernel computes in fp32
-            return ops.DropoutFn.apply(x.float(), self.p).to(x.dtype)
-        return ops.DropoutFn.apply(x, self.p)
+        return ops.DropoutFn.apply(x, self.p)       # fp32 (the head) or bf16 (feature maps), in memory order
 
 
 class CrossEntropyLoss(nn.CrossEntropyLoss):

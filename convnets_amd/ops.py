@@ -837,28 +837,29 @@ CAPTURE = [None]          # the CaptureScalars of the step being captured, else 
 
 
 class DropoutFn(torch.autograd.Function):
-    """nn.Dropout, training mode (resnet.py:105).  Keep pattern = hash(torch.initial_seed(), call
-    counter, element index): reproducible under torch.manual_seed, not torch's Philox stream."""
+    """nn.Dropout, training mode (resnet.py:105; feature maps: densenet.py, squeezenet.py), fp32 or bf16, any dense
+    layout.  Keep pattern = hash(torch.initial_seed(), call counter, position in memory): reproducible under
+    torch.manual_seed, not torch's Philox stream.  The mask is saved bit-packed."""
 
     @staticmethod
     def forward(ctx, x, p):
         _require_gpu(x)
         lib = _lib.load()
-        if x.dtype != torch.float32:
-            raise ValueError('dropout: the head runs in fp32')
-        x = x if (x.is_contiguous() or x.is_contiguous(memory_format=CL)) else x.contiguous()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('dropout: fp32 or bf16 tensors')
+        x = x if (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=CL))) else x.contiguous()
         y = torch.empty_like(x)
-        mask = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+        mask = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device)
         _dropout_calls[0] += 1
         cap = CAPTURE[0]
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         if cap is None:
-            check(lib.cnk_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p),
-                                      torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_calls[0], _stream()))
+            check(lib.cnk_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), seed, _dropout_calls[0], None,
+                                      _dtype_code(x), _stream()))
         else:        # captured step: counter = (calls before this step, from device memory) + index inside the step
             cap.dropout_calls += 1
-            check(lib.cnk_dropout_fwd_dev(_p(x), _p(y), _p(mask), x.numel(), float(p),
-                                          torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, cap.dropout_calls,
-                                          cap.dropout_ptr, _stream()))
+            check(lib.cnk_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), seed, cap.dropout_calls,
+                                      cap.dropout_ptr, _dtype_code(x), _stream()))
         ctx.save_for_backward(mask)
         ctx.p = float(p)
         ctx.fmt = CL if (x.dim() == 4 and not x.is_contiguous()) else torch.contiguous_format
@@ -870,7 +871,7 @@ class DropoutFn(torch.autograd.Function):
         (mask,) = ctx.saved_tensors
         dy = dy.contiguous(memory_format=ctx.fmt)
         dx = torch.empty_like(dy)
-        check(lib.cnk_dropout_bwd(_p(dy), _p(mask), _p(dx), dy.numel(), ctx.p, _stream()))
+        check(lib.cnk_dropout_bwd(_p(dy), _p(mask), _p(dx), dy.numel(), ctx.p, _dtype_code(dy), _stream()))
         return dx, None
 
 

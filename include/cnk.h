@@ -304,16 +304,17 @@ int cnk_softmax_ce_sum(const float* logits, const int64_t* target, float* loss, 
                        int32_t* argmax, int32_t B, int32_t N, void* workspace, size_t workspace_bytes,
                        void* stream);
 
-/* nn.Dropout in training mode (resnet.py:105): y = keep ? x/(1-p) : 0 with a counter-based keep
- * decision hash(seed, offset, index) -- reproducible for a given (seed, offset), independent of the
- * launch geometry; mask (n bytes) is the keep pattern for the backward dx = mask ? dy/(1-p) : 0.
+/* nn.Dropout in training mode (resnet.py:105; feature-map dropout: densenet.py dense layers, squeezenet.py head):
+ * y = keep ? x/(1-p) : 0 with a counter-based keep decision hash(seed, offset, index) -- reproducible for a given
+ * (seed, offset), independent of the launch geometry and of the tensor layout (index = position in memory); x / y
+ * are `dtype` (fp32 or bf16), 16-byte aligned.  mask_bits ((n+7)/8 bytes, bit k of byte g = element 8g+k) is the
+ * keep pattern for the backward dx = keep ? dy/(1-p) : 0.  offset_dev (NULL: none): the call counter is
+ * offset + *offset_dev, device memory the host refreshes before each replay of a hipGraph-captured step.
  * It does not reproduce torch's Philox stream: parity runs use dropout_rate = 0. */
-int cnk_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
-                    uint64_t offset, void* stream);
-/* Same with the call counter = offset + *offset_dev (device memory, refreshed per replay of a captured step). */
-int cnk_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
-                        uint64_t offset, const uint64_t* offset_dev, void* stream);
-int cnk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+int cnk_dropout_fwd(const void* x, void* y, uint8_t* mask_bits, int64_t n, float p, uint64_t seed,
+                    uint64_t offset, const uint64_t* offset_dev, int dtype, void* stream);
+int cnk_dropout_bwd(const void* dy, const uint8_t* mask_bits, void* dx, int64_t n, float p, int dtype,
+                    void* stream);
 
 /* Squeeze-and-excitation unit (SEUnit, senet.py:215-254 / se_resnet.py:216-255): nn.Sigmoid on the fp32 [N][C]
  * descriptor, and the scale step x * gate.expand_as(x) on NHWC activations (gate fp32 [N][C]):

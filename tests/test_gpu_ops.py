@@ -473,6 +473,37 @@ def test_dropout_statistics_and_backward():
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(3, 24, 7, 5), (2, 64, 14, 14), (5, 13), (1, 8, 1, 1), (4, 1003)], ids=str)
+def test_dropout_feature_maps_and_ragged_sizes(shape, dtype):
+    """Feature-map dropout (densenet.py dense layers, squeezenet.py head) natively in bf16 / fp32 on NHWC or plain
+    tensors, sizes that are not a multiple of the 8-element mask byte: same keep pattern for both dtypes (the hash
+    depends on seed, call counter and memory position only), exact scaling, backward through the bit-packed mask."""
+    from convnets_amd import layers, ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(*shape, generator=g)
+    x = x.bfloat16().float() if dtype == torch.bfloat16 else x
+    keeps = []
+    for dt in (dtype, torch.float32):
+        torch.manual_seed(3)
+        ops._dropout_calls[0] = 7
+        xt = x.cuda().to(dt)
+        xt = xt.contiguous(memory_format=CL) if xt.dim() == 4 else xt
+        xt.requires_grad_(True)
+        y = layers.Dropout(p=0.4).cuda().train()(xt)
+        assert y.dtype == dt and y.shape == xt.shape
+        dy = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).cuda().to(dt)
+        dy = dy.contiguous(memory_format=CL) if dy.dim() == 4 else dy
+        y.backward(dy)
+        torch.cuda.synchronize()
+        want = (xt.detach().float() * (1.0 / (1.0 - 0.4))).to(dt)          # one rounding, as in the kernel
+        keep = y != 0
+        assert torch.equal(y[keep], want[keep])
+        assert torch.equal(xt.grad[keep], (dy.float() * (1.0 / (1.0 - 0.4))).to(dt)[keep]) and float(xt.grad[~keep].abs().sum()) == 0
+        keeps.append(keep | (xt.detach() == 0))                                 # (a zero input reads as dropped)
+    assert torch.equal(keeps[0], keeps[1])
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
 @pytest.mark.parametrize('cfg', [(64, 64, 3, 1, 1, True, False), (64, 128, 3, 2, 1, True, False),
                                  (128, 256, 1, 1, 0, True, True), (256, 64, 1, 2, 0, False, False)],
                          ids=['k3s1', 'k3s2', 'k1-res', 'k1s2-noact'])
