@@ -839,7 +839,12 @@ bool igemm_supported(const cnk_conv_desc* d, int pass) {
     // off the grid (Inception / SqueezeNet / MobileNet widths): any multiple of one 16-byte vector, as long as
     // the zero padding of K stays below 2x; narrower layers keep the small-channel kernels
     if (conv_groups(d) > 1) return false;
-    return cred % vec == 0 && nout % vec == 0 && cred >= kstep / 2 && nout >= 16;
+    if (cred % vec || nout % vec || nout < 16) return false;
+    // a data gradient with a narrow reduction but a wide output (Inception's 1x1 "reduce" convs: Cout 16/24, Cin
+    // 192..512) writes N*H*W*Cin values per 16..24-deep dot product: HBM-bound whatever the MFMA does with the
+    // zero-padded K, and 6x faster here than on the direct kernel
+    if (pass == CNK_PASS_DGRAD && nout >= 64) return true;
+    return cred >= kstep / 2;
 }
 
 // elements of the (zero-padded) weight image of one pass: [ceil(nout/64)*64][taps][ceil(cred/kstep)*kstep]

@@ -636,6 +636,9 @@ def _random_conv_cases(n, seed):
         if H + 2 * ph < kh or W + 2 * pw < kw or kh * kw > 25:
             continue
         cases.append((N, cin, H, W, cout, kh, kw, sh, sw, ph, pw, bool(rng.randint(0, 2))))
+    # narrow outputs behind wide inputs (Inception's 1x1 reduce convs): the data gradient has a 16/24-deep reduction
+    cases += [(2, 192, 9, 9, 16, 1, 1, 1, 1, 0, 0, False), (3, 512, 7, 7, 24, 1, 1, 1, 1, 0, 0, True),
+              (2, 128, 8, 8, 16, 3, 3, 1, 1, 1, 1, False), (2, 480, 6, 6, 16, 1, 1, 2, 2, 0, 0, False)]
     return cases
 
 
