@@ -94,7 +94,8 @@ SIGNATURES = {
     'cnk_sigmoid_fwd': (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     'cnk_sigmoid_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
     'cnk_channel_scale_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
-    'cnk_channel_scale_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),
+    'cnk_channel_scale_workspace_bytes': (ctypes.c_size_t, [_i32, _i32, _i32, ctypes.c_int]),
+    'cnk_channel_scale_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     'cnk_sk_workspace_bytes': (ctypes.c_size_t, [_i32, _i32, _i32, _i32]),
     'cnk_sk_pool_fwd': (ctypes.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     'cnk_sk_select_fwd': (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, ctypes.c_int, _vp]),

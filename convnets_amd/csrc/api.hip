@@ -35,6 +35,8 @@ int sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, hipStream
 int channel_scale_fwd(const void* x, const float* g, void* y, int N, int HW, int C, int dtype, hipStream_t s);
 int channel_scale_bwd(const void* dy, const void* x, const float* g, void* dx, float* dg, int N, int HW, int C, int dtype, hipStream_t s);
 bool sk_supported(int C, int P, int dtype);
+int sk_scale_fwd(const void* x, const float* gate, void* y, int N, int HW, int C, int dtype, hipStream_t s);
+int sk_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int N, int HW, int C, int dtype, float* ws, hipStream_t s);
 size_t sk_workspace(int N, int HW, int C, int P);
 int sk_pool_fwd(const void* const* u, int P, float* pooled, int N, int HW, int C, int dtype, float* ws, hipStream_t s);
 int sk_select_fwd(const void* const* u, const float* const* logits, int P, float* attn, void* out, int N, int HW, int C, int dtype, hipStream_t s);
@@ -610,10 +612,18 @@ int cnk_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void*
 }
 int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
     CNK_CHECK_ARG(x && gate && y && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_fwd: bad arguments");
+    if (sk_supported(C, 1, dtype)) return sk_scale_fwd(x, gate, y, N, HW, C, dtype, S(stream));      // 16-byte lanes along C
     return channel_scale_fwd(x, gate, y, N, HW, C, dtype, S(stream));
 }
-int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N, int32_t HW, int32_t C, int dtype, void* stream) {
+size_t cnk_channel_scale_workspace_bytes(int32_t N, int32_t HW, int32_t C, int dtype) {
+    return N > 0 && HW > 0 && C > 0 && sk_supported(C, 1, dtype) ? sk_workspace(N, HW, C, 1) : 0;
+}
+int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N, int32_t HW, int32_t C, int dtype, void* ws, size_t ws_bytes, void* stream) {
     CNK_CHECK_ARG(dy && x && gate && dx && dgate && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_bwd: bad arguments");
+    if (sk_supported(C, 1, dtype)) {
+        CNK_CHECK_ARG(ws && ws_bytes >= sk_workspace(N, HW, C, 1), "cnk_channel_scale_bwd: workspace too small (cnk_channel_scale_workspace_bytes)");
+        return sk_scale_bwd(dy, x, gate, dx, dgate, N, HW, C, dtype, (float*)ws, S(stream));
+    }
     return channel_scale_bwd(dy, x, gate, dx, dgate, N, HW, C, dtype, S(stream));
 }
 

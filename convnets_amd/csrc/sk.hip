@@ -72,9 +72,11 @@ __device__ __forceinline__ SkLane sk_lane(int CV) {
 }
 
 // partial[n][chunk][q][c] = sum over the chunk's rows of  (DOT ? dout * U_q : sum_i U_i)   (Q = DOT ? P : 1)
-template <typename T, int P, bool DOT>
+// WDX (SE unit backward, P = 1): the same pass also writes dx = dout * gate[n][c] (channel-scale gradient).
+template <typename T, int P, bool DOT, bool WDX = false>
 __global__ __launch_bounds__(256) void sk_reduce_kernel(SkMaps maps, const T* __restrict__ dout,
-                                                        float* __restrict__ partial, int HW, int C, int chunks) {
+                                                        float* __restrict__ partial, int HW, int C, int chunks,
+                                                        const float* __restrict__ gate = nullptr, T* __restrict__ dx = nullptr) {
     constexpr int V = SkVec<T>::N;
     constexpr int Q = DOT ? P : 1;
     using Raw = typename SkVec<T>::Raw;
@@ -91,10 +93,21 @@ __global__ __launch_bounds__(256) void sk_reduce_kernel(SkMaps maps, const T* __
         for (int j = 0; j < V; ++j) acc[q][j] = 0.f;
     if (l.on) {
         const size_t img = (size_t)n * HW * CV;
+        float gv[V];
+        if (WDX) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) gv[j] = gate[(size_t)n * C + (size_t)l.col * V + j];
+        }
         for (int r = r_lo + l.row0; r < r_hi; r += l.rstep) {
             const size_t at = img + (size_t)r * CV + l.col;
             float d[V];
             if (DOT) SkVec<T>::unpack(reinterpret_cast<const Raw*>(dout)[at], d);
+            if (WDX) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[j] = d[j] * gv[j];
+                reinterpret_cast<Raw*>(dx)[at] = SkVec<T>::pack(o);
+            }
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 float u[V];
@@ -327,6 +340,38 @@ int sk_maps_bwd(const void* dout, const float* attn, const float* dpooled, void*
         SK_SWITCH_P(P, hipLaunchKernelGGL((sk_maps_bwd_kernel<float, PP>), dim3(sk_grid1d(total_v)), dim3(256), 0, s, (const float*)dout, attn, dpooled, o, total_v, HW, C, NC, inv_hw));
     }
     CNK_CHECK_LAUNCH("sk_maps_bwd");
+    return 0;
+}
+
+// ---- squeeze-and-excitation unit on the same passes (P = 1) -------------------------------------------------
+// y = x * gate[n][c]: the select pass with the gate as the (already normalised) attention
+int sk_scale_fwd(const void* x, const float* gate, void* y, int N, int HW, int C, int dtype, hipStream_t s) {
+    SkMaps m = {};
+    m.u[0] = x;
+    const int64_t total_v = (int64_t)N * HW * (C / sk_vec(dtype));
+    if (dtype == CNK_BF16)
+        hipLaunchKernelGGL((sk_select_fwd_kernel<bf16, 1>), dim3(sk_grid1d(total_v)), dim3(256), 0, s, m, gate, (bf16*)y, total_v, HW, C, N * C);
+    else
+        hipLaunchKernelGGL((sk_select_fwd_kernel<float, 1>), dim3(sk_grid1d(total_v)), dim3(256), 0, s, m, gate, (float*)y, total_v, HW, C, N * C);
+    CNK_CHECK_LAUNCH("sk_scale_fwd");
+    return 0;
+}
+// dx = dy * gate, dgate[n][c] = sum_hw dy * x: ONE pass over dy and x (chunked fixed-order partials) + the chunk sum
+int sk_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int N, int HW, int C, int dtype,
+                 float* ws, hipStream_t s) {
+    SkMaps m = {};
+    m.u[0] = x;
+    const int chunks = sk_chunks(N, HW);
+    if (dtype == CNK_BF16) {
+        dim3 grid(chunks, N, (C / 8 + 255) / 256);
+        hipLaunchKernelGGL((sk_reduce_kernel<bf16, 1, true, true>), grid, dim3(256), 0, s, m, (const bf16*)dy, ws, HW, C, chunks, gate, (bf16*)dx);
+    } else {
+        dim3 grid(chunks, N, (C / 4 + 255) / 256);
+        hipLaunchKernelGGL((sk_reduce_kernel<float, 1, true, true>), grid, dim3(256), 0, s, m, (const float*)dy, ws, HW, C, chunks, gate, (float*)dx);
+    }
+    CNK_CHECK_LAUNCH("sk_scale_bwd_reduce");
+    hipLaunchKernelGGL(sk_pool_finish_kernel, dim3(ceil_div(N * C, 256)), dim3(256), 0, s, ws, dgate, N, C, chunks, 1.f);
+    CNK_CHECK_LAUNCH("sk_scale_bwd_finish");
     return 0;
 }
 

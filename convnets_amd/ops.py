@@ -708,7 +708,14 @@ class GlobalAvgPoolFn(torch.autograd.Function):
         x = _nhwc(x)
         N, C, H, W = x.shape
         y = torch.empty((N, C, 1, 1), dtype=torch.float32, device=x.device)
-        check(lib.cnk_gap_fwd(_p(x), _p(y), N, H * W, C, _dtype_code(x), _stream()))
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        if H * W >= 64 and C % vec == 0:
+            # large maps (the squeeze step of an SE unit): the chunked streaming reduction of csrc/sk.hip, one path
+            nws = lib.cnk_sk_workspace_bytes(N, H * W, C, 1)
+            ws = workspace(nws, x.device)
+            check(lib.cnk_sk_pool_fwd(_ptr_table([x]), 1, _p(y), N, H * W, C, _dtype_code(x), _p(ws), nws, _stream()))
+        else:
+            check(lib.cnk_gap_fwd(_p(x), _p(y), N, H * W, C, _dtype_code(x), _stream()))
         ctx.shape, ctx.dt = x.shape, x.dtype
         return y
 
@@ -1094,8 +1101,10 @@ class ChannelScaleFn(torch.autograd.Function):
         N, C, H, W = x.shape
         dx = torch.empty_like(x, memory_format=CL)
         dgate = torch.empty_like(gate)
+        nws = lib.cnk_channel_scale_workspace_bytes(N, H * W, C, _dtype_code(x))
+        ws = workspace(nws, x.device) if nws else None
         check(lib.cnk_channel_scale_bwd(_p(dy), _p(x), _p(gate), _p(dx), _p(dgate), N, H * W, C, _dtype_code(x),
-                                        _stream()))
+                                        _p(ws), nws, _stream()))
         return dx, dgate
 
 

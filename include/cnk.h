@@ -323,8 +323,11 @@ int cnk_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
 int cnk_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, int32_t HW, int32_t C, int dtype,
                           void* stream);
+/* ws: cnk_channel_scale_workspace_bytes(N, HW, C, dtype) bytes (0 when C is not a multiple of one 16-byte vector:
+ * the scalar kernels then need none) -- fixed-order partial sums of dgate. */
+size_t cnk_channel_scale_workspace_bytes(int32_t N, int32_t HW, int32_t C, int dtype);
 int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N,
-                          int32_t HW, int32_t C, int dtype, void* stream);
+                          int32_t HW, int32_t C, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- selective-kernel unit (reference src/sknet.py:172-240 == src/sk_resnet.py:171-239) -----------------
  * P (<= 4) NHWC feature maps u[i] of one shape [N][HW][C] (the grouped, dilated conv paths, sknet.py:186-198).

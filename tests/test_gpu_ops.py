@@ -939,3 +939,44 @@ def test_input_pipeline_with_random_affine_vs_pillow_golden(dtype):
     ref = tf.train_transform(imgs, mean, std, size, pad, yx, flip, aff)
     assert out.is_contiguous(memory_format=CL)
     assert np.abs(host(out) - ref).max() < (2e-6 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(3, 64, 14, 14), (2, 256, 56, 56), (4, 2048, 7, 7), (2, 72, 9, 11), (3, 20, 5, 5),
+                                   (2, 4096, 8, 8), (1, 6, 3, 3)], ids=str)
+def test_se_unit_squeeze_and_scale_vs_torch(shape, dtype):
+    """The SE unit's two tensor passes (senet.py:240-252): squeeze = AdaptiveAvgPool2d(1) and x * gate.expand_as(x),
+    forward and backward (dx, dgate), on the streaming 16-byte-lane kernels for channel counts on the vector grid
+    and the scalar kernels otherwise; large and small maps."""
+    from convnets_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    N, C, H, W = shape
+    x = torch.randn(*shape, generator=g)
+    x = x.bfloat16().float() if dtype == torch.bfloat16 else x
+    gate = torch.rand(N, C, generator=g)
+    dy = torch.randn(*shape, generator=g)
+    dy = dy.bfloat16().float() if dtype == torch.bfloat16 else dy
+    dp = torch.randn(N, C, 1, 1, generator=g)
+    xr, gr = x.double().requires_grad_(True), gate.double().requires_grad_(True)
+    yr = xr * gr.view(N, C, 1, 1)
+    pr = xr.mean((2, 3), keepdim=True)
+    (yr * dy.double()).sum().backward()
+    dx_scale, dgate = xr.grad.clone(), gr.grad.clone()
+    xr.grad = None
+    (pr * dp.double()).sum().backward()
+    xt = dev(x.numpy(), dtype).requires_grad_(True)
+    gt = gate.cuda().requires_grad_(True)
+    y = ops.ChannelScaleFn.apply(xt, gt)
+    y.backward(dev(dy.numpy(), dtype))
+    torch.cuda.synchronize()
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(host(y), yr.detach().numpy()) < t
+    assert rel_l2(host(xt.grad), dx_scale.numpy()) < t
+    assert rel_l2(gt.grad.cpu().numpy(), dgate.numpy()) < (2e-5 if dtype == torch.float32 else 1e-4)   # fp32 sums of exact products
+    xt.grad = None
+    p = ops.GlobalAvgPoolFn.apply(xt)
+    assert p.dtype == torch.float32 and tuple(p.shape) == (N, C, 1, 1)
+    p.backward(dp.cuda())
+    torch.cuda.synchronize()
+    assert rel_l2(p.detach().cpu().numpy(), pr.detach().numpy()) < 2e-6
+    assert rel_l2(host(xt.grad), xr.grad.numpy()) < t
