@@ -38,6 +38,13 @@ class Conv2d(nn.Conv2d):
                 or isinstance(self.padding, str):
             raise NotImplementedError('convnets_amd.Conv2d: zeros padding; dilation (equal in h and w) only on the '
                                       'implicit-GEMM shapes (channel counts that are multiples of 8, not depthwise)')
+        # bf16 activations whose channel count is a multiple of 4 but not of 8 (ShuffleNet g1..g4: 36/60/68-wide
+        # bottlenecks) have rows that are not whole 16-byte vectors, which the bf16 MFMA kernels need; the fp32
+        # kernels take multiples of 4, so such a layer runs in fp32 between two casts instead of on the direct
+        # kernels (50x slower): ShuffleNet-g4 106.9 -> see DESIGN.md
+        ci, co = self.in_channels, self.out_channels
+        self._f32_detour = not self._depthwise and not self._chunked and (ci % 8 != 0 or co % 8 != 0) \
+            and ci % 4 == 0 and co % 4 == 0 and ci >= 16 and co >= 16 and dl[0] == 1
         self._packed = ops.PackedWeights()
 
     def __deepcopy__(self, memo):
@@ -53,6 +60,12 @@ class Conv2d(nn.Conv2d):
     def forward(self, x, want_bn_partial=False, link=None):
         if self._depthwise:                      # conv2d_depthwise (basemodel.py:981-997)
             y = ops.DepthwiseConv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
+            return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
+        if self._f32_detour and x.dtype == torch.bfloat16 and link is None:
+            w = ops.GroupedDenseWeightFn.apply(self.weight, self.groups) if self._dense_grouped else self.weight
+            y = ops.Conv2dFn.apply(x.float(), w, self.bias, _pair(self.stride), _pair(self.padding), self._packed, False,
+                                   None, None, 1 if self._dense_grouped else self.groups, self._dil)
+            y = y.to(torch.bfloat16)
             return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
         # x._cnk_bn: set when x is the output of a training-mode BatchNorm2d of this package (ops.BnRecord)
         if self._dense_grouped:
