@@ -97,8 +97,32 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
             }
         };
         if constexpr (TAPS == 9) {
+            // all nine loads are issued before the first FMA: taps that fall outside read the (valid) centre-safe
+            // pixel 0 of the image and are multiplied away, so no load sits behind a branch
+            RawV<T, VEC> tv[9];
+            bool tok[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) tap(t, t / 3, t % 3);
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, q = t % 3;
+                int ih, iw;
+                bool ok;
+                if constexpr (DGRAD) {
+                    const int th = oh + p.ph - r, tw = ow + p.pw - q;
+                    ok = th >= 0 && tw >= 0 && th % p.sh == 0 && tw % p.sw == 0;
+                    ih = th / p.sh; iw = tw / p.sw;
+                } else {
+                    ih = oh * p.sh - p.ph + r; iw = ow * p.sw - p.pw + q;
+                    ok = true;
+                }
+                ok = ok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
+                tok[t] = ok;
+                const size_t pix = ok ? (size_t)(img * SH + ih) * SW + iw : (size_t)img * SH * SW;
+                tv[t].load(src + pix * p.C + c0);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += (tok[t] ? tv[t].get(e) : 0.f) * wr[t][e];
         } else {
             for (int r = 0, t = 0; r < p.kh; ++r)
                 for (int q = 0; q < p.kw; ++q, ++t) tap(t, r, q);
@@ -134,17 +158,22 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const DwParams p) {
             const int oh = (int)fd_div(rem, p.fd_w), ow = (int)(rem - (uint32_t)oh * p.fd_w.d);
             RawV<T, VEC> d;
             d.load(dy + (size_t)m * p.C + c0);
+            // every tap's load is issued before the first FMA (out-of-image taps read pixel 0 of the image and
+            // are selected away): no load behind a branch
+            RawV<T, VEC> tv[TAPS];
+            bool tok[TAPS];
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int r = t / p.kw, q = t - r * p.kw;
                 const int ih = oh * p.sh - p.ph + r, iw = ow * p.sw - p.pw + q;
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-                    RawV<T, VEC> v;
-                    v.load(x + ((size_t)(img * p.H + ih) * p.W + iw) * p.C + c0);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[t][e] += d.get(e) * v.get(e);
-                }
+                tok[t] = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const size_t pix = tok[t] ? (size_t)(img * p.H + ih) * p.W + iw : (size_t)img * p.H * p.W;
+                tv[t].load(x + pix * p.C + c0);
             }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[t][e] += d.get(e) * (tok[t] ? tv[t].get(e) : 0.f);
         }
     }
     int span = 1;
