@@ -93,7 +93,8 @@ class MultiClassBaseModel(nn.Module):
         """Count of correct predictions (basemodel.py:119-121) -- kept on the device; the caller
         decides when to pay the host sync."""
         cf = self.cost_function
-        if getattr(cf, 'last_logits', None) is outputs and cf.last_pred is not None:
+        ref = getattr(cf, 'last_logits', None)
+        if ref is not None and ref() is outputs and cf.last_pred is not None:
             return (cf.last_pred == targets).sum()          # argmax came with the loss kernel
         return (outputs.argmax(dim=1) == targets).sum()
 

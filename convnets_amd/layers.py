@@ -7,6 +7,8 @@ They SUBCLASS the stock torch.nn modules the reference's factory returns
 shapes for state_dict interchange (:883,940), `.train()/.eval()`, `.to(device)`, deepcopy.
 Only `forward` is replaced: it dispatches to the HIP kernels through convnets_amd.ops.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -185,7 +187,9 @@ class CrossEntropyLoss(nn.CrossEntropyLoss):
 
     def forward(self, outputs, targets):
         loss, pred = ops.SoftmaxCrossEntropySumFn.apply(outputs, targets)
-        self.last_pred, self.last_logits = pred, outputs
+        # weak: a strong reference to the logits would keep the whole autograd graph of the step (and the
+        # AccumulateGrad nodes of its leaves) alive until the next forward -- which breaks hipGraph capture
+        self.last_pred, self.last_logits = pred, weakref.ref(outputs)
         return loss
 
 

@@ -41,6 +41,8 @@ def _grad_written(param):
 
 def _arena_grad(param):
     """The parameter's .grad if a kernel may accumulate into it directly (fp32, dense, same shape)."""
+    if not param.is_leaf:              # e.g. the dense image of a grouped weight: autograd carries its gradient
+        return None
     g = param.grad
     if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape \
             and g.device == param.device:
@@ -327,10 +329,13 @@ class PackedWeights:
                 check(lib.cnk_conv2d_pack_weights(ctypes.byref(desc), _p(weight), _p(self.w_fwd),
                                                   _p(self.w_dgrad), _stream()))
             self.key = key
-            self.weight, self.desc = weight, desc
+            # a non-leaf weight (the dense image of a grouped weight, re-made every forward) is neither kept -- the
+            # reference would keep its autograd graph, and the AccumulateGrad node of an earlier iteration, alive --
+            # nor batched (its storage changes from step to step)
+            self.weight, self.desc = (weight if weight.is_leaf else None), desc
             # batch from the next epoch on if every image of this conv is an implicit-GEMM image
             probe = (_lib.PackJob * 24)()
-            self.batched = weight.requires_grad and lib.cnk_conv2d_pack_jobs(
+            self.batched = weight.is_leaf and weight.requires_grad and lib.cnk_conv2d_pack_jobs(
                 ctypes.byref(desc), _p(weight), _p(self.w_fwd), _p(self.w_dgrad), probe, 24) >= 0
             if self.batched:
                 self.batched_epoch = weights_epoch()

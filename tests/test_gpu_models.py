@@ -399,20 +399,23 @@ def test_training_trajectory_tracks_the_oracle(mixed):
     assert abs(last_h - last_r) < (0.15 if not mixed else 0.3) * first_r      # same trajectory, not just "decreasing"
 
 
+@pytest.mark.parametrize('family,kind', [('resnet', 18), ('shufflenet', 'g4'), ('seresnet', 26)], ids=['resnet18', 'shufflenet_g4', 'seresnet26'])
 @pytest.mark.parametrize('mixed', [False, True], ids=['f32', 'bf16'])
-def test_graphed_step_equals_eager_step(mixed):
+def test_graphed_step_equals_eager_step(mixed, family, kind):
     """convnets_amd.GraphedTrainStep (hipGraph capture of one loop iteration, basemodel.py:245-288): N replays
     leave the model exactly where N eager steps leave it -- same losses, scores, parameters, Adam moments, BN
     running statistics -- with dropout ON (the call counter of each replay comes from device memory) and the
-    bias corrections of each step read from device memory.  Constructing the graph must not advance training."""
+    bias corrections of each step read from device memory.  Constructing the graph must not advance training.
+    ShuffleNet: grouped weights whose gradients reach .grad through autograd's AccumulateGrad (a node kept alive from
+    an earlier iteration would sit on the wrong stream and break the capture); SE-ResNet: torch adds in the graph."""
     import convnets_amd as ca
     from convnets_amd import ops
 
     def make():
         torch.manual_seed(5)
-        s = ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, batch_size=8, batch_norm=True,
+        s = ca.Settings(kind=kind, input_size=(3, 32, 32), num_classes=10, batch_size=8, batch_norm=True,
                         mixed_precision=mixed, dropout_rate=0.3, seed=5)
-        m = ca.MODELS['resnet'](s).cuda()
+        m = ca.MODELS[family](s).cuda()
         m.init_optimizer()
         m.train()
         return m
