@@ -477,3 +477,33 @@ def test_train_model_with_hipgraph_setting_equals_eager_epoch():
     assert len(gm._graphed_steps) == 2                     # one graph per batch shape
     assert g_out == e_out
     assert torch.equal(g_p, e_p)
+
+
+@pytest.mark.parametrize('name,family,kind,in_size,bn', MODEL_CASES)
+def test_every_family_captures_into_a_hipgraph(name, family, kind, in_size, bn):
+    """GraphedTrainStep on each of the reference's model files (bf16 path; ConvNet fp32): two replays give the losses
+    of two eager steps -- concat, channel shuffle, SE / SK gating, grouped, depthwise and dilated convs, torch-side
+    gradient sums and casts are all capturable."""
+    import convnets_amd as ca
+    from convnets_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(8, *in_size, generator=gen).cuda()
+    y = torch.randint(0, 10, (8,), generator=gen).cuda()
+
+    def make():
+        torch.manual_seed(2)
+        ops._dropout_calls[0] = 0
+        s = ca.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=8, batch_norm=bn,
+                        mixed_precision=bn, dropout_rate=0.25, seed=2)
+        m = ca.MODELS[family](s).cuda()
+        m.init_optimizer()
+        m.train()
+        return m
+    eager = make()
+    want = [float(eager.train_batch((x, y))[0]) for _ in range(2)]
+    graphed = make()
+    step = ca.GraphedTrainStep(graphed, (x, y))
+    got = [float(step.replay()[0]) for _ in range(2)]
+    torch.cuda.synchronize()
+    assert got == want
+    assert torch.equal(graphed.optimizer.flat_p, eager.optimizer.flat_p)
