@@ -619,7 +619,8 @@ size_t cnk_channel_scale_workspace_bytes(int32_t N, int32_t HW, int32_t C, int d
     return N > 0 && HW > 0 && C > 0 && sk_supported(C, 1, dtype) ? sk_workspace(N, HW, C, 1) : 0;
 }
 int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N, int32_t HW, int32_t C, int dtype, void* ws, size_t ws_bytes, void* stream) {
-    CNK_CHECK_ARG(dy && x && gate && dx && dgate && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_bwd: bad arguments");
+    CNK_CHECK_ARG(dy && x && gate && dgate && N > 0 && HW > 0 && C > 0, "cnk_channel_scale_bwd: bad arguments");
+    CNK_CHECK_ARG(dx || sk_supported(C, 1, dtype), "cnk_channel_scale_bwd: dx may be NULL only on the vector path (C a multiple of one 16-byte vector)");
     if (sk_supported(C, 1, dtype)) {
         CNK_CHECK_ARG(ws && ws_bytes >= sk_workspace(N, HW, C, 1), "cnk_channel_scale_bwd: workspace too small (cnk_channel_scale_workspace_bytes)");
         return sk_scale_bwd(dy, x, gate, dx, dgate, N, HW, C, dtype, (float*)ws, S(stream));

@@ -362,12 +362,15 @@ int sk_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, flo
     SkMaps m = {};
     m.u[0] = x;
     const int chunks = sk_chunks(N, HW);
+    // dx == nullptr: only the reduction (the caller writes dx later, together with the squeeze branch's gradient)
     if (dtype == CNK_BF16) {
         dim3 grid(chunks, N, (C / 8 + 255) / 256);
-        hipLaunchKernelGGL((sk_reduce_kernel<bf16, 1, true, true>), grid, dim3(256), 0, s, m, (const bf16*)dy, ws, HW, C, chunks, gate, (bf16*)dx);
+        if (dx) hipLaunchKernelGGL((sk_reduce_kernel<bf16, 1, true, true>), grid, dim3(256), 0, s, m, (const bf16*)dy, ws, HW, C, chunks, gate, (bf16*)dx);
+        else hipLaunchKernelGGL((sk_reduce_kernel<bf16, 1, true, false>), grid, dim3(256), 0, s, m, (const bf16*)dy, ws, HW, C, chunks, nullptr, nullptr);
     } else {
         dim3 grid(chunks, N, (C / 4 + 255) / 256);
-        hipLaunchKernelGGL((sk_reduce_kernel<float, 1, true, true>), grid, dim3(256), 0, s, m, (const float*)dy, ws, HW, C, chunks, gate, (float*)dx);
+        if (dx) hipLaunchKernelGGL((sk_reduce_kernel<float, 1, true, true>), grid, dim3(256), 0, s, m, (const float*)dy, ws, HW, C, chunks, gate, (float*)dx);
+        else hipLaunchKernelGGL((sk_reduce_kernel<float, 1, true, false>), grid, dim3(256), 0, s, m, (const float*)dy, ws, HW, C, chunks, nullptr, nullptr);
     }
     CNK_CHECK_LAUNCH("sk_scale_bwd_reduce");
     hipLaunchKernelGGL(sk_pool_finish_kernel, dim3(ceil_div(N * C, 256)), dim3(256), 0, s, ws, dgate, N, C, chunks, 1.f);

@@ -212,6 +212,12 @@ class SEUnit(nn.Module):
 
     def forward(self, x):
         n, c = x.shape[0], x.shape[1]
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        if x.is_cuda and c % vec == 0:
+            # x is read by the squeeze and by the scale: their two gradients are written by ONE pass (ops.SKLink)
+            link = ops.SKLink() if torch.is_grad_enabled() and x.requires_grad else None
+            gate = self.excitation(ops.SKPoolFn.apply(link, x).view(n, c))
+            return ops.ChannelScaleFn.apply(x, gate, link)
         gate = self.excitation(self.squeeze(x).view(n, c))
         return ops.ChannelScaleFn.apply(x, gate)
 

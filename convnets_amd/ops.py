@@ -1082,10 +1082,13 @@ class SigmoidFn(torch.autograd.Function):
 
 
 class ChannelScaleFn(torch.autograd.Function):
-    """x * gate.expand_as(x) (senet.py:252): NHWC activations scaled per (sample, channel) by the fp32 gate [N, C]."""
+    """x * gate.expand_as(x) (senet.py:252): NHWC activations scaled per (sample, channel) by the fp32 gate [N, C].
+    link: the SKLink shared with the SKPoolFn that squeezed the same x (layers.SEUnit): this backward then produces
+    only dgate and leaves (dy, gate) for the pool backward, which writes dx = dy * gate + dpooled / HW in one pass
+    instead of two gradient tensors plus autograd's add."""
 
     @staticmethod
-    def forward(ctx, x, gate):
+    def forward(ctx, x, gate, link=None):
         _require_gpu(x)
         lib = _lib.load()
         x = _nhwc(x)
@@ -1096,6 +1099,7 @@ class ChannelScaleFn(torch.autograd.Function):
         y = torch.empty_like(x, memory_format=CL)
         check(lib.cnk_channel_scale_fwd(_p(x), _p(gate), _p(y), N, H * W, C, _dtype_code(x), _stream()))
         ctx.save_for_backward(x, gate)
+        ctx.link = link
         return y
 
     @staticmethod
@@ -1104,13 +1108,17 @@ class ChannelScaleFn(torch.autograd.Function):
         x, gate = ctx.saved_tensors
         dy = _nhwc(dy)
         N, C, H, W = x.shape
-        dx = torch.empty_like(x, memory_format=CL)
+        link = ctx.link
+        linked = link is not None and link.pool_pending and ctx.needs_input_grad[0]
+        dx = None if linked else torch.empty_like(x, memory_format=CL)
         dgate = torch.empty_like(gate)
         nws = lib.cnk_channel_scale_workspace_bytes(N, H * W, C, _dtype_code(x))
         ws = workspace(nws, x.device) if nws else None
         check(lib.cnk_channel_scale_bwd(_p(dy), _p(x), _p(gate), _p(dx), _p(dgate), N, H * W, C, _dtype_code(x),
                                         _p(ws), nws, _stream()))
-        return dx, dgate
+        if linked:
+            link.stash = (dy, gate)                    # SKPoolFn.backward writes the gradient of x
+        return dx, dgate, None
 
 
 # ---- selective-kernel unit (sknet.py:172-240) ---------------------------------------------------------

@@ -324,7 +324,9 @@ int cnk_sigmoid_bwd(const float* dy, const float* y, float* dx, int64_t n, void*
 int cnk_channel_scale_fwd(const void* x, const float* gate, void* y, int32_t N, int32_t HW, int32_t C, int dtype,
                           void* stream);
 /* ws: cnk_channel_scale_workspace_bytes(N, HW, C, dtype) bytes (0 when C is not a multiple of one 16-byte vector:
- * the scalar kernels then need none) -- fixed-order partial sums of dgate. */
+ * the scalar kernels then need none) -- fixed-order partial sums of dgate.  dx may be NULL on the vector path: only
+ * dgate is produced, and the caller writes dx = dy * gate + dpooled / HW in one pass with cnk_sk_maps_bwd (P = 1,
+ * attn = gate) once the squeeze branch's gradient dpooled is known (layers.SEUnit does). */
 size_t cnk_channel_scale_workspace_bytes(int32_t N, int32_t HW, int32_t C, int dtype);
 int cnk_channel_scale_bwd(const void* dy, const void* x, const float* gate, void* dx, float* dgate, int32_t N,
                           int32_t HW, int32_t C, int dtype, void* ws, size_t ws_bytes, void* stream);
