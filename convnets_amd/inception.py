@@ -27,7 +27,13 @@ class InceptionBlock(nn.Module):                             # src/inceptionnet_
         network.in_channels = ch_conv1x1 + ch_conv3x3 + ch_conv5x5 + pool_proj
 
     def forward(self, x):
-        return torch.cat([self.branch1(x), self.branch2(x), self.branch3(x), self.branch4(x)], dim=1)
+        # x feeds three 1x1 convs (and the pooling branch): the convs' data gradients are summed inside the last
+        # one's dgrad epilogue (ops.GradLink); autograd only adds the pooling branch's gradient to that total
+        from . import ops
+        link = ops.GradLink(3) if (self.training and torch.is_grad_enabled() and x.requires_grad) else None
+        b2 = self.branch2[1](self.branch2[0](x, in_link=link))
+        b3 = self.branch3[1](self.branch3[0](x, in_link=link))
+        return torch.cat([self.branch1(x, in_link=link), b2, b3, self.branch4(x)], dim=1)
 
 
 class InceptionNetV1(MultiClassBaseModel):

@@ -245,7 +245,11 @@ class SKConv(nn.Module):
         self.softmax = nn.Softmax(dim=1)              # kept for the module tree; the math runs in cnk_sk_select_fwd
 
     def forward(self, x):
-        maps = [path(x) for path in self.kernels]
+        # x feeds every path: their data gradients are summed inside the last path's dgrad epilogue (ops.GradLink)
+        # instead of by autograd -- which also lets that epilogue carry the backward reduction of the BN that made x
+        glink = ops.GradLink(self.num_paths) if (self.num_paths > 1 and self.training and torch.is_grad_enabled()
+                                                 and x.requires_grad) else None
+        maps = [path(x, in_link=glink) for path in self.kernels]
         link = ops.SKLink() if torch.is_grad_enabled() and maps[0].requires_grad else None
         features = self.descriptor(ops.SKPoolFn.apply(link, *maps))
         logits = [attention(features) for attention in self.attentions]
