@@ -32,14 +32,22 @@ class ShuffleUnit(nn.Module):                                # src/shufflenet_v1
         self.relu = layers.ReLU(inplace=True)
 
     def forward(self, x):
-        identity = self.avg_pool(x) if self.downsample else x
-        output = self.conv1x1_group_compress(x)
+        if self.downsample:
+            identity = self.avg_pool(x)
+            output = self.conv1x1_group_compress(x)
+            output = ops.ChannelShuffleFn.apply(output, self.groups)
+            output = self.conv1x1_group_expand(self.conv3x3_depthwise(output))
+            return self.relu(torch.cat([identity, output], dim=1))
+        # stride-1 unit: `output + x` and the ReLU run inside the last BN's apply pass, and the two gradients of x
+        # (compress conv, shortcut) are summed inside the compress conv's dgrad epilogue (ops.GradLink) -- unless
+        # that conv takes the fp32 detour (channel counts off the 8-grid), which does not carry a link
+        first = self.conv1x1_group_compress.conv
+        link = ops.GradLink(2) if (self.training and torch.is_grad_enabled() and x.requires_grad
+                                   and not first._f32_detour and hasattr(self.conv1x1_group_compress, 'bn')) else None
+        output = self.conv1x1_group_compress(x, in_link=link)
         output = ops.ChannelShuffleFn.apply(output, self.groups)
         output = self.conv3x3_depthwise(output)
-        output = self.conv1x1_group_expand(output)
-        if self.downsample:
-            return self.relu(torch.cat([identity, output], dim=1))
-        return ops.AddReLUFn.apply(output, identity)
+        return self.conv1x1_group_expand(output, residual=x, relu_after_add=True, res_link=link)
 
 
 class ShuffleNetV1(MultiClassBaseModel):
