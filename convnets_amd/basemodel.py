@@ -314,6 +314,9 @@ class MultiClassBaseModel(nn.Module):
         if not (x.dtype == self.setting.compute_dtype and x.is_contiguous(memory_format=torch.channels_last)):
             x = ops.nchw_to_nhwc(x, self.setting.compute_dtype)     # NCHW fp32 batch -> NHWC compute dtype
         # (else: already prepared on the device by ops.input_pipeline)
+        if not self.__dict__.get('_pools_linked'):
+            layers.link_block_pools(self)                       # conv -> BN -> ReLU -> MaxPool2d: BN inside the pooling pass
+            self.__dict__['_pools_linked'] = True
         x = self.features(x)
         x = torch.flatten(x, start_dim=1).float()               # head runs in fp32
         return self.classifier(x)

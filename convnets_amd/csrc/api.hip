@@ -85,6 +85,7 @@ size_t bn_mask_bytes(int64_t M, int C, int dtype);
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
 int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, const float* ext_partial, int64_t ext_slices, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
+int maxpool_affine_dispatch(const void* x, const float* scale, const float* shift, int relu, void* y, unsigned char* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
 int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
@@ -401,7 +402,8 @@ size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(
 size_t cnk_bn_mask_bytes(int64_t M, int32_t C, int dtype) { return bn_mask_bytes(M, C, dtype); }
 
 int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual, void* y, uint8_t* relu_mask, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* partial, int64_t partial_slices, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
-    CNK_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd, "cnk_bn_fwd_train: null pointer");
+    CNK_CHECK_ARG(x && gamma && beta && save_mean && save_invstd, "cnk_bn_fwd_train: null pointer");
+    CNK_CHECK_ARG(y || (!residual && !relu_mask), "cnk_bn_fwd_train: y == NULL (statistics only) takes no residual / mask");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_train: empty tensor");
     CNK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cnk_bn_fwd_train: running stats must both be given or both NULL");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_fwd_train: workspace too small");
@@ -449,6 +451,14 @@ int cnk_maxpool2d_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N
     CNK_CHECK_ARG(dy && argmax && dx, "cnk_maxpool2d_bwd: null pointer");
     CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && 2 * ph <= kh && 2 * pw <= kw && H + 2 * ph >= kh && W + 2 * pw >= kw, "cnk_maxpool2d_bwd: bad geometry");
     return maxpool_dispatch(true, dy, (void*)argmax, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+}
+
+int cnk_maxpool2d_fwd_bn(const void* x, const float* scale, const float* shift, int relu, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && scale && shift && y && idx, "cnk_maxpool2d_fwd_bn: null pointer");
+    CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && kh * kw <= 255, "cnk_maxpool2d_fwd_bn: bad geometry");
+    CNK_CHECK_ARG(H + 2 * ph >= kh && W + 2 * pw >= kw && 2 * ph <= kh && 2 * pw <= kw, "cnk_maxpool2d_fwd_bn: bad padding");
+    CNK_CHECK_ARG(dtype == CNK_F32 || dtype == CNK_BF16, "cnk_maxpool2d_fwd_bn: bad dtype %d", dtype);
+    return maxpool_affine_dispatch(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
 }
 
 int cnk_relu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {

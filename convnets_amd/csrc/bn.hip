@@ -676,6 +676,7 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, slices, C,
                        M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
     CNK_CHECK_LAUNCH("bn_finalize");
+    if (!y) return 0;                        // statistics only: scale | shift stay at ws[0..C) | ws[C..2C) for the caller
     const dim3 grid(g.slices, g.colgroups);
 #define CNK_BN_APPLY(R, A, W)                                                                              \
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC, R, A, W>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \

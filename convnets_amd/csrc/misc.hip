@@ -33,10 +33,14 @@ struct PoolParams {
     FastDiv fd_cols, fd_wo, fd_ho, fd_w, fd_h;
 };
 
-template <typename T, int VEC>
+// AFFINE: the pooled tensor is act(x * scale[c] + shift[c]) -- a training-mode BatchNorm(+ReLU) applied on the fly (the
+// stems: conv -> BN -> ReLU -> MaxPool2d), each value rounded to T as the stand-alone BN pass would have stored it.
+template <typename T, int VEC, bool AFFINE = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           unsigned char* __restrict__ idx,
-                                                          PoolParams p, int64_t total) {
+                                                          PoolParams p, int64_t total,
+                                                          const float* __restrict__ scale = nullptr,
+                                                          const float* __restrict__ shift = nullptr, int relu = 0) {
     const int cols = p.C / VEC;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -56,6 +60,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 if ((unsigned)w >= (unsigned)p.W) continue;
                 VL<T, VEC> v;
                 v.load(x + ((size_t)(n * p.H + h) * p.W + w) * p.C + vc * VEC);
+                if constexpr (AFFINE) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float a = v.f[k] * scale[vc * VEC + k] + shift[vc * VEC + k];
+                        if (relu) a = a > 0.f ? a : 0.f;
+                        v.f[k] = to_f32(from_f32<T>(a));
+                    }
+                }
                 unsigned char pos = (unsigned char)(r * p.kw + q);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
@@ -429,6 +441,29 @@ static int maxpool_t(bool bwd, const void* a, void* b, void* o, int N, int H, in
     }
     CNK_CHECK_LAUNCH("maxpool");
     return 0;
+}
+
+template <typename T, int VEC>
+static int maxpool_affine_t(const void* x, const float* scale, const float* shift, int relu, void* y, unsigned char* idx,
+                            int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t s) {
+    PoolParams p = make_pool(N, H, W, C, kh, kw, sh, sw, ph, pw, VEC);
+    int64_t total = (int64_t)N * p.Ho * p.Wo * (C / VEC);
+    CNK_CHECK_ARG(total < (1ll << 31), "maxpool: tensor too large");
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T, VEC, true>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, (T*)y, idx, p,
+                       total, scale, shift, relu);
+    CNK_CHECK_LAUNCH("maxpool_affine");
+    return 0;
+}
+
+int maxpool_affine_dispatch(const void* x, const float* scale, const float* shift, int relu, void* y, unsigned char* idx,
+                            int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
+                            hipStream_t s) {
+    if (dtype == CNK_BF16) {
+        if (C % 8 == 0) return maxpool_affine_t<bf16, 8>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+        return maxpool_affine_t<bf16, 1>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    }
+    if (C % 4 == 0) return maxpool_affine_t<float, 4>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    return maxpool_affine_t<float, 1>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
 }
 
 template <typename T, int VEC>

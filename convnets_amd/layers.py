@@ -87,19 +87,27 @@ class BatchNorm2d(nn.BatchNorm2d):
     # model then bumps every layer's num_batches_tracked with ONE kernel per step, not one per layer
     _deferred_counter = None
 
-    def forward(self, x, residual=None, relu=False, partial=None, link=None):
+    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None):
+        """pool: the MaxPool2d module that consumes this layer's output (ConvBlock passes it for the stems, training
+        mode only): BN, ReLU and the pooling then run as one autograd node and the POOLED tensor is returned."""
         if not (self.affine and self.track_running_stats):
             raise NotImplementedError('convnets_amd.BatchNorm2d: affine=True, '
                                       'track_running_stats=True only (the factory default)')
         if self.training:
             if self.momentum is None:
                 raise NotImplementedError('convnets_amd.BatchNorm2d: cumulative momentum (None)')
-            rec = ops.BnRecord() if (torch.is_grad_enabled() and x.requires_grad) else None
-            y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
-                                         self.running_var, float(self.eps), float(self.momentum),
-                                         bool(relu), partial, link, rec)
-            if rec is not None and rec.x is not None:
-                y._cnk_bn = rec
+            if pool is not None:
+                y = ops.BatchNormActMaxPoolFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                                    float(self.eps), float(self.momentum), bool(relu), partial,
+                                                    _pair(pool.kernel_size), _pair(pool.stride), _pair(pool.padding))
+                y._cnk_pooled_by = pool
+            else:
+                rec = ops.BnRecord() if (torch.is_grad_enabled() and x.requires_grad) else None
+                y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
+                                             self.running_var, float(self.eps), float(self.momentum),
+                                             bool(relu), partial, link, rec)
+                if rec is not None and rec.x is not None:
+                    y._cnk_bn = rec
             self._stats_epoch = getattr(self, '_stats_epoch', 0) + 1     # running statistics changed
             if self._deferred_counter is not None:
                 self._deferred_counter[0] += 1        # flushed for all BN layers at once by the model
@@ -126,6 +134,8 @@ class MaxPool2d(nn.MaxPool2d):
             raise NotImplementedError('convnets_amd.MaxPool2d: dilation=1, ceil_mode=False only')
 
     def forward(self, x):
+        if getattr(x, '_cnk_pooled_by', None) is self:      # the ConvBlock in front already pooled (fused stem node)
+            return x
         k = _pair(self.kernel_size)
         s = _pair(self.stride if self.stride is not None else self.kernel_size)
         return ops.MaxPool2dFn.apply(x, k, s, _pair(self.padding))
@@ -271,6 +281,10 @@ class ConvBlock(nn.Sequential):
         if bn is not None:
             if bn.training:      # the conv epilogue also emits the BN statistics partials
                 y, partial = conv(x, want_bn_partial=True, link=in_link)
+                pool = self.__dict__.get('_next_pool')
+                if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
+                    # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
+                    return bn(y, relu=act, partial=partial, pool=pool)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
                           link=res_link)
             if not torch.is_grad_enabled():
@@ -289,6 +303,22 @@ class ConvBlock(nn.Sequential):
                 y = ops.ReLUFn.apply(y)
             return ops.AddReLUFn.apply(y, residual) if relu_after_add else y + residual
         return ops.ReLUFn.apply(y) if act else y
+
+
+def link_block_pools(model):
+    """Marks every ConvBlock (with a BatchNorm) that is immediately followed by a MaxPool2d in an nn.Sequential --
+    the stems of the ResNet-style families, VGG's stage ends, LeNet / AlexNet -- so that its training forward
+    normalises inside the pooling pass (ops.BatchNormActMaxPoolFn).  The modules and their names stay as they
+    are; the pool module sees a tensor its predecessor already pooled and passes it through."""
+    import os
+    if os.environ.get('CNK_FUSE_POOL', '1') == '0':          # A/B switch
+        return
+    for seq in model.modules():
+        if isinstance(seq, nn.Sequential) and not isinstance(seq, ConvBlock):
+            kids = list(seq.children())
+            for a, b in zip(kids, kids[1:]):
+                if isinstance(a, ConvBlock) and isinstance(b, MaxPool2d) and any(isinstance(m, BatchNorm2d) for m in a):
+                    a.__dict__['_next_pool'] = b
 
 
 class Conv2dBlock(ConvBlock):

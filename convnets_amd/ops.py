@@ -621,6 +621,69 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=Non
     return y
 
 
+class BatchNormActMaxPoolFn(torch.autograd.Function):
+    """BatchNorm2d (training) -> [ReLU] -> MaxPool2d as ONE autograd node (the stems: resnet.py:88-89; VGG's stage
+    ends).  Forward: the BN statistics, then a pooling pass that normalises the conv output on the fly
+    (cnk_maxpool2d_fwd_bn) -- the full-size normalised tensor is neither written nor read.  Backward: the regular
+    max-pool backward, then the BN backward with the ReLU mask re-derived from x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, partial, ksize, stride, padding):
+        _require_gpu(x)
+        lib = _lib.load()
+        x = _nhwc(x)
+        N, C, H, W = x.shape
+        M = N * H * W
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        if partial is not None and partial.numel() == 0:
+            partial = None
+        nsl = 0 if partial is None else partial.shape[0]
+        check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), None, None, None, _p(running_mean), _p(running_var),
+                                   _p(save_mean), _p(save_invstd), _p(partial), nsl, M, C, eps, momentum, int(relu),
+                                   _dtype_code(x), _p(ws), ws.numel(), _stream()))
+        Ho = (H + 2 * padding[0] - ksize[0]) // stride[0] + 1
+        Wo = (W + 2 * padding[1] - ksize[1]) // stride[1] + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=CL)
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        scale, shift = ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(ws.data_ptr() + 4 * C)   # left there by the BN call
+        check(lib.cnk_maxpool2d_fwd_bn(_p(x), scale, shift, int(relu), _p(y), _p(idx), N, H, W, C, ksize[0], ksize[1],
+                                       stride[0], stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
+        ctx.save_for_backward(x, idx, gamma, beta, save_mean, save_invstd)
+        ctx.relu, ctx.geom, ctx.params = bool(relu), (ksize, stride, padding), (gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, idx, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        ksize, stride, padding = ctx.geom
+        dy = _nhwc(dy)
+        N, C, H, W = x.shape
+        M = N * H * W
+        da = torch.empty_like(x, memory_format=CL)
+        check(lib.cnk_maxpool2d_bwd(_p(dy), _p(idx), _p(da), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
+                                    padding[0], padding[1], _dtype_code(x), _stream()))
+        dx = torch.empty_like(x, memory_format=CL)
+        pg, pb = ctx.params
+        gg, gb = _arena_grad(pg), _arena_grad(pb)
+        direct = gg is not None and gb is not None
+        if direct:
+            dg_buf, db_buf, dgamma, dbeta = gg, gb, None, None
+        else:
+            dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+            db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        check(lib.cnk_bn_bwd(_p(da), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dx), None,
+                             _p(dg_buf), _p(db_buf), int(direct), None, 0, M, C, int(ctx.relu), _dtype_code(x), _p(ws),
+                             ws.numel(), _stream()))
+        if direct:
+            _grad_written(pg)
+            _grad_written(pb)
+        return (dx, dgamma, dbeta) + (None,) * 9
+
+
 class MaxPool2dFn(torch.autograd.Function):
     """nn.MaxPool2d (basemodel.py:1021)."""
 

@@ -205,6 +205,16 @@ int cnk_maxpool2d_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N
                       int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
                       int32_t ph, int32_t pw, int dtype, void* stream);
 
+/* Forward of a training-mode BatchNorm(+ReLU) and the MaxPool2d that follows it (the stems, resnet.py:88-89) without
+ * the full-size normalised tensor: call cnk_bn_fwd_train with y == NULL (statistics only: save_mean / save_invstd / the
+ * running statistics are produced and the per-channel scale[C] | shift[C], fp32, are left at the START of its
+ * workspace), then this pooling pass, which applies x * scale + shift (+ReLU) to the conv output on the fly, each
+ * value rounded to `dtype` as the BN pass would have stored it.  idx as cnk_maxpool2d_fwd (required).  The backward is
+ * the regular pair: cnk_maxpool2d_bwd, then cnk_bn_bwd with y == NULL and no mask (it re-derives the ReLU mask). */
+int cnk_maxpool2d_fwd_bn(const void* x, const float* scale, const float* shift, int relu, void* y, uint8_t* idx,
+                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                         int32_t ph, int32_t pw, int dtype, void* stream);
+
 /* nn.ReLU (basemodel.py:1012,1065) and the block-level  output += identity; F.relu(output)
  * (resnet.py:151-154,191-194) as stand-alone ops for unfused use. */
 int cnk_relu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
