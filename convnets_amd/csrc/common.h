@@ -116,6 +116,31 @@ struct DgradClass {
     signed char kh[32], kw[32], dh[32], dw[32];
 };
 
+// Ping-pong 3x3 core (conv_pp.hip): arguments of one launch, filled by conv_igemm.hip from its GatherParams.
+struct PPArgs {
+    const void* src;
+    const void* wpk;
+    void* dst;
+    const float* bias;
+    const void* addend;
+    const unsigned char* addend_mask;
+    float* stats;
+    const void* bnf_x;
+    const float* bnf_mean;
+    const float* bnf_invstd;
+    const float* bnf_gamma;
+    const float* bnf_beta;
+    const unsigned char* bnf_mask;
+    float* bnf_partial;
+    int bnf_relu, bnf_tile0, relu;
+    int N, H, W, C, Nout;
+    signed char dh[9], dw[9];
+    double algo_bytes;
+};
+bool pp3x3_ok(int N, int H, int W, int C, int Nout);
+int64_t pp3x3_slices(int N, int H, int W);
+int pp3x3_launch(const PPArgs& a, hipStream_t s);
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int conv_groups(const cnk_conv_desc* d) { return d->groups > 1 ? d->groups : 1; }
 static inline int conv_dil(const cnk_conv_desc* d) { return d->dilation > 1 ? d->dilation : 1; }

@@ -806,6 +806,18 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         if (p.tiles_total == 0) return 0;
         return launch_gather<T, 64, true>(p, s);
     }
+    if (sizeof(T) == 2 && !p.chunked && halo_shape(p) && pp3x3_ok(p.N, p.IH, p.IW, p.C, p.Nout)) {
+        // stride-1 3x3 on the ping-pong core (conv_pp.hip); partials are per 64-row slice there
+        PPArgs a = {};
+        a.src = p.src; a.wpk = p.wpk; a.dst = p.dst; a.bias = p.bias; a.addend = p.addend; a.addend_mask = p.addend_mask;
+        a.stats = p.stats; a.bnf_x = p.bnf_x; a.bnf_mean = p.bnf_mean; a.bnf_invstd = p.bnf_invstd; a.bnf_gamma = p.bnf_gamma;
+        a.bnf_beta = p.bnf_beta; a.bnf_mask = p.bnf_mask; a.bnf_partial = p.bnf_partial; a.bnf_relu = p.bnf_relu;
+        a.bnf_tile0 = p.bnf_tile0; a.relu = p.relu;
+        a.N = p.N; a.H = p.IH; a.W = p.IW; a.C = p.C; a.Nout = p.Nout;
+        for (int t = 0; t < 9; ++t) { a.dh[t] = p.dh[t]; a.dw[t] = p.dw[t]; }
+        a.algo_bytes = gather_bytes(p, sizeof(T));
+        return pp3x3_launch(a, s);
+    }
     bool use128 = !p.chunked && pick_bn128(p.M, p.Nout);
     int bn = use128 ? 128 : 64;
     p.tiles_n = p.Nout / bn;
@@ -862,9 +874,18 @@ bool igemm_on_grid(const cnk_conv_desc* d, int pass) {
     return cred % kstep == 0 && nout % 64 == 0;
 }
 
+// stride-1 "same" 3x3 conv (or its data gradient) that launch_gather_bn hands to the ping-pong core
+static bool pp_desc(const cnk_conv_desc* d, int pass) {
+    if (d->dtype != CNK_BF16 || conv_groups(d) > 1 || conv_dil(d) > 1) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1) return false;
+    const int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout, nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
+    return pp3x3_ok(d->N, d->H, d->W, cred, nout);
+}
+
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
+    if (pp_desc(d, CNK_PASS_FWD)) return pp3x3_slices(d->N, d->H, d->W);
     return ceil_div(d->N * Ho * Wo, BM);
 }
 
@@ -923,6 +944,7 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w]
 // slices of the fused BN-backward partials: one per 128-row tile of every stride-parity class
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     if (d->stride_h * d->stride_w > 16 || d->Cin % (d->dtype == CNK_BF16 ? 8 : 4)) return 0;
+    if (pp_desc(d, CNK_PASS_DGRAD)) return pp3x3_slices(d->N, d->H, d->W);
     DgradClass cls[16];
     int nc = dgrad_classes(d, cls);
     int64_t n = 0;
