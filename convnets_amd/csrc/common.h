@@ -134,11 +134,12 @@ struct PPArgs {
     float* bnf_partial;
     int bnf_relu, bnf_tile0, relu;
     int N, H, W, C, Nout;
+    int dgrad;                 // data-gradient launch (configuration choice, conv_pp.hip pp_pick)
     signed char dh[9], dw[9];
     double algo_bytes;
 };
-bool pp3x3_ok(int N, int H, int W, int C, int Nout);
-int64_t pp3x3_slices(int N, int H, int W);
+bool pp3x3_ok(int N, int H, int W, int C, int Nout, int dgrad);
+int64_t pp3x3_slices(int N, int H, int W, int C, int Nout, int dgrad);
 int pp3x3_launch(const PPArgs& a, hipStream_t s);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -42,6 +42,7 @@ struct GatherParams {
     float* bnf_partial;      // [slices][Nout][2]
     int bnf_relu, bnf_tile0; // tile0: first slice of this launch (stride-parity classes)
     int relu;                // inference epilogue: dst = max(conv + bias [+ addend], 0)
+    int is_dgrad;            // data-gradient launch
     int chunked;             // grouped conv: n-tile t (64 wide) reduces over channel chunk [64t, 64t+64) only
     int Cpad;                // K length of one tap in the weight image (C rounded up to the K step; == C on the grid)
     int N, IH, IW, C;
@@ -806,14 +807,14 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         if (p.tiles_total == 0) return 0;
         return launch_gather<T, 64, true>(p, s);
     }
-    if (sizeof(T) == 2 && !p.chunked && halo_shape(p) && pp3x3_ok(p.N, p.IH, p.IW, p.C, p.Nout)) {
+    if (sizeof(T) == 2 && !p.chunked && halo_shape(p) && pp3x3_ok(p.N, p.IH, p.IW, p.C, p.Nout, p.is_dgrad)) {
         // stride-1 3x3 on the ping-pong core (conv_pp.hip); partials are per 64-row slice there
         PPArgs a = {};
         a.src = p.src; a.wpk = p.wpk; a.dst = p.dst; a.bias = p.bias; a.addend = p.addend; a.addend_mask = p.addend_mask;
         a.stats = p.stats; a.bnf_x = p.bnf_x; a.bnf_mean = p.bnf_mean; a.bnf_invstd = p.bnf_invstd; a.bnf_gamma = p.bnf_gamma;
         a.bnf_beta = p.bnf_beta; a.bnf_mask = p.bnf_mask; a.bnf_partial = p.bnf_partial; a.bnf_relu = p.bnf_relu;
         a.bnf_tile0 = p.bnf_tile0; a.relu = p.relu;
-        a.N = p.N; a.H = p.IH; a.W = p.IW; a.C = p.C; a.Nout = p.Nout;
+        a.N = p.N; a.H = p.IH; a.W = p.IW; a.C = p.C; a.Nout = p.Nout; a.dgrad = p.is_dgrad;
         for (int t = 0; t < 9; ++t) { a.dh[t] = p.dh[t]; a.dw[t] = p.dw[t]; }
         a.algo_bytes = gather_bytes(p, sizeof(T));
         return pp3x3_launch(a, s);
@@ -879,13 +880,13 @@ static bool pp_desc(const cnk_conv_desc* d, int pass) {
     if (d->dtype != CNK_BF16 || conv_groups(d) > 1 || conv_dil(d) > 1) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1) return false;
     const int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout, nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
-    return pp3x3_ok(d->N, d->H, d->W, cred, nout);
+    return pp3x3_ok(d->N, d->H, d->W, cred, nout, pass == CNK_PASS_DGRAD);
 }
 
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
-    if (pp_desc(d, CNK_PASS_FWD)) return pp3x3_slices(d->N, d->H, d->W);
+    if (pp_desc(d, CNK_PASS_FWD)) return pp3x3_slices(d->N, d->H, d->W, d->Cin, d->Cout, 0);
     return ceil_div(d->N * Ho * Wo, BM);
 }
 
@@ -944,7 +945,7 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w]
 // slices of the fused BN-backward partials: one per 128-row tile of every stride-parity class
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     if (d->stride_h * d->stride_w > 16 || d->Cin % (d->dtype == CNK_BF16 ? 8 : 4)) return 0;
-    if (pp_desc(d, CNK_PASS_DGRAD)) return pp3x3_slices(d->N, d->H, d->W);
+    if (pp_desc(d, CNK_PASS_DGRAD)) return pp3x3_slices(d->N, d->H, d->W, d->Cout, d->Cin, 1);
     DgradClass cls[16];
     int nc = dgrad_classes(d, cls);
     int64_t n = 0;
@@ -967,7 +968,7 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
         const DgradClass& k = cls[c];
         GatherParams p = {};
         p.src = dy; p.wpk = (const char*)w_dgrad + woff * esz; p.dst = dx; p.bias = nullptr;
-        p.addend = addend; p.addend_mask = addend_mask; p.chunked = conv_groups(d) > 1;
+        p.addend = addend; p.addend_mask = addend_mask; p.chunked = conv_groups(d) > 1; p.is_dgrad = 1;
         p.N = d->N; p.IH = Ho; p.IW = Wo; p.C = d->Cout;
         p.OH = k.OH; p.OW = k.OW; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
         p.sm_h = 1; p.sm_w = 1;

@@ -1,8 +1,11 @@
-"""Stride-1 3x3 conv forward (with BN statistics partials) and data gradient on the ResNet-50 shapes, cold operands.
-Prints time per launch, TFLOP/s, a SHA-1 of the output bytes and the merged BN statistics, so two builds / settings
-(e.g. CNK_PP3X3=0 vs 1: the r01 halo kernels vs the ping-pong core) can be compared bit for bit.
-    python tools/bench_pp.py [N] [--check]      (--check: also compare against a torch fp32 conv on the GPU)"""
-import ctypes, hashlib, os, sys
+"""Stride-1 3x3 conv forward (with BN statistics partials) and data gradient on the ResNet-50 shapes, cold operands,
+several kernel variants INTERLEAVED in one process (cdna_hip_programming.md 5.4 rule 24):
+    old   the r01 halo kernels (CNK_PP3X3=0)          auto  the ping-pong core, its own configuration choice
+    0..3  the ping-pong core forced to configuration 0..3 where it fits (CNK_PP_CFG, conv_pp.hip pp_pick)
+Prints per variant the median time per launch, TFLOP/s, a SHA-1 of the output bytes and the merged BN statistics.
+    PP_VARIANTS=old,auto PP_SHAPES=0,1,2,3 python tools/bench_pp.py [N] [--check]
+    (--check: also compare against a torch fp32 conv on the GPU)"""
+import ctypes, hashlib, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from convnets_amd import _lib
@@ -17,9 +20,20 @@ CHECK = '--check' in sys.argv
 SHAPES = [(64, 64, 56), (128, 128, 28), (256, 256, 14), (512, 512, 7)]
 if os.environ.get('PP_SHAPES'):
     SHAPES = [SHAPES[int(i)] for i in os.environ['PP_SHAPES'].split(',')]
+VARIANTS = os.environ.get('PP_VARIANTS', 'old,auto').split(',')
+ROUNDS = int(os.environ.get('PP_ROUNDS', '3'))
 P = lambda t: ctypes.c_void_p(t.data_ptr())
-sha = lambda t: hashlib.sha1(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()[:12]
-tot = {'fwd': 0.0, 'dgrad': 0.0}
+sha = lambda t: hashlib.sha1(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()[:10]
+
+
+def select(v):
+    os.environ.pop('CNK_PP_CFG', None)
+    os.environ['CNK_PP3X3'] = '0' if v == 'old' else '1'
+    if v not in ('old', 'auto'):
+        os.environ['CNK_PP_CFG'] = v
+
+
+tot = {v: {'fwd': 0.0, 'dgrad': 0.0} for v in VARIANTS}
 for Cin, Cout, H in SHAPES:
     torch.manual_seed(5)
     per = (N * Cin * H * H + N * Cout * H * H) * 2
@@ -31,47 +45,56 @@ for Cin, Cout, H in SHAPES:
     pk = ops.PackedWeights()
     wf, wd = pk.get(w, desc, True)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
-    part = torch.zeros(max(nsl, 1) * Cout * 3, device='cuda')
-    yo = torch.empty_like(ys[0])
-    dxo = torch.empty_like(xs[0])
-    # correctness artefacts first (fixed operands)
-    assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xs[0]), P(wf), None, P(yo), P(part), None, 0, st) == 0, lib.cnk_last_error()
-    assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[0]), P(wd), P(dxo), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
-    torch.cuda.synchronize()
-    pt = part.view(nsl, Cout, 3).double()
-    n, mean, m2 = pt[:, :, 0], pt[:, :, 1], pt[:, :, 2]
-    tn = n.sum(0)
-    tmean = (n * mean).sum(0) / tn
-    tvar = (m2.sum(0) + (n * (mean - tmean) ** 2).sum(0)) / tn
-    info = 'y %s dx %s  n %d mean[0] %.6e var[0] %.6e varsum %.8e' % (sha(yo), sha(dxo), int(tn[0]), tmean[0], tvar[0], tvar.sum())
-    if CHECK:
-        wb = w.bfloat16().float()
-        yr = torch.nn.functional.conv2d(xs[0].float(), wb, padding=1)
-        dxr = torch.nn.functional.conv_transpose2d(ys[0].float(), wb, padding=1)
-        ey = ((yo.float() - yr).norm() / yr.norm()).item()
-        ed = ((dxo.float() - dxr).norm() / dxr.norm()).item()
-        yb = yo.float()
-        em = ((tmean - yb.mean((0, 2, 3)).double()).abs().max() / yb.abs().mean()).item()
-        ev = ((tvar - yb.var((0, 2, 3), unbiased=False).double()).abs() / tvar).max().item()
-        info += '  relerr y %.2e dx %.2e mean %.2e var %.2e' % (ey, ed, em, ev)
+    part = torch.zeros((N * H * H // 64 + 8) * Cout * 3, device='cuda')
+    yo, dxo = torch.empty_like(ys[0]), torch.empty_like(xs[0])
+    info = {}
+    for v in VARIANTS:
+        select(v)
+        nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+        assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xs[0]), P(wf), None, P(yo), P(part), None, 0, st) == 0, lib.cnk_last_error()
+        assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[0]), P(wd), P(dxo), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+        torch.cuda.synchronize()
+        pt = part[:nsl * Cout * 3].view(nsl, Cout, 3).double()
+        n, mean, m2 = pt[:, :, 0], pt[:, :, 1], pt[:, :, 2]
+        tn = n.sum(0)
+        tmean = (n * mean).sum(0) / tn
+        tvar = (m2.sum(0) + (n * (mean - tmean) ** 2).sum(0)) / tn
+        s = 'y %s dx %s slices %d n %d varsum %.8e' % (sha(yo), sha(dxo), nsl, int(tn[0]), tvar.sum())
+        if CHECK:
+            wb = w.bfloat16().float()
+            yr = torch.nn.functional.conv2d(xs[0].float(), wb, padding=1)
+            dxr = torch.nn.functional.conv_transpose2d(ys[0].float(), wb, padding=1)
+            yb = yo.float()
+            s += '  relerr y %.2e dx %.2e mean %.1e var %.1e' % (
+                ((yb - yr).norm() / yr.norm()).item(), ((dxo.float() - dxr).norm() / dxr.norm()).item(),
+                ((tmean - yb.mean((0, 2, 3)).double()).abs().max() / yb.abs().mean()).item(),
+                ((tvar - yb.var((0, 2, 3), unbiased=False).double()).abs() / tvar).max().item())
+        info[v] = s
     runs = {'fwd': lambda i: lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xs[i % copies]), P(wf), None, P(ys[i % copies]), P(part), None, 0, st),
             'dgrad': lambda i: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[i % copies]), P(wd), P(xs[i % copies]), None, None, None, None, 0, st)}
-    out = []
-    for name, run in runs.items():
-        for i in range(2):
-            assert run(i) == 0, lib.cnk_last_error()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 3 * copies
-        e0.record()
-        for i in range(reps):
-            run(i + 2)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1000 / reps
-        tot[name] += us
-        fl = 2.0 * N * H * H * Cout * Cin * 9
-        out.append('%s %7.1f us %5.0f TF' % (name, us, fl / us / 1e6))
-    print('%4d->%4d @%3d   %s   %s' % (Cin, Cout, H, '   '.join(out), info), flush=True)
-print('sum: fwd %.1f us, dgrad %.1f us' % (tot['fwd'], tot['dgrad']))
+    times = {v: {'fwd': [], 'dgrad': []} for v in VARIANTS}
+    for rnd in range(ROUNDS):
+        for v in VARIANTS:
+            select(v)
+            for name, run in runs.items():
+                for i in range(2):
+                    assert run(i) == 0, lib.cnk_last_error()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 2 * copies
+                e0.record()
+                for i in range(reps):
+                    run(i + 2)
+                e1.record()
+                torch.cuda.synchronize()
+                times[v][name].append(e0.elapsed_time(e1) * 1000 / reps)
+    fl = 2.0 * N * H * H * Cout * Cin * 9
+    for v in VARIANTS:
+        out = []
+        for name in ('fwd', 'dgrad'):
+            us = statistics.median(times[v][name])
+            tot[v][name] += us
+            out.append('%s %6.1f us %5.0f TF' % (name, us, fl / us / 1e6))
+        print('%4d->%4d @%3d %5s  %s   %s' % (Cin, Cout, H, v, '   '.join(out), info[v]), flush=True)
+for v in VARIANTS:
+    print('sum %5s: fwd %.1f us, dgrad %.1f us' % (v, tot[v]['fwd'], tot[v]['dgrad']))
