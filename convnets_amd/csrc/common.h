@@ -138,7 +138,7 @@ struct PPArgs {
     signed char dh[9], dw[9];
     double algo_bytes;
 };
-bool pp3x3_ok(int N, int H, int W, int C, int Nout, int dgrad);
+bool pp3x3_ok(int N, int H, int W, int C, int Nout, int dgrad, int fused);
 int64_t pp3x3_slices(int N, int H, int W, int C, int Nout, int dgrad);
 int pp3x3_launch(const PPArgs& a, hipStream_t s);
 

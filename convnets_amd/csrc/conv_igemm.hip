@@ -807,7 +807,7 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         if (p.tiles_total == 0) return 0;
         return launch_gather<T, 64, true>(p, s);
     }
-    if (sizeof(T) == 2 && !p.chunked && halo_shape(p) && pp3x3_ok(p.N, p.IH, p.IW, p.C, p.Nout, p.is_dgrad)) {
+    if (sizeof(T) == 2 && !p.chunked && halo_shape(p) && pp3x3_ok(p.N, p.IH, p.IW, p.C, p.Nout, p.is_dgrad, p.bnf_x != nullptr)) {
         // stride-1 3x3 on the ping-pong core (conv_pp.hip); partials are per 64-row slice there
         PPArgs a = {};
         a.src = p.src; a.wpk = p.wpk; a.dst = p.dst; a.bias = p.bias; a.addend = p.addend; a.addend_mask = p.addend_mask;
@@ -876,11 +876,12 @@ bool igemm_on_grid(const cnk_conv_desc* d, int pass) {
 }
 
 // stride-1 "same" 3x3 conv (or its data gradient) that launch_gather_bn hands to the ping-pong core
+// (for the data gradient: with the BN backward fused, the case the partial slices are asked for)
 static bool pp_desc(const cnk_conv_desc* d, int pass) {
     if (d->dtype != CNK_BF16 || conv_groups(d) > 1 || conv_dil(d) > 1) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1) return false;
     const int cred = pass == CNK_PASS_FWD ? d->Cin : d->Cout, nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
-    return pp3x3_ok(d->N, d->H, d->W, cred, nout, pass == CNK_PASS_DGRAD);
+    return pp3x3_ok(d->N, d->H, d->W, cred, nout, pass == CNK_PASS_DGRAD, 1);
 }
 
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {

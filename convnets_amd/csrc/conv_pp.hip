@@ -644,7 +644,7 @@ static int pp_env(const char* name, int dflt) {
 // Configuration for a shape (-1: not taken): bf16 3x3 taps within +-1 on an output grid equal to the source grid,
 // channel counts on the 64 grid, a patch that fits the 56 prefetch slots and LDS, tensors below 2 GiB, >= 8 tiles.
 // CNK_PP3X3=0 turns the core off; CNK_PP_CFG=0..3 forces a configuration where it fits (tools/bench_pp.py A/B runs).
-static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad) {
+static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
     const int enabled = pp_env("CNK_PP3X3", 1), forced = pp_env("CNK_PP_CFG", -1);      // read per call: in-process A/B runs
     if (!enabled) return -1;
     if (C % 64 || Nout % 64) return -1;
@@ -656,7 +656,7 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad) {
         if (pp_npg(H, W, g) > 56 || pp_lds_bytes(H, W, g) > 160 * 1024) return false;
         return (M + g.bm - 1) / g.bm * (Nout / g.bn) >= 8;
     };
-    if (forced >= 0 && forced < 4 && fits(forced) && !(dgrad && forced >= 2)) return forced;
+    if (forced >= 0 && forced < 4 && fits(forced) && !(dgrad && forced >= 2)) return forced;      // (bench / test runs only)
     // wide outputs: 256 x 256 tiles while they still give every CU a tile, else 512 x 128, else 256 x 128
     const int order[4] = {3, 2, 0, 1};
     for (int c : order) {
@@ -667,15 +667,23 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad) {
         // the data gradient's full epilogue (addend, fused BN backward) does not fit the registers beside 128
         // accumulators: 64 x 64 wave tiles there
         if ((c == 3 || c == 2) && dgrad) continue;
+        // Measured (tools/bench_pp.py, interleaved with the r01 halo kernels in one process, bs 256): 64 output
+        // channels (9 K steps per tile, epilogue-dominated) 111 vs 104 us forward: stays on the halo kernel.  With
+        // the BN backward fused into the epilogue (every 3x3 data gradient of a training step) this core's
+        // per-wave epilogue stalls both groups, the halo kernel hides its epilogue behind two other workgroups:
+        // 136 vs 114 us at 28x28, 94 vs 92 at 14x14, 76 vs 83 at 7x7 -- taken only when every workgroup has ONE tile.
+        if (c == 1) continue;
+        if (dgrad && fused && tiles > 256) continue;
         return c;
     }
     return -1;
 }
 
-bool pp3x3_ok(int N, int H, int W, int C, int Nout, int dgrad) { return pp_pick(N, H, W, C, Nout, dgrad) >= 0; }
+bool pp3x3_ok(int N, int H, int W, int C, int Nout, int dgrad, int fused) { return pp_pick(N, H, W, C, Nout, dgrad, fused) >= 0; }
 
+// slices of the partials this core writes for the shape (forward: BN statistics; data gradient: fused BN backward), 0: not taken
 int64_t pp3x3_slices(int N, int H, int W, int C, int Nout, int dgrad) {
-    const int c = pp_pick(N, H, W, C, Nout, dgrad);
+    const int c = pp_pick(N, H, W, C, Nout, dgrad, 1);
     if (c < 0) return 0;
     return ((int64_t)N * H * W + PP_GEOM[c].wrows - 1) / PP_GEOM[c].wrows;
 }
@@ -699,7 +707,7 @@ template <class CFG> static int pp_launch_cfg(const PPParams& p, int mode, size_
 }
 
 int pp3x3_launch(const PPArgs& a, hipStream_t s) {
-    const int c = pp_pick(a.N, a.H, a.W, a.C, a.Nout, a.dgrad);
+    const int c = pp_pick(a.N, a.H, a.W, a.C, a.Nout, a.dgrad, a.bnf_x != nullptr);
     CNK_CHECK_ARG(c >= 0, "pp3x3: shape not supported");
     const PPGeom& g = PP_GEOM[c];
     PPParams p = {};

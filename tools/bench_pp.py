@@ -33,7 +33,7 @@ def select(v):
         os.environ['CNK_PP_CFG'] = v
 
 
-tot = {v: {'fwd': 0.0, 'dgrad': 0.0} for v in VARIANTS}
+tot = {v: {'fwd': 0.0, 'dgrad': 0.0, 'dgbn': 0.0} for v in VARIANTS}
 for Cin, Cout, H in SHAPES:
     torch.manual_seed(5)
     per = (N * Cin * H * H + N * Cout * H * H) * 2
@@ -70,9 +70,17 @@ for Cin, Cout, H in SHAPES:
                 ((tmean - yb.mean((0, 2, 3)).double()).abs().max() / yb.abs().mean()).item(),
                 ((tvar - yb.var((0, 2, 3), unbiased=False).double()).abs() / tvar).max().item())
         info[v] = s
+    # the training step's data gradient: fused backward of the producing BN(+ReLU) layer (its input read in the epilogue,
+    # ReLU mask re-derived, per-slice sums written) -- cnk_bn_bwd_fuse
+    mean, invstd = torch.zeros(Cin, device='cuda'), torch.ones(Cin, device='cuda')
+    gamma, beta = torch.ones(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
+    bpart = torch.zeros((N * H * H // 64 + 8) * Cin * 2, device='cuda')
+    bnx = [torch.randn(N, Cin, H, H, device='cuda').bfloat16().contiguous(memory_format=CL) for _ in range(min(copies, 4))]
+    fuses = [_lib.BnBwdFuse(b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, bpart.data_ptr(), 1) for b in bnx]
     runs = {'fwd': lambda i: lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xs[i % copies]), P(wf), None, P(ys[i % copies]), P(part), None, 0, st),
-            'dgrad': lambda i: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[i % copies]), P(wd), P(xs[i % copies]), None, None, None, None, 0, st)}
-    times = {v: {'fwd': [], 'dgrad': []} for v in VARIANTS}
+            'dgrad': lambda i: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[i % copies]), P(wd), P(xs[i % copies]), None, None, None, None, 0, st),
+            'dgbn': lambda i: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[i % copies]), P(wd), P(xs[i % copies]), None, None, ctypes.byref(fuses[i % len(fuses)]), None, 0, st)}
+    times = {v: {'fwd': [], 'dgrad': [], 'dgbn': []} for v in VARIANTS}
     for rnd in range(ROUNDS):
         for v in VARIANTS:
             select(v)
@@ -91,10 +99,10 @@ for Cin, Cout, H in SHAPES:
     fl = 2.0 * N * H * H * Cout * Cin * 9
     for v in VARIANTS:
         out = []
-        for name in ('fwd', 'dgrad'):
+        for name in ('fwd', 'dgrad', 'dgbn'):
             us = statistics.median(times[v][name])
             tot[v][name] += us
             out.append('%s %6.1f us %5.0f TF' % (name, us, fl / us / 1e6))
         print('%4d->%4d @%3d %5s  %s   %s' % (Cin, Cout, H, v, '   '.join(out), info[v]), flush=True)
 for v in VARIANTS:
-    print('sum %5s: fwd %.1f us, dgrad %.1f us' % (v, tot[v]['fwd'], tot[v]['dgrad']))
+    print('sum %5s: fwd %.1f us, dgrad %.1f us, dgrad+BN-backward fusion %.1f us' % (v, tot[v]['fwd'], tot[v]['dgrad'], tot[v]['dgbn']))
