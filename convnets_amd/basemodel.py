@@ -163,6 +163,12 @@ class MultiClassBaseModel(nn.Module):
         """setting.hipgraph: the loop body as one hipGraph launch (convnets_amd/graph.py), one captured graph per
         batch shape (the last, smaller batch of an epoch gets its own)."""
         from .graph import GraphedTrainStep
+        red = getattr(self, 'grad_reducer', None)
+        if red is not None and red.world > 1:
+            # Capture and every re-capture (new batch shape, new learning rate) issue collectives in their warm-up
+            # steps, so they are COLLECTIVE operations every rank must enter together, and the replay of captured RCCL
+            # nodes has only been verified with one rank: multi-rank data parallel training runs the eager step.
+            return self.train_batch(batch)
         x, y = self.setting.device.move(batch)
         steps = self.__dict__.setdefault('_graphed_steps', {})
         key = (tuple(x.shape), x.dtype, tuple(y.shape))

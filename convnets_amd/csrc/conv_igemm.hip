@@ -9,9 +9,13 @@
 //
 // Tile: 128 (m) x BN (n) x 128 bytes of K per step (64 bf16 / 32 fp32 channels of one tap),
 // 256 threads = 4 waves (2 x 2), wave tile 64 x BN/2 from 32x32 MFMA blocks
-// (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for exact fp32).  Global -> registers ->
-// LDS staging, double-buffered LDS, one barrier per K step; LDS rows are 128 B with the 16-byte
-// chunk index XORed by (row>>1)&7 so every ds_read_b128 lane group hits 16 distinct bank slots.
+// (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for exact fp32).  Global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write), ONE LDS buffer and two barriers per K
+// step (35 KiB, 116 VGPRs: four workgroups per CU overlap each other's loads and MFMAs); LDS rows are
+// 128 B with the 16-byte chunk index XORed by (row>>1)&7 -- applied to the DMA SOURCE address, the
+// LDS image is lane-linear -- so every ds_read_b128 lane group hits 16 distinct bank slots.
+// Stride-1 3x3 shapes: igemm_halo3x3*_kernel below (pixel patch loaded once per chunk), and for bf16
+// the ping-pong core of conv_pp.hip where launch_gather_bn's measured dispatch picks it.
 #include <cstdlib>
 
 #include "common.h"

@@ -59,6 +59,10 @@ class GradReducer:
         self._compute_stream = None
         if flat_param is not None and self.world > 1:
             dist.broadcast(flat_param, src=0, group=process_group)      # identical replicas
+            # the arena was overwritten behind autograd: packed weight images / folded inference images built from
+            # the pre-broadcast weights (any forward before attach) must not be reused
+            from . import ops as _ops
+            _ops.bump_weights_epoch()
 
     def _param_ready(self, i):
         """Idempotent per parameter and step: a gradient written in place by a kernel is reported
@@ -136,4 +140,17 @@ def attach(model, bucket_bytes=32 << 20, process_group=None):
         bucket_bytes = int(float(os.environ['CNK_DP_BUCKET_MB']) * (1 << 20))
     model.grad_reducer = GradReducer(opt.params, opt.flat_g, opt.offsets, bucket_bytes,
                                      process_group, flat_param=opt.flat_p)
+    if model.grad_reducer.world > 1:
+        # attaching mid-training is well defined: rank 0's Adam moments, step count and buffers (BN running
+        # statistics) too; from here on the running statistics evolve rank-locally (no SyncBN in the reference)
+        for t in (opt.exp_avg, opt.exp_avg_sq):
+            dist.broadcast(t, src=0, group=process_group)
+        step = torch.tensor([opt.step_count], dtype=torch.int64, device=opt.flat_p.device)
+        dist.broadcast(step, src=0, group=process_group)
+        opt.step_count = int(step.item())
+        for b in model.buffers():
+            dist.broadcast(b, src=0, group=process_group)
+        for m in model.modules():
+            if hasattr(m, '_stats_epoch'):
+                m._stats_epoch += 1
     return model.grad_reducer

@@ -41,8 +41,16 @@ class GraphedTrainStep:
         self.replays = 0
         model.train()
         snap = self._snapshot()
-        for _ in range(warmup):
-            model.train_batch((self.x, self.y))
+        # The warm-up runs on the SAME side stream the capture uses: autograd remembers the stream a parameter's
+        # AccumulateGrad node was created on and synchronises with it in every later backward -- a node left over from
+        # the default stream would make the captured backward touch a stream outside the capture (a hard crash in
+        # capture_end, not a Python error).
+        self.stream = torch.cuda.Stream(device=x.device)
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                model.train_batch((self.x, self.y))
+        torch.cuda.current_stream(x.device).wait_stream(self.stream)
         self._bn_layers = [m for m in model.modules() if hasattr(m, '_stats_epoch')]
         self._restore(snap)
         self._capture()
@@ -80,14 +88,31 @@ class GraphedTrainStep:
         # every eager collective / kernel issued so far has completed, and the capture checks only THIS thread:
         # the RCCL watchdog thread polls the events of eager collectives, a HIP call that a process-wide
         # ("global") capture would reject and abort the process on
+        self._drop_stale_autograd_state()
         torch.cuda.synchronize()
         try:
-            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode='thread_local'):
                 self.loss, self.score = self.model.train_batch((self.x, self.y))
         finally:
             ops.CAPTURE[0] = None
         # capture ran the Python side of one step without executing it
         opt.step_count, ops._dropout_calls[0] = step0, drop0
+
+    def _drop_stale_autograd_state(self):
+        """Nothing of an earlier eager step may survive into the capture: the loss module's references to its last
+        outputs go, parameter gradients that are not views of the arena are detached, and a collection frees graphs
+        kept alive only by cycles.  A caller that still HOLDS a non-detached loss / output of an eager step keeps that
+        step's graph alive; its nodes are not replayed by this capture, so they are harmless as long as they are not
+        run (backward) during it."""
+        import gc
+        cf = getattr(self.model, 'cost_function', None)
+        for name in ('last_logits', 'last_pred'):
+            if cf is not None and hasattr(cf, name):
+                try:
+                    setattr(cf, name, None)
+                except Exception:
+                    pass
+        gc.collect()
 
     def replay(self, batch=None):
         """One training step on `batch` (None: the resident batch again).  Returns (loss, correct) as device

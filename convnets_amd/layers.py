@@ -281,7 +281,7 @@ class ConvBlock(nn.Sequential):
         if bn is not None:
             if bn.training:      # the conv epilogue also emits the BN statistics partials
                 y, partial = conv(x, want_bn_partial=True, link=in_link)
-                pool = self.__dict__.get('_next_pool')
+                pool = self._linked_pool()
                 if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
                     return bn(y, relu=act, partial=partial, pool=pool)
@@ -305,6 +305,28 @@ class ConvBlock(nn.Sequential):
         return ops.ReLUFn.apply(y) if act else y
 
 
+def _conv_block_linked_pool(self):
+    """The MaxPool2d that link_block_pools found behind this block -- re-validated at every call: the marker holds
+    weak references to the parent Sequential and the pool, and is dropped as soon as the pool is no longer the
+    module that follows this block there (child replaced or removed, block deep-copied or reused elsewhere)."""
+    mark = self.__dict__.get('_next_pool')
+    if mark is None:
+        return None
+    parent, pool = mark[0](), mark[1]()
+    if parent is not None and pool is not None:
+        kids = list(parent.children())
+        for a, b in zip(kids, kids[1:]):
+            if a is self:
+                if b is pool:
+                    return pool
+                break
+    del self.__dict__['_next_pool']
+    return None
+
+
+ConvBlock._linked_pool = _conv_block_linked_pool
+
+
 def link_block_pools(model):
     """Marks every ConvBlock (with a BatchNorm) that is immediately followed by a MaxPool2d in an nn.Sequential --
     the stems of the ResNet-style families, VGG's stage ends, LeNet / AlexNet -- so that its training forward
@@ -318,7 +340,7 @@ def link_block_pools(model):
             kids = list(seq.children())
             for a, b in zip(kids, kids[1:]):
                 if isinstance(a, ConvBlock) and isinstance(b, MaxPool2d) and any(isinstance(m, BatchNorm2d) for m in a):
-                    a.__dict__['_next_pool'] = b
+                    a.__dict__['_next_pool'] = (weakref.ref(seq), weakref.ref(b))
 
 
 class Conv2dBlock(ConvBlock):

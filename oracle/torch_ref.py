@@ -332,6 +332,26 @@ def ref_training_step(model, inputs, targets):
     return float(loss.detach()), correct
 
 
+def damp_residual_branches(model, factor):
+    """Scales gamma of the last BatchNorm of every residual branch (resnet.py:130-135 / :169-175), as
+    tests/golden/make_golden.py does on the reference's classes for the well-conditioned fixture `resnet26w`
+    (module names are the reference's, so this works on the oracle's and on the product's models alike)."""
+    with torch.no_grad():
+        for m in model.modules():
+            seq = getattr(m, 'res_bottleneck', None)
+            if seq is None:
+                seq = getattr(m, 'res_block', None)
+            if seq is not None:
+                bn = [c for c in seq[-1].modules() if isinstance(c, nn.BatchNorm2d)][-1]
+                bn.weight.mul_(factor)
+    return model
+
+
+def sample_indices(numel, n):
+    """The element positions tests/golden/make_golden.py:sample() stores of a tensor."""
+    return torch.linspace(0, numel - 1, min(n, numel)).long()
+
+
 def synthetic_batch(batch_size, input_size, num_classes, seed=21):
     """x ~ N(0,1) like the reference's own timing tensor (basemodel.py:646); uniform targets."""
     g = torch.Generator(device='cpu').manual_seed(seed)

@@ -368,11 +368,78 @@ def make_affine():
     print('affine.npz', len(out), 'arrays')
 
 
+def damp_residual_branches(model, factor):
+    """Scales gamma of the LAST BatchNorm of every residual branch (resnet.py:130-135 / :169-175).  A randomly
+    initialised deep BN ResNet is in the chaotic phase: any perturbation of a pre-activation that flips a ReLU mask
+    changes its gradients by ~sqrt(flipped fraction) per layer, so bf16 rounding alone moves whole-model gradients by
+    0.3-0.8 L2 (oracle/bf16_emu.py vs fp32, any input size or batch -- measured 0.72 for ResNet-26 at 64x64, bs 32).
+    Damped branches (a trained network's regime: near-identity blocks) bring that to ~0.1, where a whole-model bf16
+    comparison means something.  Returns the scaled modules."""
+    out = []
+    with torch.no_grad():
+        for m in model.modules():
+            seq = getattr(m, 'res_bottleneck', None) or getattr(m, 'res_block', None)
+            if seq is not None:
+                bn = [c for c in seq[-1].modules() if isinstance(c, nn.BatchNorm2d)][-1]
+                bn.weight.mul_(factor)
+                out.append(bn)
+    return out
+
+
+def make_models2(settings, resnet, vggnet):
+    """Round-2 whole-model traces (models2.npz; models.npz stays byte-identical):
+      resnet26w  -- ResNet-26 bottleneck, 64x64, bs 32, residual branches damped x0.1: the well-conditioned fixture
+                    for the bf16 path (every BN reduces over >= 128 values; dense gradient samples)
+      vgg16r / resnet152r -- the BASELINE configs 3 and 5 architectures (src/vggnet.py:33, src/resnet.py:35) at reduced
+                    input size and batch, one reference step each."""
+    out = meta()
+    cases = [('resnet26w', resnet.ResNet, 26, (3, 64, 64), 32, 0.1, 512),
+             ('vgg16r', vggnet.VGGNet, 16, (3, 32, 32), 8, None, 64),
+             ('resnet152r', resnet.ResNet, 152, (3, 32, 32), 8, None, 32)]
+    for name, cls, kind, in_size, bs, damp, nsamp in cases:
+        s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs, batch_norm=True,
+                              mixed_precision=False, dropout_rate=0, seed=21)
+        torch.manual_seed(21)
+        model = cls(s)
+        if damp is not None:
+            damp_residual_branches(model, damp)
+        model.init_optimizer()
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(bs, *in_size, generator=g)
+        y = torch.randint(0, 10, (bs,), generator=g)
+        model.train()
+        out[f'{name}/x'], out[f'{name}/targets'] = x.numpy(), y.numpy()
+        out[f'{name}/damp'] = np.array(-1.0 if damp is None else damp)
+        out[f'{name}/init_norms'] = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+        model.optimizer.zero_grad()
+        outputs = model(x)
+        loss = model.cost_function(outputs, y)
+        correct = model.score(outputs, y)
+        loss.backward()
+        out[f'{name}/logits'] = outputs.detach().numpy()
+        out[f'{name}/loss'] = np.array(float(loss))
+        out[f'{name}/correct'] = np.array(correct)
+        out[f'{name}/grad_norms'] = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+        out[f'{name}/grad_samples'] = np.stack([np.resize(sample(p.grad, nsamp), nsamp) for p in model.parameters()])
+        model.optimizer.step()
+        out[f'{name}/post_norms'] = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+        out[f'{name}/post_samples'] = np.stack([np.resize(sample(p, nsamp), nsamp) for p in model.parameters()])
+        out[f'{name}/n_params'] = np.array(sum(p.numel() for p in model.parameters()))
+        out[f'{name}/sd_keys'] = np.array(list(model.state_dict().keys()))
+        print(name, 'loss', float(loss), 'params', int(out[f'{name}/n_params']))
+    np.savez_compressed(os.path.join(HERE, 'models2.npz'), **out)
+    print('models2.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     settings, basemodel, resnet, vggnet = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'models2':
+        make_models2(settings, resnet, vggnet)
+        sys.exit(0)
     make_ops(settings, basemodel)
     make_resblocks(settings, resnet)
     make_models(settings, basemodel, resnet, vggnet)
     make_dwblocks(settings, basemodel)
     make_affine()
+    make_models2(settings, resnet, vggnet)

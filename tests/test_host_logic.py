@@ -161,3 +161,33 @@ def test_affine_fixed_coeffs_host_helper_matches_oracle():
         a, sc, sh = rng.uniform(-180, 180), rng.uniform(0.2, 3), rng.uniform(-60, 60)
         m = tf.tv_inverse_affine_matrix([W * 0.5, H * 0.5], a, [0, 0], sc, [sh, 0.0])
         assert ops.affine_fixed_coeffs(a, sc, sh, W, H) == tf.pil_fixed_coeffs_abi_order(m)
+
+
+def test_integration_snippet_matches_header():
+    """INTEGRATION.md section C is the template a maintainer would copy: its ConvDesc must have the size of
+    struct cnk_conv_desc in include/cnk.h, its cnk_conv2d_fwd argtypes the header's parameter count, and the example
+    call must pass that many arguments (a short struct or a shifted stream argument would corrupt a launch silently)."""
+    import ctypes
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = md[md.index("```python\nimport ctypes\nlib = ctypes.CDLL('convnets_amd/libcnk.so')"):]
+    block = block[len('```python\n'):block.index('\n```')]
+    hdr = open(os.path.join(root, 'include', 'cnk.h')).read()
+    struct = hdr[hdr.index('typedef struct cnk_conv_desc'):hdr.index('} cnk_conv_desc;')]
+    n_fields = sum(len(re.sub(r'/\*.*?\*/', '', line).split(';')[0].split(',')) for line in struct.splitlines() if 'int32_t' in line)
+    # the snippet's class definition and argtypes, executed without loading any library
+    ns = {'ctypes': ctypes}
+    cls_src = block[block.index('class ConvDesc'):block.index('# int cnk_conv2d_fwd')]
+    exec(cls_src, ns)
+    from convnets_amd import _lib
+    assert ctypes.sizeof(ns['ConvDesc']) == 4 * n_fields == ctypes.sizeof(_lib.ConvDesc)
+    assert [f[0] for f in ns['ConvDesc']._fields_] == [f[0] for f in _lib.ConvDesc._fields_]
+    proto = re.search(r'int cnk_conv2d_fwd\((.*?)\);', hdr, re.S).group(1)
+    n_params = len(proto.split(','))
+    argtypes = eval(re.search(r'lib\.cnk_conv2d_fwd\.argtypes = (.*)', block).group(1), {'ctypes': ctypes, 'ConvDesc': ns['ConvDesc']})
+    assert len(argtypes) == n_params == len(_lib.SIGNATURES['cnk_conv2d_fwd'][1])
+    call = re.search(r'rc = lib\.cnk_conv2d_fwd\((.*)\)\s*#', block).group(1)
+    assert len(call.split(',')) == n_params
+    ctor = re.search(r'd = ConvDesc\((.*?)\)', block).group(1)
+    assert len(ctor.split(',')) == n_fields
