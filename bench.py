@@ -80,7 +80,12 @@ def cpu_baseline(model_key, dtype_note):
     """The oracle ('port' of the reference's torch-CPU step) timed on the host cores."""
     from oracle import torch_ref as tr
     family, kind, in_size, classes, _ = MODEL_CFG[model_key]
-    threads = min(os.cpu_count() or 1, 16)
+    nproc = os.cpu_count() or 1
+    try:
+        nproc = len(os.sched_getaffinity(0))             # the cores this process may actually use
+    except (AttributeError, OSError):
+        pass
+    threads = nproc                                      # SURVEY 8d: all host cores
     torch.set_num_threads(threads)
     bs = 16
     torch.manual_seed(21)
@@ -96,7 +101,10 @@ def cpu_baseline(model_key, dtype_note):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
+    cfg = torch.__config__.show()
+    build = '; '.join(l.strip(' -') for l in cfg.splitlines() if any(k in l for k in ('oneAPI', 'oneDNN', 'MKL-DNN', 'OpenMP', 'CPU capability')))
     return {'value': round(bs / med, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'nproc': nproc, 'threads': torch.get_num_threads(), 'torch': torch.__version__, 'torch_build': build[:400],
             'sample': '%d fp32 training steps of %s at bs=%d on torch-CPU (oracle/torch_ref.py), median'
                       % (len(times), model_key, bs)}
 
@@ -238,6 +246,21 @@ def main():
             bound, achieved, peak, unit = 'mfma', tflops, peak_tf, 'TFLOP/s'
         else:
             bound, achieved, peak, unit = 'hbm', gbps, PEAK_HBM_GBPS, 'GB/s'
+        # every kernel family against the roofline that binds it (durations: HIP events recorded on the launch stream
+        # around each launch, serial breakdown step = weight gradients on the compute stream, eager)
+        by_kernel = []
+        for kname, (n_k, ms_k, fl_k, by_k) in sorted(ktable.items(), key=lambda kv: -kv[1][1]):
+            if not n_k or ms_k <= 0:
+                continue
+            tf_k, gb_k = fl_k / ms_k / 1e9, by_k / ms_k / 1e6
+            mf = tf_k / peak_tf >= gb_k / PEAK_HBM_GBPS
+            by_kernel.append({'kernel': kname, 'kernel_runs': KERNEL_NOTE[kname], 'bound': 'mfma' if mf else 'hbm',
+                              'achieved': round(tf_k if mf else gb_k, 2), 'peak': peak_tf if mf else PEAK_HBM_GBPS,
+                              'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': round((tf_k / peak_tf) if mf else (gb_k / PEAK_HBM_GBPS), 4),
+                              'launches_per_step': n_k, 'avg_launch_us': round(ms_k / n_k * 1e3, 2), 'step_ms': round(ms_k, 3),
+                              'duration_source': 'HIP events on the launch stream around every launch (cnk_prof_*), serial eager step'})
+        conv_classes = {c: {'tflops': round(table[c][2] / table[c][1] / 1e9, 1), 'frac_of_mfma_peak': round(table[c][2] / table[c][1] / 1e9 / peak_tf, 4),
+                            'calls_per_step': table[c][0], 'step_ms': round(table[c][1], 3)} for c in CONV_CLASSES if table[c][1] > 0}
         out = {
             'metric': 'images/sec training step, ResNet-50 224x224 bs=256/GPU' if args.model == 'resnet50'
                       else 'images/sec training step, %s bs=%d/GPU' % (args.model, bs),
@@ -259,7 +282,14 @@ def main():
                          'launch_durations_from': 'eager steps after the timed region' if graphed is not None else 'the timed region',
                          'serial_step_ms_by_kernel': {k: round(ktable[k][1], 3) for k in ktable},
                          'serial_launches_by_kernel': {k: ktable[k][0] for k in ktable},
-                         'serial_conv_tflops_by_class': {c: round(table[c][2] / table[c][1] / 1e9, 1) for c in CONV_CLASSES if table[c][1] > 0}},
+                         'serial_conv_tflops_by_class': {c: round(table[c][2] / table[c][1] / 1e9, 1) for c in CONV_CLASSES if table[c][1] > 0},
+                         'duration_source': 'HIP events recorded on the launch stream around every launch of the kernel (libcnk cnk_prof_*); '
+                                            + ('eager two-stream steps after the timed hipGraph replays' if graphed is not None else 'the timed eager steps')
+                                            + '; cross-check: profiles/ rocprofv3 --kernel-trace --stats of the same command'},
+            # every timed kernel family against its own roofline, and the conv classes (C-ABI call scopes: the 3x3 MFMA
+            # fraction north_star names is conv3x3_fwd / conv3x3_dgrad here)
+            'roofline_by_kernel': by_kernel,
+            'conv_classes_serial': conv_classes,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model, args.dtype)

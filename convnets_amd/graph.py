@@ -88,13 +88,22 @@ class GraphedTrainStep:
         # every eager collective / kernel issued so far has completed, and the capture checks only THIS thread:
         # the RCCL watchdog thread polls the events of eager collectives, a HIP call that a process-wide
         # ("global") capture would reject and abort the process on
+        import gc
         self._drop_stale_autograd_state()
+        # objects freed by that collection may have been registered convs of other models: bring the weight packer's
+        # device table up to date BEFORE the capture (the upload is a host-to-device copy), and keep the collector off
+        # while capturing so the registered set cannot change under it
+        ops.packer_for(self.x.device).sync_table()
         torch.cuda.synchronize()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode='thread_local'):
                 self.loss, self.score = self.model.train_batch((self.x, self.y))
         finally:
             ops.CAPTURE[0] = None
+            if gc_was_on:
+                gc.enable()
         # capture ran the Python side of one step without executing it
         opt.step_count, ops._dropout_calls[0] = step0, drop0
 

@@ -264,6 +264,19 @@ class WeightPacker:
         self.map_dev = torch.tensor(blocks, dtype=torch.int32).to(dev)
         self.nblocks = len(blocks)
 
+    def sync_table(self):
+        """Rebuilds the device-side job table NOW if the set of registered convs changed (a model was freed, a new one
+        registered).  GraphedTrainStep calls it right before a capture: the rebuild uploads a table from the host,
+        which is not allowed while a stream is capturing."""
+        entries = self.entries
+        if not entries:
+            return
+        key = tuple((pw.weight.data_ptr(), pw.w_fwd.data_ptr(),
+                     0 if pw.w_dgrad is None else pw.w_dgrad.data_ptr()) for pw in entries)
+        if key != self.table_key:
+            self._build(entries)
+            self.table_key = key
+
     def ensure(self):
         """Called by a registered PackedWeights whose images are stale: repack ALL of them."""
         ep = weights_epoch()
