@@ -82,11 +82,23 @@ def cpu_baseline(model_key, dtype_note):
     family, kind, in_size, classes, _ = MODEL_CFG[model_key]
     nproc = os.cpu_count() or 1
     try:
-        nproc = len(os.sched_getaffinity(0))             # the cores this process may actually use
+        nproc = len(os.sched_getaffinity(0))             # the cores this process may be scheduled on
     except (AttributeError, OSError):
         pass
-    threads = nproc                                      # all host cores
+    # ... of which a container may only be granted a share (cgroup v2 cpu.max / v1 cfs quota): more threads than that
+    # share only fight each other (a first run with one thread per visible core did not finish a step in 7 minutes)
+    quota = None
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: None if t.split()[0] == 'max' else float(t.split()[0]) / float(t.split()[1])),
+                        ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            quota = parse(open(path).read().strip())
+            break
+        except Exception:
+            continue
+    granted = nproc if not quota else max(1, min(nproc, int(quota + 0.5)))
+    threads = granted                                    # all host cores this process is granted
     torch.set_num_threads(threads)
+    print('bench: CPU baseline on %d threads (nproc %d, cgroup cpu share %s) ...' % (threads, nproc, quota), file=sys.stderr, flush=True)
     bs = 16
     torch.manual_seed(21)
     m = tr.MODELS[family](tr.RefSettings(kind, in_size, classes, batch_size=bs, dropout_rate=0.5))
@@ -99,12 +111,13 @@ def cpu_baseline(model_key, dtype_note):
         t0 = time.perf_counter()
         tr.ref_training_step(m, x, y)
         times.append(time.perf_counter() - t0)
+        print('bench: CPU step %d: %.2f s' % (len(times), times[-1]), file=sys.stderr, flush=True)
     times.sort()
     med = times[len(times) // 2]
     cfg = torch.__config__.show()
     build = '; '.join(l.strip(' -') for l in cfg.splitlines() if any(k in l for k in ('oneAPI', 'oneDNN', 'MKL-DNN', 'OpenMP', 'CPU capability')))
     return {'value': round(bs / med, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'nproc': nproc, 'threads': torch.get_num_threads(), 'torch': torch.__version__, 'torch_build': build[:400],
+            'nproc': nproc, 'cgroup_cpus': quota, 'threads': torch.get_num_threads(), 'torch': torch.__version__, 'torch_build': build[:400],
             'sample': '%d fp32 training steps of %s at bs=%d on torch-CPU (oracle/torch_ref.py), median'
                       % (len(times), model_key, bs)}
 

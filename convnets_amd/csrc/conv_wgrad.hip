@@ -38,15 +38,19 @@ template <> struct WgCfg<float> {
     static constexpr int PAD = 0;
 };
 
-template <typename T, int BMW, int BNW, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(const WgradParams p) {
+// WM x WN waves (2 x 2: 256 threads, two workgroups per CU; 4 x 2 / 2 x 4: 512 threads, ONE 256x128 / 128x256 tile per
+// CU -- the kernel is bound by the global -> LDS path (rocprofv3 MFMA-busy 21 % with 64 B/clk/CU demanded at full MFMA
+// rate for 128x128 against ~28 B/clk delivered), and a 256x128 tile moves 25 % fewer bytes per flop).
+template <typename T, int BMW, int BNW, int NBUF, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NBUF != 2) ? 3 : 2) void wgrad_mfma_kernel(const WgradParams p) {
+    constexpr int NT = 64 * WM * WN;
     constexpr int PER16 = ElemTraits<T>::PER16;
     constexpr int KP = WgCfg<T>::KP;
     constexpr int ROWA = BMW * (int)sizeof(T) + WgCfg<T>::PAD;
     constexpr int ROWB = BNW * (int)sizeof(T) + WgCfg<T>::PAD;
     constexpr int CPRA = BMW / PER16, CPRB = BNW / PER16;       // 16-B chunks per row
-    constexpr int PASSA = KP * CPRA / 256, PASSB = KP * CPRB / 256;
-    constexpr int TM = BMW / 64, TN = BNW / 64;                // 32x32 blocks per wave
+    constexpr int PASSA = KP * CPRA / NT, PASSB = KP * CPRB / NT;
+    constexpr int TM = BMW / (32 * WM), TN = BNW / (32 * WN);   // 32x32 blocks per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                      // [NBUF][KP][ROWA]
     unsigned char* Bs = smem + NBUF * KP * ROWA;   // [NBUF][KP][ROWB]
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const T* dy = (const T*)p.dy;
     const T* x = (const T*)p.x;
     const int ks0 = split * p.ksteps_per_split;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
         const int m0 = ks * KP;
 #pragma unroll
         for (int i = 0; i < PASSA; ++i) {
-            int idx = tid + 256 * i, r = idx / CPRA, c = idx - r * CPRA;
+            int idx = tid + NT * i, r = idx / CPRA, c = idx - r * CPRA;
             int m = m0 + r;
             u32x4 v = {0, 0, 0, 0};
             // (channel bound: Cout / Cin may be any multiple of one vector; columns past them are zeros)
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
         }
 #pragma unroll
         for (int i = 0; i < PASSB; ++i) {
-            int idx = tid + 256 * i, r = idx / CPRB, c = idx - r * CPRB;
+            int idx = tid + NT * i, r = idx / CPRB, c = idx - r * CPRB;
             int m = m0 + r;
             u32x4 v = {0, 0, 0, 0};
             if (m < p.M && tile_ci * BNW + c * PER16 < p.Cin) {
@@ -112,12 +116,12 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < PASSA; ++i) {
-            int idx = tid + 256 * i, r = idx / CPRA, c = idx - r * CPRA;
+            int idx = tid + NT * i, r = idx / CPRA, c = idx - r * CPRA;
             *(u32x4*)(As + buf * (KP * ROWA) + r * ROWA + c * 16) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < PASSB; ++i) {
-            int idx = tid + 256 * i, r = idx / CPRB, c = idx - r * CPRB;
+            int idx = tid + NT * i, r = idx / CPRB, c = idx - r * CPRB;
             *(u32x4*)(Bs + buf * (KP * ROWB) + r * ROWB + c * 16) = rb[i];
         }
     };
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
                 bf16x8 fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    int col = wm * (BMW / 2) + i * 32 + 16 * (g & 1) + 4 * pp;
+                    int col = wm * (BMW / WM) + i * 32 + 16 * (g & 1) + 4 * pp;
                     const unsigned char* a0 = Ab + (ss * 16 + 8 * h + q) * ROWA + col * 2;
                     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(a0));
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    int col = wn * (BNW / 2) + j * 32 + 16 * (g & 1) + 4 * pp;
+                    int col = wn * (BNW / WN) + j * 32 + 16 * (g & 1) + 4 * pp;
                     const unsigned char* b0 = Bb + (ss * 16 + 8 * h + q) * ROWB + col * 2;
                     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(b0));
@@ -187,11 +191,11 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     fa[i] = *(const float*)(Ab + (ss * 2 + lk) * ROWA +
-                                            (wm * (BMW / 2) + i * 32 + l31) * 4);
+                                            (wm * (BMW / WM) + i * 32 + l31) * 4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     fb[j] = *(const float*)(Bb + (ss * 2 + lk) * ROWB +
-                                            (wn * (BNW / 2) + j * 32 + l31) * 4);
+                                            (wn * (BNW / WN) + j * 32 + l31) * 4);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -213,8 +217,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void wgrad_mfma_kernel(cons
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int co = tile_co * BMW + wm * (BMW / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                int ci = slab_ci0 + wn * (BNW / 2) + j * 32 + l31;
+                int co = tile_co * BMW + wm * (BMW / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int ci = slab_ci0 + wn * (BNW / WN) + j * 32 + l31;
                 if (co < p.Cout && ci < slab_row) slab[((size_t)co * p.ntaps + tap) * slab_row + ci] = acc[i][j][r];
             }
 }
@@ -262,14 +266,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     }
 }
 
-template <typename T, int BMW, int BNW> int launch_wgrad(const WgradParams& p, hipStream_t s) {
+template <typename T, int BMW, int BNW, int WM = 2, int WN = 2> int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int KP = WgCfg<T>::KP;
     size_t lds = 2 * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));   // double-buffered
     int grid = p.splits * p.tiles_co * p.ntaps * p.tiles_ci;
     ProfScope kscope(CNK_KF_WGRAD, s, 2.0 * p.M * p.Cout * (double)(p.diag ? BNW : p.Cin) * p.ntaps,
                      ((double)p.M * p.Cout + (double)p.N * p.H * p.W * p.Cin) * sizeof(T) +
                          (double)p.splits * p.Cout * p.ntaps * (p.diag ? BNW : p.Cin) * sizeof(float));
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2>), dim3(grid), dim3(256), lds, s, p);
+    if (lds > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN>), dim3(grid), dim3(64 * WM * WN), lds, s, p);
     CNK_CHECK_LAUNCH("wgrad_mfma");
     return 0;
 }
@@ -327,12 +338,20 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
     const bool grouped = conv_groups(d) > 1;
     *bmw = (!grouped && d->Cout % 128 == 0) ? 128 : 64;
     *bnw = (!grouped && d->Cin % 128 == 0) ? 128 : 64;
+    // bf16, both channel counts on the 128 grid and one of them on the 256 grid: one 256x128 / 128x256 tile per CU
+    // (CNK_WGRAD_BIG=0: the 128x128 tiles, for in-process A/B runs)
+    int slots = 512;                                         // resident workgroups: 2 per CU (80 KiB LDS each) ...
+    {
+        const char* e = getenv("CNK_WGRAD_BIG");
+        const bool big = !(e && e[0] == '0') && d->dtype == CNK_BF16 && *bmw == 128 && *bnw == 128;
+        if (big && d->Cout % 256 == 0) { *bmw = 256; slots = 256; }            // ... or 1 (112 KiB)
+        else if (big && d->Cin % 256 == 0) { *bnw = 256; slots = 256; }
+    }
     int tiles = grouped ? (d->Cout / 64) * d->kh * d->kw
                         : ceil_div(d->Cout, *bmw) * ceil_div(d->Cin, *bnw) * d->kh * d->kw;
     *ksteps = ceil_div(M, kp);
     // The kernel is resident at 2 workgroups per CU (80 KiB LDS each): 512 slots on 256 CUs.  Fill
     // them exactly once -- tiles*splits just ABOVE a multiple of 512 costs a whole extra round.
-    const int slots = 512;                                   // (256..512 measure the same under the two-stream backward)
     int want = tiles >= slots ? 1 : slots / tiles;
     int max_by_k = *ksteps / 4 > 0 ? *ksteps / 4 : 1;       // at least 4 K steps per split
     int sp = want < max_by_k ? want : max_by_k;
@@ -368,7 +387,9 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     p.fd_wo = make_fastdiv(Wo);
     int rc;
     bool b = d->dtype == CNK_BF16;
-    if (bmw == 128 && bnw == 128) rc = b ? launch_wgrad<bf16, 128, 128>(p, s) : launch_wgrad<float, 128, 128>(p, s);
+    if (bmw == 256) rc = launch_wgrad<bf16, 256, 128, 4, 2>(p, s);
+    else if (bnw == 256) rc = launch_wgrad<bf16, 128, 256, 2, 4>(p, s);
+    else if (bmw == 128 && bnw == 128) rc = b ? launch_wgrad<bf16, 128, 128>(p, s) : launch_wgrad<float, 128, 128>(p, s);
     else if (bmw == 128) rc = b ? launch_wgrad<bf16, 128, 64>(p, s) : launch_wgrad<float, 128, 64>(p, s);
     else if (bnw == 128) rc = b ? launch_wgrad<bf16, 64, 128>(p, s) : launch_wgrad<float, 64, 128>(p, s);
     else rc = b ? launch_wgrad<bf16, 64, 64>(p, s) : launch_wgrad<float, 64, 64>(p, s);

@@ -1,7 +1,7 @@
 """Weight-gradient kernels on the ResNet-50 shapes (bs from argv, default 256), operands COLD (rotating copies larger
-than the Infinity Cache): time per launch (MFMA kernel + slab reduce) and TFLOP/s.  The two columns are the same
-library unless an experimental build reads CNK_WGRAD_DMA (A/B aid; an LDS-DMA ring variant measured 0.99x of the
-register-staged kernel here and was dropped).      python tools/bench_wgrad.py [N]"""
+than the Infinity Cache): time per launch (MFMA kernel + slab reduce) and TFLOP/s.  Two variants interleaved in
+one process: CNK_WGRAD_BIG=0 (128x128 tiles, two workgroups per CU) and =1 (the default: 256x128 / 128x256 tiles, one
+512-thread workgroup per CU, where both channel counts allow).      python tools/bench_wgrad.py [N]"""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,12 +26,15 @@ for Cin, Cout, k, s, p, H in SHAPES:
     xs = [torch.randn(N, Cin, H, H, device='cuda', generator=g).bfloat16().contiguous(memory_format=CL) for _ in range(copies)]
     dys = [torch.randn(N, Cout, Ho, Ho, device='cuda', generator=g).bfloat16().contiguous(memory_format=CL) for _ in range(copies)]
     desc = ops.make_desc(xs[0].shape, (Cout, Cin, k, k), (s, s), (p, p), _lib.CNK_BF16)
-    nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), 2)
+    nws = 0
+    for mode in (0, 1):
+        os.environ['CNK_WGRAD_BIG'] = str(mode)
+        nws = max(nws, lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), 2))
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device='cuda')
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     res, us = {}, {}
-    for mode in (0, 1):
-        os.environ['CNK_WGRAD_DMA'] = str(mode)
+    for mode in (0, 1, 0, 1):
+        os.environ['CNK_WGRAD_BIG'] = str(mode)
         dw = torch.zeros(Cout, Cin, k, k, device='cuda')
         run = lambda i: lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dys[i % copies]), P(xs[i % copies]), P(dw), None, 0, P(ws), nws, st)
         for i in range(2):
@@ -45,14 +48,15 @@ for Cin, Cout, k, s, p, H in SHAPES:
             run(i + 2)
         e1.record()
         torch.cuda.synchronize()
-        us[mode] = e0.elapsed_time(e1) * 1000 / reps
+        us[mode] = min(us.get(mode, 1e9), e0.elapsed_time(e1) * 1000 / reps)
         run(0)
         torch.cuda.synchronize()
         res[mode] = dw.clone()
-        tot[mode] += us[mode]
     fl = 2.0 * N * Ho * Ho * Cout * Cin * k * k
+    tot[0] += us[0]
+    tot[1] += us[1]
     diff = (res[0] - res[1]).abs().max().item()
     ref = res[0].abs().max().item()
-    print('%4d->%4d k%d s%d @%3d   old %7.1f us %5.0f TF   dma %7.1f us %5.0f TF   maxdiff %.3g (max %.3g)' % (
+    print('%4d->%4d k%d s%d @%3d   128x128 %7.1f us %5.0f TF   big tile %7.1f us %5.0f TF   maxdiff %.3g (max %.3g)' % (
         Cin, Cout, k, s, H, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, diff, ref), flush=True)
-print('sum: old %.1f us, dma %.1f us' % (tot[0], tot[1]))
+print('sum: 128x128 %.1f us, big tile %.1f us' % (tot[0], tot[1]))
