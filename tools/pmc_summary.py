@@ -15,7 +15,8 @@ def short(name):
         tail = name[m.end() - 1:]
         variant = re.sub(r'[^0-9A-Za-z]+', '_', tail[:28])
         return m.group(1) + '<' + variant.strip('_') + '>'
-    return re.split(r'[(<]', name)[0].strip()[:60]
+    name = re.sub(r'^void ', '', name)
+    return re.sub(r'\((?:anonymous namespace)::[A-Za-z]*Params\)|\(.*$', '', name).strip()[:60]
 
 
 def load_counter(d, cname):
