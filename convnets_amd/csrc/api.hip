@@ -52,6 +52,9 @@ int grad_clip_norm(float* g, int64_t n, float max_norm, float* norm_out, float* 
 int grad_clip_value(float* g, int64_t n, float c, hipStream_t s);
 int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
 bool wgrad_mfma_supported(const cnk_conv_desc* d);
+bool wgrad3x3_supported(const cnk_conv_desc* d);
+size_t wgrad3x3_workspace(const cnk_conv_desc* d);
+int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
 int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int direct_fwd(const cnk_conv_desc* d, const void* x, const void* w_t, const float* bias, void* y, hipStream_t s);
@@ -213,9 +216,13 @@ size_t cnk_conv2d_workspace_bytes(const cnk_conv_desc* d, int pass) {
     if (pass != CNK_PASS_WGRAD) return 0;
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
+    // (the 3x3 all-taps kernel and the one-tap kernel may both serve a shape -- CNK_WGRAD3 switches at run time for A/B
+    // runs -- so the workspace covers whichever asks for more)
+    size_t a3 = wgrad3x3_supported(d) ? wgrad3x3_workspace(d) : 0;
     size_t a = wgrad_mfma_supported(d) ? wgrad_mfma_workspace(d)
                : rowpatch_supported(d) ? rowpatch_wgrad_workspace(d)
                : smallc_supported(d) ? smallc_wgrad_workspace(d) : direct_wgrad_workspace(d);
+    if (a3 > a) a = a3;
     a = (a + 255) & ~(size_t)255;
     return a + colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout);
 }
@@ -374,7 +381,10 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
     ProfScope ps(conv_cls(d, 2), S(stream), fl, by);
     int rc;
     size_t a;
-    if (wgrad_mfma_supported(d)) {
+    if (wgrad3x3_supported(d)) {
+        a = wgrad3x3_workspace(d);
+        rc = wgrad3x3(d, dy, x, dw, accumulate, workspace, a, S(stream));
+    } else if (wgrad_mfma_supported(d)) {
         a = wgrad_mfma_workspace(d);
         rc = wgrad_mfma(d, dy, x, dw, accumulate, workspace, a, S(stream));
     } else if (rowpatch_supported(d)) {

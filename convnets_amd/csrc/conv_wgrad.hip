@@ -266,6 +266,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     }
 }
 
+// The same sum for the slab order [co][t][ci] with Cin % 4 == 0 (every MFMA weight-gradient kernel): 16-byte loads of FOUR
+// consecutive input channels (a wave instruction reads whole 16-byte vectors instead of single floats of four slabs), four
+// slabs in flight per lane, fixed summation order -- bitwise reproducible.
+// G lanes share one 4-channel group when the gradient is small and the slabs many (64 x 64 x 9 weights from 100+ slabs: one
+// thread per group would be 36 workgroups walking 100 dependent steps): lane q sums slabs q, q+G, ... and the G partial sums
+// are combined by a fixed xor-shuffle tree.
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
+                                                            size_t slab_stride, int Cout, int Cin, int ntaps, int accumulate) {
+    const int c4 = Cin >> 2;
+    const size_t total = (size_t)Cout * ntaps * c4;
+    const size_t total_r = (total + 63) / 64 * 64;                        // whole waves stay converged for the shuffles
+    const int q = threadIdx.x % G;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / G; i < total_r; i += ((size_t)gridDim.x * blockDim.x) / G) {
+        const bool live = i < total;
+        const size_t ii = live ? i : 0;
+        const int cq = (int)(ii % c4);
+        const size_t r = ii / c4;
+        const int t = (int)(r % ntaps), co = (int)(r / ntaps);
+        const float* sp = slab + ii * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        int s = q;
+        for (; s + 3 * G < splits; s += 4 * G) {
+            const f32x4 v0 = *(const f32x4*)(sp + (size_t)s * slab_stride);
+            const f32x4 v1 = *(const f32x4*)(sp + (size_t)(s + G) * slab_stride);
+            const f32x4 v2 = *(const f32x4*)(sp + (size_t)(s + 2 * G) * slab_stride);
+            const f32x4 v3 = *(const f32x4*)(sp + (size_t)(s + 3 * G) * slab_stride);
+            a = a + v0;
+            a = a + v1;
+            a = a + v2;
+            a = a + v3;
+        }
+        for (; s < splits; s += G) a = a + *(const f32x4*)(sp + (size_t)s * slab_stride);
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += __shfl_xor(a[j], m, 64);
+        if (q == 0 && live) {
+            float* o = dw + ((size_t)co * Cin + cq * 4) * ntaps + t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)j * ntaps] = accumulate ? o[(size_t)j * ntaps] + a[j] : a[j];
+        }
+    }
+}
+
 template <typename T, int BMW, int BNW, int WM = 2, int WN = 2> int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int KP = WgCfg<T>::KP;
     size_t lds = 2 * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));   // double-buffered
@@ -291,6 +336,21 @@ int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_st
                         int Cin, int ntaps, size_t s_co, size_t s_t, size_t s_ci, int inner_is_ci,
                         int accumulate, hipStream_t s) {
     size_t total = (size_t)Cout * Cin * ntaps;
+    if (inner_is_ci && Cin % 4 == 0 && s_ci == 1 && s_t == (size_t)Cin && s_co == (size_t)ntaps * Cin && slab_stride % 4 == 0) {
+        // lanes per 4-channel group: enough threads to fill the chip (>= ~256 k), never more lanes than slabs
+        const size_t groups = total / 4;
+        int G = 1;
+        while (G < 16 && groups * G < 262144 && 2 * G <= splits) G <<= 1;
+        int grid4 = (int)((groups * G + 255) / 256);
+        if (grid4 > 4096) grid4 = 4096;
+        if (G == 1) hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3(grid4), dim3(256), 0, s, slab, dw, splits, slab_stride, Cout, Cin, ntaps, accumulate);
+        else if (G == 2) hipLaunchKernelGGL(wgrad_reduce4_kernel<2>, dim3(grid4), dim3(256), 0, s, slab, dw, splits, slab_stride, Cout, Cin, ntaps, accumulate);
+        else if (G == 4) hipLaunchKernelGGL(wgrad_reduce4_kernel<4>, dim3(grid4), dim3(256), 0, s, slab, dw, splits, slab_stride, Cout, Cin, ntaps, accumulate);
+        else if (G == 8) hipLaunchKernelGGL(wgrad_reduce4_kernel<8>, dim3(grid4), dim3(256), 0, s, slab, dw, splits, slab_stride, Cout, Cin, ntaps, accumulate);
+        else hipLaunchKernelGGL(wgrad_reduce4_kernel<16>, dim3(grid4), dim3(256), 0, s, slab, dw, splits, slab_stride, Cout, Cin, ntaps, accumulate);
+        CNK_CHECK_LAUNCH("wgrad_reduce4");
+        return 0;
+    }
     int grid = (int)((total * 4 + 255) / 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, dw, splits,

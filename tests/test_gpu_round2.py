@@ -351,3 +351,37 @@ def test_pool_fusion_marker_follows_module_surgery():
     inp = torch.randn(4, blk[0].in_channels, 16, 16, device='cuda').contiguous(memory_format=CL)
     out = blk(inp)
     assert out.shape[-1] == 16                       # not pooled
+
+
+@pytest.mark.parametrize('Cin,Cout,k,H', [(128, 128, 3, 28), (64, 64, 3, 56), (256, 512, 1, 14), (192, 128, 3, 6)])
+def test_wgrad_bitwise_reproducible_and_vs_fp64(Cin, Cout, k, H):
+    """Weight gradients (the all-taps 3x3 kernel of conv_wgrad3.hip, the one-tap split-K kernel, both through the fixed-order
+    slab sum): two launches on the same operands agree bit for bit, and the result matches torch-CPU in fp64."""
+    import ctypes
+    import torch.nn.functional as F
+    from convnets_amd import _lib, ops
+    lib = _lib.load()
+    N = 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    dy = torch.randn(N, Cout, H, H, generator=g)
+    xb = x.cuda().bfloat16().contiguous(memory_format=CL)
+    dyb = dy.cuda().bfloat16().contiguous(memory_format=CL)
+    desc = ops.make_desc(xb.shape, (Cout, Cin, k, k), (1, 1), (k // 2, k // 2), _lib.CNK_BF16)
+    nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), 2)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device='cuda')
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cout, Cin, k, k), 7.0, device='cuda')          # overwritten (accumulate = 0)
+        assert lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dyb), P(xb), P(dw), None, 0, P(ws), nws, st) == 0, lib.cnk_last_error()
+        torch.cuda.synchronize()
+        outs.append(dw.clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.grad.conv2d_weight(xb.double().cpu(), (Cout, Cin, k, k), dyb.double().cpu(), padding=k // 2)
+    assert rel_l2(host(outs[0]), ref.numpy()) < 2e-6
+    acc = torch.ones(Cout, Cin, k, k, device='cuda')
+    assert lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dyb), P(xb), P(acc), None, 1, P(ws), nws, st) == 0
+    torch.cuda.synchronize()
+    assert rel_l2(host(acc), ref.numpy() + 1.0) < 2e-6

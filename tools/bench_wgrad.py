@@ -1,7 +1,7 @@
 """Weight-gradient kernels on the ResNet-50 shapes (bs from argv, default 256), operands COLD (rotating copies larger
 than the Infinity Cache): time per launch (MFMA kernel + slab reduce) and TFLOP/s.  Two variants interleaved in
-one process: CNK_WGRAD_BIG=0 (128x128 tiles, two workgroups per CU) and =1 (the default: 256x128 / 128x256 tiles, one
-512-thread workgroup per CU, where both channel counts allow).      python tools/bench_wgrad.py [N]"""
+one process, selected by BENCH_WGRAD_VAR (default CNK_WGRAD3: 0 = the one-tap-per-workgroup kernel, 1 = the 3x3 all-taps kernel
+where it applies; CNK_WGRAD_BIG: 128x128 tiles vs 256x128 / 128x256 on one 512-thread workgroup).  python tools/bench_wgrad.py [N]"""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,6 +15,7 @@ SHAPES = [(64, 64, 3, 1, 1, 56), (128, 128, 3, 1, 1, 28), (256, 256, 3, 1, 1, 14
           (256, 1024, 1, 1, 0, 14), (1024, 256, 1, 1, 0, 14), (512, 2048, 1, 1, 0, 7), (2048, 512, 1, 1, 0, 7),
           (256, 512, 1, 2, 0, 56), (1024, 2048, 1, 2, 0, 14)]
 P = lambda t: ctypes.c_void_p(t.data_ptr())
+VAR = os.environ.get('BENCH_WGRAD_VAR', 'CNK_WGRAD3')
 tot = {0: 0.0, 1: 0.0}
 for Cin, Cout, k, s, p, H in SHAPES:
     g = torch.Generator(device='cuda').manual_seed(Cin + Cout + k + H)
@@ -28,13 +29,13 @@ for Cin, Cout, k, s, p, H in SHAPES:
     desc = ops.make_desc(xs[0].shape, (Cout, Cin, k, k), (s, s), (p, p), _lib.CNK_BF16)
     nws = 0
     for mode in (0, 1):
-        os.environ['CNK_WGRAD_BIG'] = str(mode)
+        os.environ[VAR] = str(mode)
         nws = max(nws, lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), 2))
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device='cuda')
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     res, us = {}, {}
     for mode in (0, 1, 0, 1):
-        os.environ['CNK_WGRAD_BIG'] = str(mode)
+        os.environ[VAR] = str(mode)
         dw = torch.zeros(Cout, Cin, k, k, device='cuda')
         run = lambda i: lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dys[i % copies]), P(xs[i % copies]), P(dw), None, 0, P(ws), nws, st)
         for i in range(2):
@@ -57,6 +58,8 @@ for Cin, Cout, k, s, p, H in SHAPES:
     tot[1] += us[1]
     diff = (res[0] - res[1]).abs().max().item()
     ref = res[0].abs().max().item()
-    print('%4d->%4d k%d s%d @%3d   128x128 %7.1f us %5.0f TF   big tile %7.1f us %5.0f TF   maxdiff %.3g (max %.3g)' % (
-        Cin, Cout, k, s, H, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, diff, ref), flush=True)
-print('sum: 128x128 %.1f us, big tile %.1f us' % (tot[0], tot[1]))
+    ref = torch.nn.grad.conv2d_weight(xs[0].float(), (Cout, Cin, k, k), dys[0].float(), stride=s, padding=p)
+    e0_, e1_ = [float((res[m] - ref).norm() / ref.norm()) for m in (0, 1)]
+    print('%4d->%4d k%d s%d @%3d   %s=0 %7.1f us %5.0f TF   =1 %7.1f us %5.0f TF   rel err vs torch fp32 %.2e / %.2e' % (
+        Cin, Cout, k, s, H, VAR, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, e0_, e1_), flush=True)
+print('sum: %s=0 %.1f us, =1 %.1f us' % (VAR, tot[0], tot[1]))
