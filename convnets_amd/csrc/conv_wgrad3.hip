@@ -25,6 +25,10 @@
 
 #include "common.h"
 
+#ifndef W3_ABL
+#define W3_ABL 0      // debug builds only (tools/ablate_w3.sh): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMA, 8 no slab store
+#endif
+
 namespace {
 
 constexpr int W3_RING = 512;                       // padded rows per x ring (two rings: input channels 0-31, 32-63)
@@ -70,7 +74,11 @@ __device__ __forceinline__ void w3_dma16(const void* g, uint32_t lds_addr) {
 // transposing LDS read of one half fragment (4 x bf16 per lane) and the wait that retires it (form (ii) of
 // cdna_hip_programming.md 5.7 item 1: the wait names the registers "+v", so no consumer is scheduled above it)
 __device__ __forceinline__ void w3_tr_read(u32x2& d, uint32_t addr) {
+#if (W3_ABL & 2)
+    asm volatile("" : "+v"(d) : "v"(addr));
+#else
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(addr));
+#endif
 }
 template <int N> __device__ __forceinline__ void w3_wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
@@ -192,19 +200,13 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW == 8 ? 2 : 2) void wgrad3x3_kernel
 
         for (int ks = ks0; ks < ks1; ++ks) {
             if (ks > ks0) {
-                W3_WAIT_VM(CFG::NPW);                        // everything but the previous step's own pieces has landed
+                W3_WAIT_VM((W3_ABL & 1) ? 0 : CFG::NPW);                        // everything but the previous step's own pieces has landed
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // ... and this wave's pixel-map writes
                 __builtin_amdgcn_s_barrier();
             }
-            // window and dy of step ks+2; pixel map of step ks+1
-            {
-                const bool more = ks + 2 < ks1;
-                const bool xlive = more && xl < need(ks + 2);
-                issue_x(xl, xlive);
-                if (xlive) xl += CFG::XROWS;
-                issue_dy(ks + 2, (ks + 2) % 3, more);
-                if (ks + 1 < ks1) fill_map(ks + 1);
-            }
+            // pixel map of step ks+1 (the window and dy of step ks+2 are issued further down, behind the first k-step's
+            // MFMAs: their address arithmetic then hides under the matrix pipe instead of delaying the step's first reads)
+            if (ks + 1 < ks1) fill_map(ks + 1);
             // this step's padded rows: 2*SS table reads per lane
             uint32_t arow[SS][2];
 #pragma unroll
@@ -217,33 +219,70 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW == 8 ? 2 : 2) void wgrad3x3_kernel
 #pragma unroll
             for (int ss = 0; ss < SS; ++ss) asm volatile("" : "+v"(arow[ss][0]), "+v"(arow[ss][1]));
             const uint32_t a_st = a_lane + (ks % 3) * CFG::DY_STAGE;
-            // per k-step: the dy fragment and ALL nine x fragments are requested before the first MFMA -- as inline asm,
-            // hipcc otherwise sinks every read next to its MFMA into one reused register pair and pays the LDS round trip
-            // nine times (measured: 2 reads, s_waitcnt lgkmcnt(0), 1 MFMA, ...).  LDS returns in order: before MFMA t the
-            // 4 + 2t oldest of the 20 reads must be back, i.e. 16 - 2t may stay outstanding (the counter holds 15).
+            // Fragment reads as inline asm (hipcc otherwise sinks every read next to its MFMA into one reused register
+            // pair and pays the LDS round trip nine times: measured 2 reads, s_waitcnt lgkmcnt(0), 1 MFMA, ...), ROLLING one
+            // k-step ahead through two register sets: the reads of tap t of k-step ss+1 are issued right before the MFMA of
+            // tap t of k-step ss.  LDS returns in order and 20 reads are younger than the pair an MFMA consumes, so
+            // `lgkmcnt(15)` (the counter's maximum) retires it; the last k-step drains with counted waits.
+            u32x2 fa[2][2], fb[2][9][2];
+#if (W3_ABL & 2)
+            for (int a_ = 0; a_ < 2; ++a_) { fa[a_][0] = fa[a_][1] = u32x2{0x3f803f80u, 0x3f803f80u}; for (int t_ = 0; t_ < 9; ++t_) fb[a_][t_][0] = fb[a_][t_][1] = u32x2{0x3f803f80u, 0x3f803f80u}; }
+#endif
+            auto reads_a = [&](int ss, int set) {
+                w3_tr_read(fa[set][0], a_st + ss * 16 * 64);
+                w3_tr_read(fa[set][1], a_st + ss * 16 * 64 + 4 * 64);
+            };
+            auto reads_b = [&](int ss, int set, int t) {
+                w3_tr_read(fb[set][t][0], ((arow[ss][0] + offs[t]) & (W3_RINGB - 1)) | ring_hi);
+                w3_tr_read(fb[set][t][1], ((arow[ss][1] + offs[t]) & (W3_RINGB - 1)) | ring_hi);
+            };
+            reads_a(0, 0);
 #pragma unroll
-            for (int ss = 0; ss < SS; ++ss) {
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                u32x2 alo, ahi, blo[9], bhi[9];
-                w3_tr_read(alo, a_st + ss * 16 * 64);
-                w3_tr_read(ahi, a_st + ss * 16 * 64 + 4 * 64);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    w3_tr_read(blo[t], ((arow[ss][0] + offs[t]) & (W3_RINGB - 1)) | ring_hi);
-                    w3_tr_read(bhi[t], ((arow[ss][1] + offs[t]) & (W3_RINGB - 1)) | ring_hi);
-                }
-#define W3_STEP(T, NLEFT)                                                                                              \
+            for (int t = 0; t < 9; ++t) reads_b(0, 0, t);
+#define W3_MMA(SET, T, NLEFT)                                                                                          \
     {                                                                                                                  \
-        w3_wait_lgkm2<NLEFT>(blo[T], bhi[T]);                                                                          \
-        const u32x4 b4 = {blo[T][0], blo[T][1], bhi[T][0], bhi[T][1]};                                                 \
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, b4), acc[T], 0, 0, 0); \
+        if ((T) == 0) w3_wait_lgkm<NLEFT>(fa[SET][0], fa[SET][1], fb[SET][T][0], fb[SET][T][1]);                       \
+        else w3_wait_lgkm2<NLEFT>(fb[SET][T][0], fb[SET][T][1]);                                                       \
+        const u32x4 a4 = {fa[SET][0][0], fa[SET][0][1], fa[SET][1][0], fa[SET][1][1]};                                 \
+        const u32x4 b4 = {fb[SET][T][0][0], fb[SET][T][0][1], fb[SET][T][1][0], fb[SET][T][1][1]};                     \
+        if (W3_ABL & 4) asm volatile("" ::"v"(a4), "v"(b4));                                                           \
+        else acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4), __builtin_bit_cast(bf16x8, b4), acc[T], 0, 0, 0); \
     }
-                w3_wait_lgkm<15>(alo, ahi, blo[0], bhi[0]);
-                const u32x4 a4 = {alo[0], alo[1], ahi[0], ahi[1]};
-                W3_STEP(0, 15) W3_STEP(1, 14) W3_STEP(2, 12) W3_STEP(3, 10) W3_STEP(4, 8)
-                W3_STEP(5, 6) W3_STEP(6, 4) W3_STEP(7, 2) W3_STEP(8, 0)
-#undef W3_STEP
+#define W3_PIPE(SS, SET)                                                                                               \
+    reads_a((SS) + 1, (SET) ^ 1);                                                                                      \
+    reads_b((SS) + 1, (SET) ^ 1, 0); W3_MMA(SET, 0, 15) reads_b((SS) + 1, (SET) ^ 1, 1); W3_MMA(SET, 1, 15)           \
+    reads_b((SS) + 1, (SET) ^ 1, 2); W3_MMA(SET, 2, 15) reads_b((SS) + 1, (SET) ^ 1, 3); W3_MMA(SET, 3, 15)           \
+    reads_b((SS) + 1, (SET) ^ 1, 4); W3_MMA(SET, 4, 15) reads_b((SS) + 1, (SET) ^ 1, 5); W3_MMA(SET, 5, 15)           \
+    reads_b((SS) + 1, (SET) ^ 1, 6); W3_MMA(SET, 6, 15) reads_b((SS) + 1, (SET) ^ 1, 7); W3_MMA(SET, 7, 15)           \
+    reads_b((SS) + 1, (SET) ^ 1, 8); W3_MMA(SET, 8, 15)
+#define W3_LAST(SET)                                                                                                   \
+    W3_MMA(SET, 0, 15) W3_MMA(SET, 1, 14) W3_MMA(SET, 2, 12) W3_MMA(SET, 3, 10) W3_MMA(SET, 4, 8)                      \
+    W3_MMA(SET, 5, 6) W3_MMA(SET, 6, 4) W3_MMA(SET, 7, 2) W3_MMA(SET, 8, 0)
+#define W3_ISSUE                                                                                                       \
+    {                                                                                                                  \
+        const bool more = ks + 2 < ks1;                                                                                \
+        const bool xlive = more && xl < need(ks + 2);                                                                  \
+        if (!(W3_ABL & 1)) {                                                                                           \
+            issue_x(xl, xlive);                                                                                        \
+            issue_dy(ks + 2, (ks + 2) % 3, more);                                                                      \
+        }                                                                                                              \
+        if (xlive) xl += CFG::XROWS;                                                                                   \
+    }
+            if constexpr (SS == 4) {
+                W3_PIPE(0, 0)
+                W3_ISSUE
+                W3_PIPE(1, 1)
+                W3_PIPE(2, 0)
+                W3_LAST(1)
+            } else {
+                W3_PIPE(0, 0)
+                W3_ISSUE
+                W3_LAST(1)
             }
+#undef W3_ISSUE
+#undef W3_PIPE
+#undef W3_LAST
+#undef W3_MMA
         }
         W3_WAIT_VM(0);                                       // the trailing (dummy) pieces must not outlive the workgroup's LDS
     }
@@ -257,7 +296,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW == 8 ? 2 : 2) void wgrad3x3_kernel
         for (int r = 0; r < 16; ++r) {
             const int co = tile_co * CFG::TCO + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int ci = tile_ci * 64 + wn * 32 + l31;
-            slab[((size_t)co * 9 + t) * p.Cin + ci] = acc[t][r];
+            if (!(W3_ABL & 8) || acc[t][r] == 12345.f) slab[((size_t)co * 9 + t) * p.Cin + ci] = acc[t][r];
         }
 }
 

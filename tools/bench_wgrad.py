@@ -5,7 +5,10 @@ where it applies; CNK_WGRAD_BIG: 128x128 tiles vs 256x128 / 128x256 on one 512-t
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from convnets_amd import _lib, ops
+from convnets_amd import _lib
+if os.environ.get('CNK_LIB_OVERRIDE'):
+    _lib.LIB_PATH = os.environ['CNK_LIB_OVERRIDE']      # ablated debug build (tools/ablate_w3.sh)
+from convnets_amd import ops
 CL = torch.channels_last
 lib = _lib.load()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -14,6 +17,8 @@ SHAPES = [(64, 64, 3, 1, 1, 56), (128, 128, 3, 1, 1, 28), (256, 256, 3, 1, 1, 14
           (64, 256, 1, 1, 0, 56), (256, 64, 1, 1, 0, 56), (256, 128, 1, 1, 0, 56), (128, 512, 1, 1, 0, 28), (512, 128, 1, 1, 0, 28),
           (256, 1024, 1, 1, 0, 14), (1024, 256, 1, 1, 0, 14), (512, 2048, 1, 1, 0, 7), (2048, 512, 1, 1, 0, 7),
           (256, 512, 1, 2, 0, 56), (1024, 2048, 1, 2, 0, 14)]
+if os.environ.get('WG_SHAPES'):
+    SHAPES = [SHAPES[int(i)] for i in os.environ['WG_SHAPES'].split(',')]
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 VAR = os.environ.get('BENCH_WGRAD_VAR', 'CNK_WGRAD3')
 tot = {0: 0.0, 1: 0.0}
