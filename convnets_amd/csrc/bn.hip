@@ -616,6 +616,221 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
+// ---- BN backward fed by a max-pool backward (the stems: conv -> BN -> ReLU -> MaxPool2d) -----------------------------
+// The gradient of the BN output is never materialised: both passes gather it from the POOLED gradient and the saved
+// arg-max positions (<= 2 x 2 windows cover an element when ceil(k/s) <= 2), summing in the window order
+// maxpool_bwd_kernel uses.  Against cnk_maxpool2d_bwd + cnk_bn_bwd that removes one full-size write and two full-size
+// reads (the stem of ResNet-50 at batch 256: 411 MB each) for two gathers of the 4x smaller pooled tensors.
+struct PoolGeom {
+    int H, W, Ho, Wo, kh, kw, sh, sw, ph, pw;
+    FastDiv fd_w, fd_h;
+};
+
+template <typename T, int VEC> struct PoolGather {
+    using IB = typename std::conditional<VEC == 8, u32x2, typename std::conditional<VEC == 4, unsigned int, unsigned char>::type>::type;
+    Raw<T, VEC> g[4];
+    IB b[4];
+    int pos[4];          // position of this element inside window k (row-major), -1: no such window
+    __device__ __forceinline__ void issue(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                          const PoolGeom& p, uint32_t m, int vcol, int C) {
+        const uint32_t t = fd_div(m, p.fd_w), w = m - t * p.W;
+        const uint32_t n = fd_div(t, p.fd_h), h = t - n * p.H;
+        int ho_lo = ((int)h + p.ph - p.kh + p.sh) / p.sh;          // ceil((h+p-k+1)/s) when non-negative
+        if ((int)h + p.ph - p.kh + 1 <= 0) ho_lo = 0;
+        int ho_hi = ((int)h + p.ph) / p.sh;
+        if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
+        int wo_lo = ((int)w + p.pw - p.kw + p.sw) / p.sw;
+        if ((int)w + p.pw - p.kw + 1 <= 0) wo_lo = 0;
+        int wo_hi = ((int)w + p.pw) / p.sw;
+        if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ho = ho_lo + (k >> 1), wo = wo_lo + (k & 1);
+            const bool ok = ho <= ho_hi && wo <= wo_hi;
+            pos[k] = ok ? ((int)h - (ho * p.sh - p.ph)) * p.kw + ((int)w - (wo * p.sw - p.pw)) : -1;
+            b[k] = IB{};
+            if (ok) {
+                const size_t o = ((size_t)(n * p.Ho + ho) * p.Wo + wo) * C + (size_t)vcol * VEC;
+                g[k].load(dy + o);
+                b[k] = *(const IB*)(idx + o);
+            }
+        }
+    }
+    __device__ __forceinline__ void sum(float (&d)[VEC]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned char by[VEC];
+            __builtin_memcpy(by, &b[k], VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if ((int)by[i] == pos[k]) d[i] += g[k].get(i);
+        }
+    }
+};
+
+constexpr int POOL_ROWS_U = 2;
+
+// slices of one launch are walked XCD by XCD (blocks are dealt to the 8 XCDs round-robin): neighbouring slices share
+// the pooled rows at their seam, which then hit in that XCD's L2
+__device__ __forceinline__ int pool_slice_of_block(int bx, int slices) {
+    const int s8 = slices & ~7;
+    return bx < s8 ? (bx & 7) * (s8 >> 3) + (bx >> 3) : bx;
+}
+
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
+    const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ partial, int64_t M, int C, SliceGeom g, PoolGeom pg) {
+    __shared__ float sh[2][256 * (VEC > 1 ? VEC : 1)];
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    const bool active = trow < g.rpb && vcol < g.cols;
+    const int slice = pool_slice_of_block(blockIdx.x, g.slices);
+    const int64_t m0 = (int64_t)slice * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float mu[VEC], sc[VEC], sf[VEC], is[VEC];
+        load_coef<VEC>(mu, mean + vcol * VEC);
+        load_coef<VEC>(is, invstd + vcol * VEC);
+        if constexpr (RELU) {
+            load_coef<VEC>(sc, gamma + vcol * VEC);
+            load_coef<VEC>(sf, beta + vcol * VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { sc[i] *= is[i]; sf[i] -= mu[i] * sc[i]; }
+        }
+        const int64_t rstep = (int64_t)g.rpb * C;
+        int64_t m = m0 + trow;
+        int64_t off = m * C + (int64_t)vcol * VEC;
+        auto consume = [&](const PoolGather<T, VEC>& pv, const Raw<T, VEC>& xv) {
+            float d[VEC];
+            pv.sum(d);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float xi = xv.get(i);
+                if constexpr (RELU) { if (!(xi * sc[i] + sf[i] > 0.f)) d[i] = 0.f; }
+                s1[i] += d[i];
+                s2[i] += d[i] * (xi - mu[i]);
+            }
+        };
+        for (; m + (POOL_ROWS_U - 1) * g.rpb < m1; m += POOL_ROWS_U * g.rpb, off += POOL_ROWS_U * rstep) {
+            PoolGather<T, VEC> pv[POOL_ROWS_U];
+            Raw<T, VEC> xv[POOL_ROWS_U];
+#pragma unroll
+            for (int u = 0; u < POOL_ROWS_U; ++u) {
+                xv[u].load(x + off + u * rstep);
+                pv[u].issue(dy, idx, pg, (uint32_t)(m + (int64_t)u * g.rpb), vcol, C);
+            }
+#pragma unroll
+            for (int u = 0; u < POOL_ROWS_U; ++u) consume(pv[u], xv[u]);
+        }
+        for (; m < m1; m += g.rpb, off += rstep) {
+            PoolGather<T, VEC> pv;
+            Raw<T, VEC> xv;
+            xv.load(x + off);
+            pv.issue(dy, idx, pg, (uint32_t)m, vcol, C);
+            consume(pv, xv);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s2[i] *= is[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sh[0][tid * VEC + i] = s1[i];
+        sh[1][tid * VEC + i] = s2[i];
+    }
+    __syncthreads();
+    int span = 1;
+    while (span < g.rpb) span <<= 1;
+    for (int st = span >> 1; st >= 1; st >>= 1) {
+        if (trow < st && trow + st < g.rpb && vcol < g.cols) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                int a = tid * VEC + i, b = (tid + st * g.cpb) * VEC + i;
+                sh[0][a] += sh[0][b];
+                sh[1][a] += sh[1][b];
+            }
+        }
+        __syncthreads();
+    }
+    if (trow == 0 && vcol < g.cols) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            int c = vcol * VEC + i;
+            float* o = partial + ((size_t)slice * C + c) * 2;
+            o[0] = sh[0][tid * VEC + i]; o[1] = sh[1][tid * VEC + i];
+        }
+    }
+}
+
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
+    const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x, T* __restrict__ dx,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ coefA, const float* __restrict__ coefB1, const float* __restrict__ coefB2, int64_t M,
+    int C, SliceGeom g, PoolGeom pg) {
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    if (trow >= g.rpb || vcol >= g.cols) return;
+    const int slice = pool_slice_of_block(blockIdx.x, g.slices);
+    const int64_t m0 = (int64_t)slice * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
+    const int64_t rstep = (int64_t)g.rpb * C;
+    int64_t m = m0 + trow;
+    int64_t off = m * C + (int64_t)vcol * VEC;
+    float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC], ksf[VEC];
+    load_coef<VEC>(ka, coefA + vcol * VEC);             // gamma*invstd == the forward's scale
+    load_coef<VEC>(kb1, coefB1 + vcol * VEC);
+    load_coef<VEC>(kmu, mean + vcol * VEC);
+    load_coef<VEC>(kis, invstd + vcol * VEC);
+    {
+        float b2[VEC];
+        load_coef<VEC>(b2, coefB2 + vcol * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) kis[k] *= b2[k];
+    }
+    if constexpr (RELU) {
+        load_coef<VEC>(ksf, beta + vcol * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) ksf[k] -= kmu[k] * ka[k];
+    }
+    auto emit = [&](const PoolGather<T, VEC>& pv, const Raw<T, VEC>& xv, T* __restrict__ dxp) {
+        float d[VEC];
+        pv.sum(d);
+        Raw<T, VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float xk = xv.get(k);
+            if constexpr (RELU) { if (!(xk * ka[k] + ksf[k] > 0.f)) d[k] = 0.f; }
+            o.set(k, ka[k] * (d[k] - kb1[k] - (xk - kmu[k]) * kis[k]));
+        }
+        o.store(dxp);
+    };
+    for (; m + (POOL_ROWS_U - 1) * g.rpb < m1; m += POOL_ROWS_U * g.rpb, off += POOL_ROWS_U * rstep) {
+        PoolGather<T, VEC> pv[POOL_ROWS_U];
+        Raw<T, VEC> xv[POOL_ROWS_U];
+#pragma unroll
+        for (int u = 0; u < POOL_ROWS_U; ++u) {
+            xv[u].load(x + off + u * rstep);
+            pv[u].issue(dy, idx, pg, (uint32_t)(m + (int64_t)u * g.rpb), vcol, C);
+        }
+#pragma unroll
+        for (int u = 0; u < POOL_ROWS_U; ++u) emit(pv[u], xv[u], dx + off + u * rstep);
+    }
+    for (; m < m1; m += g.rpb, off += rstep) {
+        PoolGather<T, VEC> pv;
+        Raw<T, VEC> xv;
+        xv.load(x + off);
+        pv.issue(dy, idx, pg, (uint32_t)m, vcol, C);
+        emit(pv, xv, dx + off);
+    }
+}
+
 inline int grid_for(int64_t nvec) {
     int64_t b = (nvec + 255) / 256;
     return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -795,6 +1010,309 @@ int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* ma
     }
     if (C % 4 == 0) return bn_bwd_t<float, 4>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, ep, es, M, C, relu, ws, s);
     return bn_bwd_t<float, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, ep, es, M, C, relu, ws, s);
+}
+
+namespace {
+
+// Stride-2 pools (every pool of the reference's models): one thread owns a 2 x 2 cell of input elements.  The <= 2 x 2
+// windows that touch the cell are loaded once and serve its four elements, and which element sits where inside which
+// window does not depend on the cell -- pos[dy][dx][a][b] below is a launch constant (-1: not covered), so the
+// per-element work is byte compares against scalars.
+struct PoolCell {
+    int H, W, Ho, Wo, cells_h, cells_w;
+    int lo_h, lo_w;              // first window of cell (cj, ci): (cj + lo_h, ci + lo_w)
+    int nwin_h, nwin_w;          // windows per cell and dimension (1 or 2)
+    int pos[2][2][2][2];         // [dy][dx][a][b]
+    FastDiv fd_cw, fd_ch;
+};
+
+template <typename T, int VEC> struct CellGather {
+    using IB = typename PoolGather<T, VEC>::IB;
+    Raw<T, VEC> g[4];
+    IB b[4];
+    Raw<T, VEC> xv[4];
+    int64_t xoff;                // element offset of the cell's first element
+    bool in_h1, in_w1;           // second row / column of the cell inside the image
+    __device__ __forceinline__ void issue(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                          const T* __restrict__ x, const PoolCell& p, uint32_t cell, int vcol, int C) {
+        const uint32_t t = fd_div(cell, p.fd_cw), ci = cell - t * p.cells_w;
+        const uint32_t n = fd_div(t, p.fd_ch), cj = t - n * p.cells_h;
+        const int h0 = 2 * (int)cj, w0 = 2 * (int)ci;
+        in_h1 = h0 + 1 < p.H;
+        in_w1 = w0 + 1 < p.W;
+        xoff = ((int64_t)(n * p.H + h0) * p.W + w0) * C + (int64_t)vcol * VEC;
+        xv[0].load(x + xoff);
+        if (in_w1) xv[1].load(x + xoff + C);
+        if (in_h1) xv[2].load(x + xoff + (int64_t)p.W * C);
+        if (in_h1 && in_w1) xv[3].load(x + xoff + (int64_t)p.W * C + C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = k >> 1, c = k & 1;
+            const int ho = (int)cj + p.lo_h + a, wo = (int)ci + p.lo_w + c;
+            const bool ok = a < p.nwin_h && c < p.nwin_w && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            if constexpr (VEC == 8) b[k] = IB{0xffffffffu, 0xffffffffu};      // 255 is no window position (kh*kw <= 255)
+            else if constexpr (VEC == 4) b[k] = 0xffffffffu;
+            else b[k] = 0xff;
+            if (ok) {
+                const size_t o = ((size_t)(n * p.Ho + ho) * p.Wo + wo) * C + (size_t)vcol * VEC;
+                g[k].load(dy + o);
+                b[k] = *(const IB*)(idx + o);
+            }
+        }
+    }
+    // gradient reaching element e = dy*2+dx of the cell, windows summed in (ho, wo) order
+    template <int E> __device__ __forceinline__ void sum(const PoolCell& p, float (&d)[VEC]) const {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ps = p.pos[E >> 1][E & 1][k >> 1][k & 1];
+            if (ps < 0) continue;                       // launch constant: a scalar branch
+            unsigned char by[VEC];
+            __builtin_memcpy(by, &b[k], VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if ((int)by[i] == ps) d[i] += g[k].get(i);
+        }
+    }
+    template <int E> __device__ __forceinline__ bool inside() const {
+        return (E & 1 ? in_w1 : true) && (E >> 1 ? in_h1 : true);
+    }
+    template <int E> __device__ __forceinline__ int64_t offset(const PoolCell& p, int C) const {
+        return xoff + (E & 1 ? C : 0) + (E >> 1 ? (int64_t)p.W * C : 0);
+    }
+};
+
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(256) void bn_cell_bwd_reduce_kernel(
+    const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ partial, int64_t cells, int C, SliceGeom g, PoolCell pc) {
+    __shared__ float sh[2][256 * (VEC > 1 ? VEC : 1)];
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    const bool active = trow < g.rpb && vcol < g.cols;
+    const int slice = pool_slice_of_block(blockIdx.x, g.slices);
+    const int64_t m0 = (int64_t)slice * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < cells ? m0 + g.slice_rows : cells;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float mu[VEC], sc[VEC], sf[VEC], is[VEC];
+        load_coef<VEC>(mu, mean + vcol * VEC);
+        load_coef<VEC>(is, invstd + vcol * VEC);
+        if constexpr (RELU) {
+            load_coef<VEC>(sc, gamma + vcol * VEC);
+            load_coef<VEC>(sf, beta + vcol * VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { sc[i] *= is[i]; sf[i] -= mu[i] * sc[i]; }
+        }
+        for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
+            CellGather<T, VEC> cg;
+            cg.issue(dy, idx, x, pc, (uint32_t)m, vcol, C);
+            auto element = [&](auto tag) {
+                constexpr int E = decltype(tag)::value;
+                if (!cg.template inside<E>()) return;
+                float d[VEC];
+                cg.template sum<E>(pc, d);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float xi = cg.xv[E].get(i);
+                    if constexpr (RELU) { if (!(xi * sc[i] + sf[i] > 0.f)) d[i] = 0.f; }
+                    s1[i] += d[i];
+                    s2[i] += d[i] * (xi - mu[i]);
+                }
+            };
+            element(std::integral_constant<int, 0>{});
+            element(std::integral_constant<int, 1>{});
+            element(std::integral_constant<int, 2>{});
+            element(std::integral_constant<int, 3>{});
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s2[i] *= is[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sh[0][tid * VEC + i] = s1[i];
+        sh[1][tid * VEC + i] = s2[i];
+    }
+    __syncthreads();
+    int span = 1;
+    while (span < g.rpb) span <<= 1;
+    for (int st = span >> 1; st >= 1; st >>= 1) {
+        if (trow < st && trow + st < g.rpb && vcol < g.cols) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                int a = tid * VEC + i, b = (tid + st * g.cpb) * VEC + i;
+                sh[0][a] += sh[0][b];
+                sh[1][a] += sh[1][b];
+            }
+        }
+        __syncthreads();
+    }
+    if (trow == 0 && vcol < g.cols) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            int c = vcol * VEC + i;
+            float* o = partial + ((size_t)slice * C + c) * 2;
+            o[0] = sh[0][tid * VEC + i]; o[1] = sh[1][tid * VEC + i];
+        }
+    }
+}
+
+template <typename T, int VEC, bool RELU>
+__global__ __launch_bounds__(256) void bn_cell_bwd_apply_kernel(
+    const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x, T* __restrict__ dx,
+    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ coefA, const float* __restrict__ coefB1, const float* __restrict__ coefB2, int64_t cells,
+    int C, SliceGeom g, PoolCell pc) {
+    const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
+    const int vcol = blockIdx.y * g.cpb + tcol;
+    if (trow >= g.rpb || vcol >= g.cols) return;
+    const int slice = pool_slice_of_block(blockIdx.x, g.slices);
+    const int64_t m0 = (int64_t)slice * g.slice_rows;
+    const int64_t m1 = m0 + g.slice_rows < cells ? m0 + g.slice_rows : cells;
+    float ka[VEC], kb1[VEC], kmu[VEC], kis[VEC], ksf[VEC];
+    load_coef<VEC>(ka, coefA + vcol * VEC);             // gamma*invstd == the forward's scale
+    load_coef<VEC>(kb1, coefB1 + vcol * VEC);
+    load_coef<VEC>(kmu, mean + vcol * VEC);
+    load_coef<VEC>(kis, invstd + vcol * VEC);
+    {
+        float b2[VEC];
+        load_coef<VEC>(b2, coefB2 + vcol * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) kis[k] *= b2[k];
+    }
+    if constexpr (RELU) {
+        load_coef<VEC>(ksf, beta + vcol * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) ksf[k] -= kmu[k] * ka[k];
+    }
+    for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
+        CellGather<T, VEC> cg;
+        cg.issue(dy, idx, x, pc, (uint32_t)m, vcol, C);
+        auto element = [&](auto tag) {
+            constexpr int E = decltype(tag)::value;
+            if (!cg.template inside<E>()) return;
+            float d[VEC];
+            cg.template sum<E>(pc, d);
+            Raw<T, VEC> o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float xk = cg.xv[E].get(k);
+                if constexpr (RELU) { if (!(xk * ka[k] + ksf[k] > 0.f)) d[k] = 0.f; }
+                o.set(k, ka[k] * (d[k] - kb1[k] - (xk - kmu[k]) * kis[k]));
+            }
+            o.store(dx + cg.template offset<E>(pc, C));
+        };
+        element(std::integral_constant<int, 0>{});
+        element(std::integral_constant<int, 1>{});
+        element(std::integral_constant<int, 2>{});
+        element(std::integral_constant<int, 3>{});
+    }
+}
+
+// stride-2 pools whose 2 x 2 cells meet at most 2 windows per dimension: fill the cell description
+static bool make_pool_cell(PoolCell& pc, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw) {
+    if (sh != 2 || sw != 2) return false;
+    auto cdiv = [](int a, int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };     // ceil(a / b), b > 0
+    auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };       // floor(a / b)
+    pc.H = H; pc.W = W;
+    pc.Ho = (H + 2 * ph - kh) / sh + 1;
+    pc.Wo = (W + 2 * pw - kw) / sw + 1;
+    pc.cells_h = (H + 1) / 2; pc.cells_w = (W + 1) / 2;
+    pc.lo_h = cdiv(ph - kh + 1, 2); pc.lo_w = cdiv(pw - kw + 1, 2);
+    pc.nwin_h = fdiv(1 + ph, 2) - pc.lo_h + 1; pc.nwin_w = fdiv(1 + pw, 2) - pc.lo_w + 1;
+    if (pc.nwin_h < 1 || pc.nwin_h > 2 || pc.nwin_w < 1 || pc.nwin_w > 2) return false;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const int r = dy - (pc.lo_h + a) * 2 + ph, q = dx - (pc.lo_w + b) * 2 + pw;
+                    const bool in = a < pc.nwin_h && b < pc.nwin_w && r >= 0 && r < kh && q >= 0 && q < kw;
+                    pc.pos[dy][dx][a][b] = in ? r * kw + q : -1;
+                }
+    pc.fd_cw = make_fastdiv(pc.cells_w); pc.fd_ch = make_fastdiv(pc.cells_h);
+    return true;
+}
+
+}  // namespace
+
+template <typename T, int VEC>
+static int bn_bwd_pool_t(const void* dy, const unsigned char* idx, const void* x, const float* gamma, const float* beta,
+                         const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int N,
+                         int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu, float* ws,
+                         hipStream_t s) {
+    const int64_t M = (int64_t)N * H * W;
+    SliceGeom g = make_geom(M, C, VEC);
+    PoolGeom pg;
+    pg.H = H; pg.W = W; pg.kh = kh; pg.kw = kw; pg.sh = sh; pg.sw = sw; pg.ph = ph; pg.pw = pw;
+    pg.Ho = (H + 2 * ph - kh) / sh + 1;
+    pg.Wo = (W + 2 * pw - kw) / sw + 1;
+    pg.fd_w = make_fastdiv(W); pg.fd_h = make_fastdiv(H);
+    float* coefA = ws;
+    float* coefB1 = ws + 2 * C;
+    float* coefB2 = ws + 3 * C;
+    float* partial = ws + ws_partials_off(C);
+    PoolCell pc;
+    const bool cell = make_pool_cell(pc, H, W, kh, kw, sh, sw, ph, pw) && !getenv("CNK_BN_POOL_ELEMENTWISE");
+    if (cell) {
+        const int64_t cells = (int64_t)N * pc.cells_h * pc.cells_w;
+        SliceGeom gc = make_geom(cells, C, VEC);
+        const dim3 cgrid(gc.slices, gc.colgroups);
+        if (relu)
+            hipLaunchKernelGGL((bn_cell_bwd_reduce_kernel<T, VEC, true>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
+                               (const T*)x, gamma, beta, sm, si, partial, cells, C, gc, pc);
+        else
+            hipLaunchKernelGGL((bn_cell_bwd_reduce_kernel<T, VEC, false>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
+                               (const T*)x, gamma, beta, sm, si, partial, cells, C, gc, pc);
+        CNK_CHECK_LAUNCH("bn_cell_bwd_reduce");
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, gc.slices, C, M, gamma, si, dgamma,
+                           dbeta, coefA, coefB1, coefB2, accumulate);
+        CNK_CHECK_LAUNCH("bn_bwd_final");
+        const double pooled = (double)N * pc.Ho * pc.Wo * C * (sizeof(T) + 1);
+        ProfScope kscope(CNK_KF_BN_BWD_APPLY, s, 0.0, (double)M * C * sizeof(T) * 2 + pooled);
+        if (relu)
+            hipLaunchKernelGGL((bn_cell_bwd_apply_kernel<T, VEC, true>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
+                               (const T*)x, (T*)dx, beta, sm, si, coefA, coefB1, coefB2, cells, C, gc, pc);
+        else
+            hipLaunchKernelGGL((bn_cell_bwd_apply_kernel<T, VEC, false>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
+                               (const T*)x, (T*)dx, beta, sm, si, coefA, coefB1, coefB2, cells, C, gc, pc);
+        CNK_CHECK_LAUNCH("bn_cell_bwd_apply");
+        return 0;
+    }
+    const dim3 grid(g.slices, g.colgroups);
+    if (relu)
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, VEC, true>), grid, dim3(256), 0, s, (const T*)dy, idx, (const T*)x,
+                           gamma, beta, sm, si, partial, M, C, g, pg);
+    else
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<T, VEC, false>), grid, dim3(256), 0, s, (const T*)dy, idx,
+                           (const T*)x, gamma, beta, sm, si, partial, M, C, g, pg);
+    CNK_CHECK_LAUNCH("bn_pool_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, g.slices, C, M, gamma, si, dgamma, dbeta,
+                       coefA, coefB1, coefB2, accumulate);
+    CNK_CHECK_LAUNCH("bn_bwd_final");
+    const double pooled = (double)N * pg.Ho * pg.Wo * C * (sizeof(T) + 1);
+    ProfScope kscope(CNK_KF_BN_BWD_APPLY, s, 0.0, (double)M * C * sizeof(T) * 2 + pooled);
+    if (relu)
+        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, VEC, true>), grid, dim3(256), 0, s, (const T*)dy, idx, (const T*)x,
+                           (T*)dx, beta, sm, si, coefA, coefB1, coefB2, M, C, g, pg);
+    else
+        hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<T, VEC, false>), grid, dim3(256), 0, s, (const T*)dy, idx,
+                           (const T*)x, (T*)dx, beta, sm, si, coefA, coefB1, coefB2, M, C, g, pg);
+    CNK_CHECK_LAUNCH("bn_pool_bwd_apply");
+    return 0;
+}
+
+int bn_bwd_pool(const void* dy, const unsigned char* idx, const void* x, const float* gamma, const float* beta,
+                const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int N, int H,
+                int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu, int dtype, float* ws,
+                hipStream_t s) {
+#define CNK_BN_POOL(T, V) bn_bwd_pool_t<T, V>(dy, idx, x, gamma, beta, sm, si, dx, dgamma, dbeta, accumulate, N, H, W, C, kh, kw, sh, sw, ph, pw, relu, ws, s)
+    if (dtype == CNK_BF16) return C % 8 == 0 ? CNK_BN_POOL(bf16, 8) : CNK_BN_POOL(bf16, 1);
+    return C % 4 == 0 ? CNK_BN_POOL(float, 4) : CNK_BN_POOL(float, 1);
+#undef CNK_BN_POOL
 }
 
 // bytes of the packed ReLU mask: one byte per 16-byte channel vector the kernels use for (C, dtype)

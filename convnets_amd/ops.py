@@ -637,8 +637,9 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=Non
 class BatchNormActMaxPoolFn(torch.autograd.Function):
     """BatchNorm2d (training) -> [ReLU] -> MaxPool2d as ONE autograd node (the stems: resnet.py:88-89; VGG's stage
     ends).  Forward: the BN statistics, then a pooling pass that normalises the conv output on the fly
-    (cnk_maxpool2d_fwd_bn) -- the full-size normalised tensor is neither written nor read.  Backward: the regular
-    max-pool backward, then the BN backward with the ReLU mask re-derived from x."""
+    (cnk_maxpool2d_fwd_bn) -- the full-size normalised tensor is neither written nor read.  Backward: the BN backward
+    gathers the pooled gradient through the arg-max positions in both of its passes (cnk_bn_bwd_maxpool), ReLU mask
+    re-derived from x; pools with more than 2 x 2 covering windows take max-pool backward + BN backward."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, partial, ksize, stride, padding):
@@ -675,9 +676,6 @@ class BatchNormActMaxPoolFn(torch.autograd.Function):
         dy = _nhwc(dy)
         N, C, H, W = x.shape
         M = N * H * W
-        da = torch.empty_like(x, memory_format=CL)
-        check(lib.cnk_maxpool2d_bwd(_p(dy), _p(idx), _p(da), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
-                                    padding[0], padding[1], _dtype_code(x), _stream()))
         dx = torch.empty_like(x, memory_format=CL)
         pg, pb = ctx.params
         gg, gb = _arena_grad(pg), _arena_grad(pb)
@@ -688,9 +686,19 @@ class BatchNormActMaxPoolFn(torch.autograd.Function):
             dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
-        check(lib.cnk_bn_bwd(_p(da), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dx), None,
-                             _p(dg_buf), _p(db_buf), int(direct), None, 0, M, C, int(ctx.relu), _dtype_code(x), _p(ws),
-                             ws.numel(), _stream()))
+        if ksize[0] <= 2 * stride[0] and ksize[1] <= 2 * stride[1] and os.environ.get('CNK_BN_POOL_BWD', '1') != '0':
+            # both BN passes gather the pooled gradient themselves: no full-size intermediate
+            check(lib.cnk_bn_bwd_maxpool(_p(dy), _p(idx), _p(x), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                         _p(dx), _p(dg_buf), _p(db_buf), int(direct), N, H, W, C, ksize[0], ksize[1],
+                                         stride[0], stride[1], padding[0], padding[1], int(ctx.relu), _dtype_code(x),
+                                         _p(ws), ws.numel(), _stream()))
+        else:
+            da = torch.empty_like(x, memory_format=CL)
+            check(lib.cnk_maxpool2d_bwd(_p(dy), _p(idx), _p(da), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],
+                                        padding[0], padding[1], _dtype_code(x), _stream()))
+            check(lib.cnk_bn_bwd(_p(da), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dx),
+                                 None, _p(dg_buf), _p(db_buf), int(direct), None, 0, M, C, int(ctx.relu), _dtype_code(x),
+                                 _p(ws), ws.numel(), _stream()))
         if direct:
             _grad_written(pg)
             _grad_written(pb)

@@ -210,10 +210,24 @@ int cnk_maxpool2d_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N
  * running statistics are produced and the per-channel scale[C] | shift[C], fp32, are left at the START of its
  * workspace), then this pooling pass, which applies x * scale + shift (+ReLU) to the conv output on the fly, each
  * value rounded to `dtype` as the BN pass would have stored it.  idx as cnk_maxpool2d_fwd (required).  The backward is
- * the regular pair: cnk_maxpool2d_bwd, then cnk_bn_bwd with y == NULL and no mask (it re-derives the ReLU mask). */
+ * cnk_bn_bwd_maxpool below, or the regular pair: cnk_maxpool2d_bwd, then cnk_bn_bwd with y == NULL and no mask (it
+ * re-derives the ReLU mask). */
 int cnk_maxpool2d_fwd_bn(const void* x, const float* scale, const float* shift, int relu, void* y, uint8_t* idx,
                          int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
                          int32_t ph, int32_t pw, int dtype, void* stream);
+
+/* Backward of that pair in one call, for pools where at most 2 x 2 windows cover an element (kh <= 2*sh, kw <= 2*sw:
+ * the 3x3/2 stem pool, VGG's 2x2/2): cnk_bn_bwd whose incoming gradient is max-pool-backward(dy_pooled, argmax), gathered
+ * on the fly in both BN passes and summed in fp32 in cnk_maxpool2d_bwd's window order -- the full-size gradient of the
+ * BN output is neither written nor read.  x: the BN input [N][H][W][C]; dy_pooled / argmax: [N][Ho][Wo][C]; relu != 0
+ * re-derives the mask as x*scale+shift > 0 (needs beta).  fp32 results equal the two-call pair up to the order of the
+ * per-slice sums (stride-2 pools walk 2 x 2 cells of elements); bf16 ones also differ by the skipped rounding of the
+ * intermediate.  Deterministic.  workspace: cnk_bn_workspace_bytes(N*H*W, C). */
+int cnk_bn_bwd_maxpool(const void* dy_pooled, const uint8_t* argmax, const void* x, const float* gamma,
+                       const float* beta, const float* save_mean, const float* save_invstd, void* dx, float* dgamma,
+                       float* dbeta, int accumulate, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw,
+                       int32_t sh, int32_t sw, int32_t ph, int32_t pw, int relu, int dtype, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* nn.ReLU (basemodel.py:1012,1065) and the block-level  output += identity; F.relu(output)
  * (resnet.py:151-154,191-194) as stand-alone ops for unfused use. */

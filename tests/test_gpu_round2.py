@@ -385,3 +385,110 @@ def test_wgrad_bitwise_reproducible_and_vs_fp64(Cin, Cout, k, H):
     assert lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dyb), P(xb), P(acc), None, 1, P(ws), nws, st) == 0
     torch.cuda.synchronize()
     assert rel_l2(host(acc), ref.numpy() + 1.0) < 2e-6
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('N,C,H,W,k,s,p,relu', [
+    (8, 64, 32, 32, 3, 2, 1, 1),      # the ResNet stem pool (resnet.py:88-89)
+    (3, 24, 15, 13, 3, 2, 1, 1),      # odd sizes, ragged last windows, 3 vector columns
+    (4, 128, 16, 16, 2, 2, 0, 1),     # VGG stage end (vggnet.py)
+    (2, 6, 9, 11, 3, 2, 0, 0),        # scalar channel path, no padding (rows/columns no window covers), no ReLU
+    (2, 16, 12, 12, 3, 3, 1, 1),      # one window per element at most
+    (64, 64, 112, 112, 3, 2, 1, 1),   # many slices: exercises the XCD-ordered slice walk and the 4-wide final sums
+])
+def test_bn_backward_through_maxpool_gather(N, C, H, W, k, s, p, relu, dtype):
+    """cnk_bn_bwd_maxpool (BN backward whose incoming gradient is gathered from the pooled gradient and the arg-max bytes)
+    against the two-call pair cnk_maxpool2d_bwd + cnk_bn_bwd on the same operands -- fp32: same window order, equal up to
+    the order of the slice sums; bf16: only the rounding of the intermediate the pair stores differs -- and against torch
+    autograd of  max_pool2d(relu(batch_norm(x)))  in fp64 on the CPU."""
+    import ctypes
+    import torch.nn.functional as F
+    from convnets_amd import _lib
+    lib = _lib.load()
+    code = _lib.CNK_F32 if dtype == 'f32' else _lib.CNK_BF16
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).to(tdt).cuda()
+    dyp = torch.randn(N, Ho, Wo, C, generator=g).to(tdt).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C, generator=g) * 0.2).cuda()
+    M = N * H * W
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nws = lib.cnk_bn_workspace_bytes(M, C)
+    ws = torch.empty(nws // 4 + 4, dtype=torch.float32, device='cuda')
+    sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    assert lib.cnk_bn_fwd_train(P(x), P(gamma), P(beta), None, None, None, None, None, P(sm), P(si), None, 0, M, C, 1e-5, 0.1,
+                                relu, code, P(ws), nws, st) == 0, lib.cnk_last_error()
+    scale, shift = ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(ws.data_ptr() + 4 * C)
+    y = torch.empty(N, Ho, Wo, C, dtype=tdt, device='cuda')
+    idx = torch.empty(N, Ho, Wo, C, dtype=torch.uint8, device='cuda')
+    assert lib.cnk_maxpool2d_fwd_bn(P(x), scale, shift, relu, P(y), P(idx), N, H, W, C, k, k, s, s, p, p, code, st) == 0, lib.cnk_last_error()
+    # the pair
+    da = torch.empty_like(x)
+    dx_pair, dg_pair, db_pair = torch.empty_like(x), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    assert lib.cnk_maxpool2d_bwd(P(dyp), P(idx), P(da), N, H, W, C, k, k, s, s, p, p, code, st) == 0, lib.cnk_last_error()
+    assert lib.cnk_bn_bwd(P(da), P(x), None, None, P(gamma), P(beta), P(sm), P(si), P(dx_pair), None, P(dg_pair), P(db_pair), 0,
+                          None, 0, M, C, relu, code, P(ws), nws, st) == 0, lib.cnk_last_error()
+    # the gathered form, twice (determinism), then accumulating
+    outs = []
+    for _ in range(2):
+        dx, dg, db = torch.full_like(x, 3.0), torch.full((C,), 5.0, device='cuda'), torch.full((C,), 5.0, device='cuda')
+        assert lib.cnk_bn_bwd_maxpool(P(dyp), P(idx), P(x), P(gamma), P(beta), P(sm), P(si), P(dx), P(dg), P(db), 0, N, H, W, C,
+                                      k, k, s, s, p, p, relu, code, P(ws), nws, st) == 0, lib.cnk_last_error()
+        torch.cuda.synchronize()
+        outs.append((dx, dg, db))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    dx, dg, db = outs[0]
+    if dtype == 'f32':
+        # the 2 x 2-cell kernels of stride-2 pools slice the tensor differently from cnk_bn_bwd: same values up to the
+        # fp32 order of the per-slice sums; the element-wise kernels share its slices and agree bit for bit
+        assert rel_l2(host(dx), host(dx_pair)) < 2e-6
+        assert rel_l2(host(dg), host(dg_pair)) < 2e-6 and rel_l2(host(db), host(db_pair)) < 2e-6
+        os.environ['CNK_BN_POOL_ELEMENTWISE'] = '1'
+        try:
+            ex, eg, eb = torch.empty_like(x), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+            assert lib.cnk_bn_bwd_maxpool(P(dyp), P(idx), P(x), P(gamma), P(beta), P(sm), P(si), P(ex), P(eg), P(eb), 0, N, H, W,
+                                          C, k, k, s, s, p, p, relu, code, P(ws), nws, st) == 0, lib.cnk_last_error()
+            torch.cuda.synchronize()
+        finally:
+            del os.environ['CNK_BN_POOL_ELEMENTWISE']
+        assert torch.equal(ex, dx_pair) and torch.equal(eg, dg_pair) and torch.equal(eb, db_pair)
+    else:
+        assert rel_l2(host(dx), host(dx_pair)) < 6e-3
+        assert rel_l2(host(dg), host(dg_pair)) < 3e-3 and rel_l2(host(db), host(db_pair)) < 3e-3
+    acc_g, acc_b = torch.ones(C, device='cuda'), torch.ones(C, device='cuda')
+    assert lib.cnk_bn_bwd_maxpool(P(dyp), P(idx), P(x), P(gamma), P(beta), P(sm), P(si), P(dx), P(acc_g), P(acc_b), 1, N, H, W, C,
+                                  k, k, s, s, p, p, relu, code, P(ws), nws, st) == 0, lib.cnk_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(acc_g, dg + 1.0) and torch.equal(acc_b, db + 1.0)
+    if M * C > 4e6:
+        return                                       # the fp64 CPU autograd below is for the small cases
+    xr = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    a = F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)
+    if dtype == 'bf16':                              # the pooled values are the bf16-rounded BN outputs
+        a = a + (a.detach().bfloat16().double() - a.detach())
+    if relu:
+        a = F.relu(a)
+    out = F.max_pool2d(a, k, s, p)
+    out.backward(dyp.double().cpu().permute(0, 3, 1, 2))
+    tol = 1e-5 if dtype == 'f32' else 8e-3
+    assert rel_l2(host(dx), xr.grad.permute(0, 2, 3, 1).numpy()) < tol
+    assert rel_l2(host(dg), gr.grad.numpy()) < tol and rel_l2(host(db), br.grad.numpy()) < tol
+
+
+def test_bn_backward_through_maxpool_refuses_wide_overlap():
+    """More than 2 x 2 windows over an element (3x3 / stride 1): the entry point refuses instead of dropping windows."""
+    import ctypes
+    from convnets_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(1 * 8 * 8 * 8, device='cuda')
+    P = lambda v: ctypes.c_void_p(v.data_ptr())
+    nws = lib.cnk_bn_workspace_bytes(64, 8)
+    ws = torch.empty(nws // 4 + 4, device='cuda')
+    rc = lib.cnk_bn_bwd_maxpool(P(t), P(t), P(t), P(t), P(t), P(t), P(t), P(t), P(t), P(t), 0, 1, 8, 8, 8, 3, 3, 1, 1, 1, 1, 1,
+                                _lib.CNK_F32, P(ws), nws, None)
+    assert rc != 0 and b'2 x 2' in lib.cnk_last_error()
