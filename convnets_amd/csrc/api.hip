@@ -68,7 +68,8 @@ int pack_taps(const cnk_conv_desc* d, const float* w, void* out, int ntaps, cons
 bool rowpatch_supported(const cnk_conv_desc* d);
 size_t rowpatch_packed_bytes(const cnk_conv_desc* d);
 int rowpatch_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t s);
-int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, hipStream_t s);
+int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, float* stats, hipStream_t s);
+int64_t rowpatch_fwd_stat_slices(const cnk_conv_desc* d);
 size_t rowpatch_wgrad_workspace(const cnk_conv_desc* d);
 int rowpatch_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 bool smallc_supported(const cnk_conv_desc* d);
@@ -308,7 +309,10 @@ int cnk_pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int3
 }
 
 int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d) {
-    return igemm_supported(d, CNK_PASS_FWD) ? igemm_fwd_stat_slices(d) : 0;
+    if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd_stat_slices(d);
+    const char* e = getenv("CNK_ROWPATCH_STATS");            // A/B switch, read per call
+    const bool rp_stats = !(e && atoi(e) == 0);
+    return rp_stats && rowpatch_supported(d) ? rowpatch_fwd_stat_slices(d) : 0;
 }
 
 int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream) {
@@ -319,8 +323,8 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
     if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd(d, x, w_fwd, bias, y, bn_partial, nullptr, 0, S(stream));
+    if (rowpatch_supported(d)) return rowpatch_fwd(d, x, w_fwd, bias, y, bn_partial, S(stream));
     CNK_CHECK_ARG(!bn_partial, "cnk_conv2d_fwd: this conv shape cannot emit BN partials (cnk_conv2d_fwd_bn_partial_slices == 0)");
-    if (rowpatch_supported(d)) return rowpatch_fwd(d, x, w_fwd, bias, y, S(stream));
     if (smallc_supported(d)) return smallc_fwd(d, x, w_fwd, bias, y, S(stream));
     return direct_fwd(d, x, w_fwd, bias, y, S(stream));
 }

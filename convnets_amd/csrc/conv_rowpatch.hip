@@ -27,6 +27,8 @@ struct RowPatchParams {
     const void* dy;
     float* slab;           // wgrad: [grid][64][Kp]
     const float* bias;
+    float* stats;          // forward: optional BN partials [grid][Cout][3]
+    int ksteps;            // forward: k-steps of two 16-B chunks that cover the KH*Rp real columns
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, s, p;
     int R, Rp, lead, Kp;   // run length, padded run, lead shift, padded K'
     int A0;                // element offset of iw = -p inside a patch row is (A0 - p*Cin)
@@ -96,59 +98,127 @@ template <> struct RpMma<float> {
 
 // ---------------------------------------------------------------------------------------------------
 // forward: one workgroup = rows_per_wg consecutive output rows (n, oh); wave w takes pixel chunks
-// w, w+4, ... of 32 pixels.  LDS: weights [64][Kp+pad] | patch [(KH+1)][PWE] | per-wave out stage.
-template <typename T, bool ALIGN4>
+// w, w+4, ... of 32 pixels.  LDS: weights [64][Kp+pad] | input-row ring [KH+s+1][PWE] | per-wave out stage.
+//
+// Consecutive output rows of one image share KH - s input rows: the patch is a RING of KH + s rows (row ih lives in
+// slot (ih + p) mod (KH + s); one more all-zero row serves the K' padding).  While row oh is computed the s input rows
+// that row oh + 1 adds are already in flight global -> registers (issued before the MFMA loop, written to their slots
+// -- which row oh does not read -- after it): one barrier per output row, each input row fetched once per workgroup,
+// no exposed load latency.  A full refill happens at the first row of a workgroup and at image boundaries.
+// STATS: per-channel BN partial (n, mean, M2) of the ROUNDED outputs of this workgroup's rows, one slice per workgroup
+// (each lane sums its <= rows_per_wg * ceil(Wo/128) pixels, lanes / waves are merged with Chan's update).
+constexpr int RP_MAXPF = 2;          // prefetched 16-B chunks per thread and output row
+
+template <typename T>
+__device__ __forceinline__ void rp_load_rows(const RowPatchParams& p, const T* x, T* ring, int n, int ih0, int nrows,
+                                             int ring_rows) {
+    constexpr int CH = RpCfg<T>::CH;
+    const int row_elems = p.W * p.Cin;
+    const int cpr = p.PWE / CH;
+    const int data0 = PATCH_A0 / CH, data1 = data0 + row_elems / CH;
+    for (int i = threadIdx.x; i < nrows * cpr; i += blockDim.x) {
+        int r = i / cpr, c = i - r * cpr;
+        int ih = ih0 + r;
+        u32x4 v = {0, 0, 0, 0};
+        if ((unsigned)ih < (unsigned)p.H && c >= data0 && c < data1)
+            v = *(const u32x4*)(x + ((size_t)(n * p.H + ih) * p.W) * p.Cin + (size_t)(c - data0) * CH);
+        *(u32x4*)(ring + (size_t)((ih + p.p) % ring_rows) * p.PWE + c * CH) = v;
+    }
+}
+
+template <typename T, bool ALIGN4, bool STATS>
 __global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams p) {
     constexpr int CH = RpCfg<T>::CH, ES = (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int WS = p.Kp * ES + 16;                               // weight row stride (odd # of 16-B slots)
+    const int RING = p.KH + p.s;
     unsigned char* Wl = smem;                                    // [64][WS]
-    T* patch = (T*)(Wl + 64 * WS);                               // [KH+1][PWE]
-    unsigned char* stage = (unsigned char*)(patch + (size_t)(p.KH + 1) * p.PWE);   // [4 waves][32][64*ES+16]
+    T* ring = (T*)(Wl + 64 * WS);                                // [RING + 1][PWE], last row all zero
+    unsigned char* stage = (unsigned char*)(ring + (size_t)(RING + 1) * p.PWE);   // [4 waves][32][64*ES+16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const T* x = (const T*)p.x;
     const T* wpk = (const T*)p.wpk;
-    // weights -> LDS (once per workgroup)
     {
         const int cpr = p.Kp / CH;
         for (int i = tid; i < 64 * cpr; i += 256) {
             int r = i / cpr, c = i - r * cpr;
             *(u32x4*)(Wl + r * WS + c * 16) = *(const u32x4*)(wpk + (size_t)r * p.Kp + c * CH);
         }
-        for (int i = tid; i < p.PWE; i += 256) patch[(size_t)p.KH * p.PWE + i] = from_f32<T>(0.f);   // guard row
+        for (int i = tid; i < p.PWE; i += 256) ring[(size_t)RING * p.PWE + i] = from_f32<T>(0.f);
     }
-    const int nsteps = p.Kp / (2 * CH);                          // MFMA k-steps (two chunks each)
+    const int nsteps = p.ksteps;                                 // MFMA k-steps that hold real taps (two chunks each)
     const int cps = p.Rp / CH;                                   // chunks per kh run
     const int SS = 64 * ES + 16;
     unsigned char* st = stage + wave * 32 * SS;
     const int row0 = blockIdx.x * p.rows_per_wg;
-    for (int rr = 0; rr < p.rows_per_wg; ++rr) {
+    const int nrows = min(p.rows_per_wg, p.rows_total - row0);
+    const int cpr_in = p.PWE / CH, data0 = PATCH_A0 / CH, data1 = data0 + (p.W * p.Cin) / CH;
+    const int npf = p.s * cpr_in;                                // chunks the next output row adds
+    const bool incremental = npf <= 256 * RP_MAXPF;
+    // STATS (Cout == 64): in the copy-out every lane always moves the same 16-byte channel group (lane % CPRO) of pixels
+    // lane / CPRO + k * (64 / CPRO): its sums cover CH channels
+    float sS[CH], sQ[CH], cnt = 0.f;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) sS[e] = sQ[e] = 0.f;
+    }
+    int n = row0 / p.Ho, oh = row0 - n * p.Ho;
+    bool need_full = true;
+    for (int rr = 0; rr < nrows; ++rr) {
         const int row = row0 + rr;
-        if (row >= p.rows_total) break;
-        const int n = row / p.Ho, oh = row - n * p.Ho;
-        __syncthreads();                                         // previous row's patch reads done
-        load_patch<T>(p, x, patch, n, oh * p.s - p.p, p.KH);
-        __syncthreads();
+        if (need_full) {
+            __syncthreads();                                     // previous row's ring reads done
+            rp_load_rows<T>(p, x, ring, n, oh * p.s - p.p, p.KH, RING);
+            __syncthreads();
+        }
+        const bool next_ok = incremental && rr + 1 < nrows && oh + 1 < p.Ho;
+        u32x4 pf[RP_MAXPF];
+        if (next_ok) {
+            const int ihn = oh * p.s - p.p + p.KH;               // first of the s rows row oh + 1 adds
+#pragma unroll
+            for (int t = 0; t < RP_MAXPF; ++t) {
+                const int i = tid + t * 256;
+                pf[t] = u32x4{0, 0, 0, 0};
+                if (i < npf) {
+                    const int r = i / cpr_in, c = i - r * cpr_in, ih = ihn + r;
+                    if ((unsigned)ih < (unsigned)p.H && c >= data0 && c < data1)
+                        pf[t] = *(const u32x4*)(x + ((size_t)(n * p.H + ih) * p.W) * p.Cin + (size_t)(c - data0) * CH);
+                }
+            }
+        }
+        const int base = (oh * p.s) % RING;                      // slot of this row's kh = 0
         for (int c0 = wave * 32; c0 < p.Wo; c0 += 128) {
             const int ow = c0 + l31;
-            const int owc = ow < p.Wo ? ow : p.Wo - 1;           // clamp: reads stay inside the patch
+            const int owc = ow < p.Wo ? ow : p.Wo - 1;           // clamp: reads stay inside the ring row
             const int e0 = PATCH_A0 - p.p * p.Cin - p.lead + owc * p.s * p.Cin;
             f32x16 acc[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            // this lane's k-chunk q = 2*step + lh walks (kh, chunk-in-run); fragments of step+1 are read before the
+            // MFMAs of step
+            int kh = lh / cps, jc = lh - kh * cps;
+            auto frag_a = [&]() {
+                int slot = kh < p.KH ? base + kh : RING;
+                slot = (slot >= RING && kh < p.KH) ? slot - RING : slot;
+                return read_chunk<T, ALIGN4>(ring + (size_t)slot * p.PWE, e0 + jc * CH);
+            };
+            const unsigned char* wrow = Wl + l31 * WS + lh * 16;
+            u32x4 fa = frag_a();
+            u32x4 fb0 = *(const u32x4*)(wrow), fb1 = *(const u32x4*)(wrow + 32 * WS);
             for (int sidx = 0; sidx < nsteps; ++sidx) {
-                const int q = 2 * sidx + lh;                     // this lane's k-chunk
-                int kh = q / cps;
-                const int j0 = (q - kh * cps) * CH;
-                kh = kh < p.KH ? kh : p.KH;                      // K' padding -> zero guard row
-                u32x4 fa = read_chunk<T, ALIGN4>(patch + (size_t)kh * p.PWE, e0 + j0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    u32x4 fb = *(const u32x4*)(Wl + (j * 32 + l31) * WS + q * 16);
-                    RpMma<T>::run(acc[j], fb, fa);               // transposed: rows = co, cols = pixels
+                const u32x4 ca = fa, cb0 = fb0, cb1 = fb1;
+                if (sidx + 1 < nsteps) {
+                    jc += 2;
+                    while (jc >= cps) { jc -= cps; ++kh; }
+                    wrow += 32;
+                    fa = frag_a();
+                    fb0 = *(const u32x4*)(wrow);
+                    fb1 = *(const u32x4*)(wrow + 32 * WS);
                 }
+                RpMma<T>::run(acc[0], cb0, ca);                  // transposed: rows = co, cols = pixels
+                RpMma<T>::run(acc[1], cb1, ca);
             }
             // lane (pixel l31, lh) holds channels j*32 + 8g + 4lh + {0..3} in regs 4g..4g+3
 #pragma unroll
@@ -174,8 +244,21 @@ __global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams 
                 constexpr int CPRO = 64 * ES / 16;               // 16-B chunks per output pixel
                 for (int i = lane; i < 32 * CPRO; i += 64) {
                     int pr = i / CPRO, c = i - pr * CPRO;
-                    if (c0 + pr < p.Wo)
-                        *(u32x4*)((unsigned char*)y + (size_t)pr * 64 * ES + c * 16) = *(const u32x4*)(st + pr * SS + c * 16);
+                    if (c0 + pr < p.Wo) {
+                        const u32x4 v = *(const u32x4*)(st + pr * SS + c * 16);
+                        *(u32x4*)((unsigned char*)y + (size_t)pr * 64 * ES + c * 16) = v;
+                        if constexpr (STATS) {
+                            Vec16<T> vv;
+                            vv.v = __builtin_bit_cast(decltype(vv.v), v);
+                            cnt += 1.f;
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) {
+                                const float f = vv.get(e);
+                                sS[e] += f;
+                                sQ[e] += f * f;
+                            }
+                        }
+                    }
                 }
             } else {
                 for (int i = lane; i < 32 * p.Cout; i += 64) {
@@ -183,6 +266,71 @@ __global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams 
                     if (c0 + pr < p.Wo) y[(size_t)pr * p.Cout + c] = *(const T*)(st + pr * SS + c * ES);
                 }
             }
+        }
+        if (next_ok) {
+            const int ihn = oh * p.s - p.p + p.KH;
+#pragma unroll
+            for (int t = 0; t < RP_MAXPF; ++t) {
+                const int i = tid + t * 256;
+                if (i < npf) {
+                    const int r = i / cpr_in, c = i - r * cpr_in;
+                    *(u32x4*)(ring + (size_t)((ihn + r + p.p) % RING) * p.PWE + c * CH) = pf[t];
+                }
+            }
+            __syncthreads();                                     // new rows visible; everyone is done with row oh
+        }
+        need_full = !next_ok;
+        if (++oh == p.Ho) { oh = 0; ++n; }
+    }
+    if constexpr (STATS) {
+        // lane -> (n, mean, M2) of its own values, then Chan merges: the 64 / CPRO lanes that share a channel group (xor
+        // shuffles), the 4 waves through LDS.  Fixed order: deterministic.
+        constexpr int CPRO = 64 * ES / 16;
+        float mean[CH], m2[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const float m = cnt > 0.f ? sS[e] / cnt : 0.f;
+            const float q = sQ[e] - sS[e] * m;
+            mean[e] = m;
+            m2[e] = q > 0.f ? q : 0.f;
+        }
+        float nn = cnt;
+#pragma unroll
+        for (int off = CPRO; off < 64; off <<= 1) {
+            const float nb = __shfl_xor(nn, off, 64);
+            const float nt = nn + nb;
+            const float wb = nt > 0.f ? nb / nt : 0.f;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const float mb = __shfl_xor(mean[e], off, 64), qb = __shfl_xor(m2[e], off, 64);
+                const float d = mb - mean[e];
+                m2[e] = m2[e] + qb + d * d * nn * wb;
+                mean[e] = mean[e] + d * wb;
+            }
+            nn = nt;
+        }
+        __syncthreads();                                         // the stage area is free now
+        float* red = (float*)stage;                              // [4 waves][64 ch][3]
+        if (lane < CPRO) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                float* o = red + ((size_t)wave * 64 + lane * CH + e) * 3;
+                o[0] = nn; o[1] = mean[e]; o[2] = m2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float na = 0.f, ma = 0.f, qa = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* o = red + ((size_t)w * 64 + tid) * 3;
+                const float nb = o[0], nt = na + nb, wb = nt > 0.f ? nb / nt : 0.f, d = o[1] - ma;
+                qa = qa + o[2] + d * d * na * wb;
+                ma = ma + d * wb;
+                na = nt;
+            }
+            float* o = p.stats + ((size_t)blockIdx.x * 64 + tid) * 3;
+            o[0] = na; o[1] = ma; o[2] = qa;
         }
     }
 }
@@ -351,6 +499,10 @@ __global__ void rowpatch_pack_kernel(const float* __restrict__ w, T* __restrict_
     }
 }
 
+size_t rp_fwd_lds(const RowPatchParams& p, int es) {
+    return (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + p.s + 1) * p.PWE * es + (size_t)4 * 32 * (64 * es + 16);
+}
+
 bool make_rp(const cnk_conv_desc* d, RowPatchParams* out) {
     RowPatchParams p = {};
     const int es = d->dtype == CNK_BF16 ? 2 : 4, ch = 16 / es;
@@ -373,7 +525,7 @@ bool make_rp(const cnk_conv_desc* d, RowPatchParams* out) {
     int need = PATCH_A0 + (p.W + p.p) * p.Cin + p.Rp + 2 * ch;
     p.PWE = (need + ch - 1) / ch * ch;
     p.rows_total = d->N * Ho;
-    size_t lds_f = (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + 1) * p.PWE * es + (size_t)4 * 32 * (64 * es + 16);
+    size_t lds_f = rp_fwd_lds(p, es);
     size_t lds_w = (size_t)(p.KH + 1) * p.PWE * es + (size_t)((Wo + 31) / 32 * 32) * (64 * es + (es == 2 ? 64 : 0));
     if (lds_f > 150 * 1024 || lds_w > 150 * 1024) return false;
     if (2 * (p.Kp / 32) > 4 * 6) return false;                   // wgrad accumulator budget (NBLK <= 6)
@@ -418,21 +570,41 @@ int rowpatch_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t
     return 0;
 }
 
-int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y,
+static int rp_fwd_grid(const RowPatchParams& p, int* rows_per_wg) {
+    // ~2048 workgroups, each a whole number of output rows; the weight image (64 x Kp) is staged once per workgroup
+    *rows_per_wg = rp_rows_per_wg(p, 2048);
+    return ceil_div(p.rows_total, *rows_per_wg);
+}
+
+int64_t rowpatch_fwd_stat_slices(const cnk_conv_desc* d) {
+    RowPatchParams p;
+    if (!make_rp(d, &p) || d->Cout != 64) return 0;      // the statistics ride on the 64-channel copy-out
+    int rpw;
+    return rp_fwd_grid(p, &rpw);
+}
+
+int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, float* stats,
                  hipStream_t s) {
     RowPatchParams p;
     make_rp(d, &p);
-    p.x = x; p.wpk = wpk; p.y = y; p.bias = bias;
-    p.rows_per_wg = rp_rows_per_wg(p, 4096);
-    int grid = ceil_div(p.rows_total, p.rows_per_wg);
-    const int es = d->dtype == CNK_BF16 ? 2 : 4;
-    size_t lds = (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + 1) * p.PWE * es + (size_t)4 * 32 * (64 * es + 16);
+    CNK_CHECK_ARG(!stats || d->Cout == 64, "cnk_conv2d_fwd: this conv shape cannot emit BN partials (cnk_conv2d_fwd_bn_partial_slices == 0)");
+    p.x = x; p.wpk = wpk; p.y = y; p.bias = bias; p.stats = stats;
+    int grid = rp_fwd_grid(p, &p.rows_per_wg);
+    const int es = d->dtype == CNK_BF16 ? 2 : 4, ch = 16 / es;
+    p.ksteps = ceil_div(p.KH * p.Rp, 2 * ch);
+    size_t lds = rp_fwd_lds(p, es);
+#define RP_FWD(TT, A4)                                                                                             \
+    do {                                                                                                           \
+        if (stats) hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, true>), dim3(grid), dim3(256), lds, s, p);      \
+        else hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, false>), dim3(grid), dim3(256), lds, s, p);           \
+    } while (0)
     if (d->dtype == CNK_BF16) {
-        if (rp_align4(d, p)) hipLaunchKernelGGL((rowpatch_fwd_kernel<bf16, true>), dim3(grid), dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((rowpatch_fwd_kernel<bf16, false>), dim3(grid), dim3(256), lds, s, p);
+        if (rp_align4(d, p)) RP_FWD(bf16, true);
+        else RP_FWD(bf16, false);
     } else {
-        hipLaunchKernelGGL((rowpatch_fwd_kernel<float, true>), dim3(grid), dim3(256), lds, s, p);
+        RP_FWD(float, true);
     }
+#undef RP_FWD
     CNK_CHECK_LAUNCH("rowpatch_fwd");
     return 0;
 }

@@ -234,63 +234,127 @@ def sample(t, n=16):
     return f[idx].numpy().copy()
 
 
+def relu_margin(model, x, small=32768):
+    """Smallest |ReLU input| of one training-mode forward, relative to that tensor's mean |input|, over the ReLU inputs
+    with at most `small` elements.  A pre-activation within fp32 rounding of zero makes the step's gradients depend on the
+    summation order of whoever evaluates it (the mask flips; in a 16 x 256 x 2 x 2 tensor ONE flip moves the layer's
+    gradients by 1e-2), so such a batch pins nothing element-wise: model_case() draws another batch instead."""
+    import torch.nn.functional as F
+    worst = [float('inf')]
+    orig = F.relu
+
+    def spy(inp, inplace=False):
+        if inp.numel() <= small:
+            a = inp.detach().abs()
+            worst[0] = min(worst[0], float(a.min() / a.mean()))
+        return orig(inp, inplace=False)
+    F.relu = spy
+    try:
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            model(x)
+        model.load_state_dict(state)                     # the probe must not advance the BN running statistics
+    finally:
+        F.relu = orig
+    return worst[0]
+
+
+MODEL_CASES = None
+
+
+def model_cases(basemodel, resnet, vggnet):
+    # batch 16: the last ResNet stage is 1x1 spatial at 32x32 input, so BN there sees only `batch`
+    # samples per channel; with fewer the normalised activations are too ill-conditioned to compare
+    return [('resnet26', resnet.ResNet, 26, (3, 32, 32), True, 16),
+            ('resnet18', resnet.ResNet, 18, (3, 32, 32), True, 16),
+            ('vgg11', vggnet.VGGNet, 11, (3, 32, 32), True, 16),
+            ('convnet', basemodel.ConvNet, 0, (1, 28, 28), False, 8),
+            ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16),
+            ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16),
+            ('inception', basemodel.inceptionnet_v1.InceptionNetV1, 1, (3, 32, 32), True, 16),
+            ('squeezenet', basemodel.squeezenet.SqueezeNet, 1.1, (3, 64, 64), True, 16),
+            ('densenet121', basemodel.densenet.DenseNet, 121, (3, 32, 32), True, 16),
+            ('seresnet26', basemodel.se_resnet.SEResNet, 26, (3, 32, 32), True, 16),
+            ('senet26', basemodel.senet.SENet, 26, (3, 32, 32), True, 16),
+            ('shufflenet_g4', basemodel.shufflenet_v1.ShuffleNetV1, 'g4', (3, 32, 32), True, 16),
+            ('sknet26', basemodel.sknet.SKNet, 26, (3, 32, 32), True, 16),
+            ('skresnet26', basemodel.sk_resnet.SKResNet, 26, (3, 32, 32), True, 16)]
+
+
+def model_case(settings, out, name, cls, kind, in_size, bn, bs, data_seeds=(21,), min_margin=0.0):
+    """One whole-model one-step trace into out[name/...].  data_seeds: batches to try in order; the first whose
+    relu_margin() reaches min_margin is used (recorded as name/data_seed, name/relu_margin)."""
+    s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
+                          batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)
+    for data_seed in data_seeds:
+        torch.manual_seed(21)                 # weights are re-drawn from this seed by the tests
+        model = cls(s)
+        model.init_optimizer()
+        g = torch.Generator().manual_seed(data_seed)
+        x = torch.randn(bs, *in_size, generator=g)
+        y = torch.randint(0, 10, (bs,), generator=g)
+        model.train()
+        margin = relu_margin(model, x)
+        if margin >= min_margin:
+            break
+        print('%-14s data seed %d: smallest |ReLU input| / mean %.2e, next batch' % (name, data_seed, margin))
+    else:
+        raise RuntimeError('%s: no batch with ReLU margin >= %g among seeds %s' % (name, min_margin, data_seeds))
+    out[f'{name}/data_seed'], out[f'{name}/relu_margin'] = np.array(data_seed), np.array(margin)
+    out[f'{name}/x'], out[f'{name}/targets'] = x.numpy(), y.numpy()
+    out[f'{name}/param_names'] = np.array([k for k, _ in model.named_parameters()])
+    out[f'{name}/init_norms'] = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+    # the reference's own step: basemodel.py:247 zero_grad, :275 training_step, :278 backward, :284 step
+    model.optimizer.zero_grad()
+    model.setting.device.move = lambda b: b            # CPU: DeviceMngr.move is the identity here
+    outputs = model(x)
+    loss = model.cost_function(outputs, y)
+    correct = model.score(outputs, y)
+    loss.backward()
+    out[f'{name}/logits'] = outputs.detach().numpy()
+    out[f'{name}/loss'] = np.array(float(loss))
+    out[f'{name}/correct'] = np.array(correct)
+    out[f'{name}/grad_norms'] = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    out[f'{name}/grad_samples'] = np.stack([np.resize(sample(p.grad), 16) for p in model.parameters()])
+    model.optimizer.step()
+    out[f'{name}/post_norms'] = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+    out[f'{name}/post_samples'] = np.stack([np.resize(sample(p), 16) for p in model.parameters()])
+    bufs = [(k, b) for k, b in model.named_buffers() if 'running' in k]
+    out[f'{name}/buf_names'] = np.array([k for k, _ in bufs])
+    out[f'{name}/buf_norms'] = np.array([float(b.double().norm()) for _, b in bufs])
+    out[f'{name}/n_params'] = np.array(sum(p.numel() for p in model.parameters()))
+    out[f'{name}/sd_keys'] = np.array(list(model.state_dict().keys()))
+    # second step's loss pins the optimizer update through the whole network
+    model.optimizer.zero_grad()
+    loss2 = model.cost_function(model(x), y)
+    out[f'{name}/loss2'] = np.array(float(loss2))
+    print('%-14s data seed %d, smallest |ReLU input| / mean %.2e' % (name, data_seed, margin))
+
+
+# Cases whose seed-21 batch has a ReLU input within fp32 rounding of zero in a small late-stage tensor (relu_margin):
+# they take the first later batch that keeps 5e-6 of the mean magnitude clear in every ReLU input of <= 32768 elements
+# (fp32 evaluations of these nets agree to ~1e-6 of it).  resnet18: 1.5e-6 at the output ReLU of the first 256-channel
+# block (16 x 256 x 2 x 2), flipped by any evaluation whose rounding differs by 13 ulp.
+REDRAWN = {'resnet18': dict(data_seeds=tuple(range(21, 1300, 100)), min_margin=5e-6)}
+
+
+def remake_model_case(settings, basemodel, resnet, vggnet, name):
+    """Regenerates ONE case of models.npz in place (the other arrays are carried over byte for byte)."""
+    path = os.path.join(HERE, 'models.npz')
+    old = np.load(path)
+    out = {k: old[k] for k in old.files if not k.startswith(name + '/')}
+    case = next(c for c in model_cases(basemodel, resnet, vggnet) if c[0] == name)
+    model_case(settings, out, *case, **REDRAWN.get(name, {}))
+    np.savez_compressed(path, **out)
+    print('models.npz: case %s rewritten (%d arrays)' % (name, len(out)))
+
+
 def make_models(settings, basemodel, resnet, vggnet):
     """Whole-model one-step traces: (logits, loss, correct, per-parameter grad norm + samples,
     post-Adam-step parameter norm + samples, BN running-stat norms) on the reference classes."""
     out = meta()
-    # batch 16: the last ResNet stage is 1x1 spatial at 32x32 input, so BN there sees only `batch`
-    # samples per channel; with fewer the normalised activations are too ill-conditioned to compare
-    cases = [('resnet26', resnet.ResNet, 26, (3, 32, 32), True, 16),
-             ('resnet18', resnet.ResNet, 18, (3, 32, 32), True, 16),
-             ('vgg11', vggnet.VGGNet, 11, (3, 32, 32), True, 16),
-             ('convnet', basemodel.ConvNet, 0, (1, 28, 28), False, 8),
-             ('mobilenet', basemodel.mobilenet_v1.MobileNetV1, 1, (3, 32, 32), True, 16),
-             ('resnext26', basemodel.resnext.ResNeXt, 26, (3, 32, 32), True, 16),
-             ('inception', basemodel.inceptionnet_v1.InceptionNetV1, 1, (3, 32, 32), True, 16),
-             ('squeezenet', basemodel.squeezenet.SqueezeNet, 1.1, (3, 64, 64), True, 16),
-             ('densenet121', basemodel.densenet.DenseNet, 121, (3, 32, 32), True, 16),
-             ('seresnet26', basemodel.se_resnet.SEResNet, 26, (3, 32, 32), True, 16),
-             ('senet26', basemodel.senet.SENet, 26, (3, 32, 32), True, 16),
-             ('shufflenet_g4', basemodel.shufflenet_v1.ShuffleNetV1, 'g4', (3, 32, 32), True, 16),
-             ('sknet26', basemodel.sknet.SKNet, 26, (3, 32, 32), True, 16),
-             ('skresnet26', basemodel.sk_resnet.SKResNet, 26, (3, 32, 32), True, 16)]
-    for name, cls, kind, in_size, bn, bs in cases:
-        s = settings.Settings(kind=kind, input_size=in_size, num_classes=10, batch_size=bs,
-                              batch_norm=bn, mixed_precision=False, dropout_rate=0, seed=21)
-        torch.manual_seed(21)                 # weights are re-drawn from this seed by the tests
-        model = cls(s)
-        model.init_optimizer()
-        g = torch.Generator().manual_seed(21)
-        x = torch.randn(bs, *in_size, generator=g)
-        y = torch.randint(0, 10, (bs,), generator=g)
-        model.train()
-        out[f'{name}/x'], out[f'{name}/targets'] = x.numpy(), y.numpy()
-        out[f'{name}/param_names'] = np.array([k for k, _ in model.named_parameters()])
-        out[f'{name}/init_norms'] = np.array([float(p.detach().double().norm()) for p in model.parameters()])
-        # the reference's own step: basemodel.py:247 zero_grad, :275 training_step, :278 backward, :284 step
-        model.optimizer.zero_grad()
-        model.setting.device.move = lambda b: b            # CPU: DeviceMngr.move is the identity here
-        outputs = model(x)
-        loss = model.cost_function(outputs, y)
-        correct = model.score(outputs, y)
-        loss.backward()
-        out[f'{name}/logits'] = outputs.detach().numpy()
-        out[f'{name}/loss'] = np.array(float(loss))
-        out[f'{name}/correct'] = np.array(correct)
-        out[f'{name}/grad_norms'] = np.array([float(p.grad.double().norm()) for p in model.parameters()])
-        out[f'{name}/grad_samples'] = np.stack([np.resize(sample(p.grad), 16) for p in model.parameters()])
-        model.optimizer.step()
-        out[f'{name}/post_norms'] = np.array([float(p.detach().double().norm()) for p in model.parameters()])
-        out[f'{name}/post_samples'] = np.stack([np.resize(sample(p), 16) for p in model.parameters()])
-        bufs = [(k, b) for k, b in model.named_buffers() if 'running' in k]
-        out[f'{name}/buf_names'] = np.array([k for k, _ in bufs])
-        out[f'{name}/buf_norms'] = np.array([float(b.double().norm()) for _, b in bufs])
-        out[f'{name}/n_params'] = np.array(sum(p.numel() for p in model.parameters()))
-        out[f'{name}/sd_keys'] = np.array(list(model.state_dict().keys()))
-        # second step's loss pins the optimizer update through the whole network
-        model.optimizer.zero_grad()
-        loss2 = model.cost_function(model(x), y)
-        out[f'{name}/loss2'] = np.array(float(loss2))
+    for case in model_cases(basemodel, resnet, vggnet):
+        model_case(settings, out, *case, **REDRAWN.get(case[0], {}))
     # architecture facts of the BASELINE configs (no weights): state_dict keys + parameter counts
     for name, cls, kind in [('resnet50', resnet.ResNet, 50), ('resnet152', resnet.ResNet, 152),
                             ('vgg16', vggnet.VGGNet, 16)]:
@@ -437,6 +501,9 @@ if __name__ == '__main__':
     settings, basemodel, resnet, vggnet = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'models2':
         make_models2(settings, resnet, vggnet)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == 'models-case':      # python make_golden.py models-case resnet18
+        remake_model_case(settings, basemodel, resnet, vggnet, sys.argv[2])
         sys.exit(0)
     make_ops(settings, basemodel)
     make_resblocks(settings, resnet)
