@@ -107,7 +107,28 @@ template <> struct RpMma<float> {
 // no exposed load latency.  A full refill happens at the first row of a workgroup and at image boundaries.
 // STATS: per-channel BN partial (n, mean, M2) of the ROUNDED outputs of this workgroup's rows, one slice per workgroup
 // (each lane sums its <= rows_per_wg * ceil(Wo/128) pixels, lanes / waves are merged with Chan's update).
-constexpr int RP_MAXPF = 2;          // prefetched 16-B chunks per thread and output row
+// The steady-state loop's vector memory operations are inline asm: hipcc then tracks none of them and inserts no
+// s_waitcnt vmcnt(0) at the loop head (it cannot count across the back edge, and loads and stores share the counter, so
+// its conservative wait drained every output store once per row).  The prefetch goes global -> LDS directly (LDS-DMA:
+// a wave fills 64 consecutive 16-byte chunks of a ring row, no registers for the compiler to shuffle while the data is
+// in flight); the one wait the loop needs -- DMA done before the row-end barrier -- is rp_wait_vm0(), placed BEFORE the
+// row's output stores are issued.
+#ifndef RP_ABL
+#define RP_ABL 0      // debug builds (tools/ablate_rp.sh): 1 no prefetch DMA, 2 one k-step, 4 no output stores, 8 no epilogue (k-loop
+                      // dies with it), 16 no statistics sums, 64 token epilogue (k-loop stays),
+                      // 32 no A-fragment reads, 128 no MFMA (a VALU op consumes the fragments)
+#endif
+typedef __attribute__((address_space(3))) unsigned char rp_lds_u8;
+__device__ __forceinline__ void rp_dma16(const void* g, uint32_t lds_addr) {          // M0 saved / restored inside
+    unsigned keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void rp_store16(void* g, const u32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(g), "v"(v) : "memory");
+}
+__device__ __forceinline__ void rp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T>
 __device__ __forceinline__ void rp_load_rows(const RowPatchParams& p, const T* x, T* ring, int n, int ih0, int nrows,
@@ -126,35 +147,69 @@ __device__ __forceinline__ void rp_load_rows(const RowPatchParams& p, const T* x
     }
 }
 
-template <typename T, bool ALIGN4, bool STATS>
-__global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams p) {
-    constexpr int CH = RpCfg<T>::CH, ES = (int)sizeof(T);
+// 8 waves per workgroup; a work item is (32-pixel chunk, 32-channel half of Cout) and item it goes to wave it % 8, so a wave
+// always works on the same channel half (it & 1 == wave & 1).  Per item: ksteps MFMAs 32x32, the 32 x 32 tile staged
+// wave-privately and copied out as 64-byte segments.
+constexpr int RP_FWD_WAVES = 4;
+
+// NS > 0: the K' loop is fully unrolled over NS = Kp / (2 CH) k-steps (the ResNet stem: 12, VGG's first conv: 4).  Where
+// the two k-chunks of a step start inside the ring depends on the output row only, so it is computed once per row with
+// scalar instructions (offA / offB below) and a lane spends one select and one add per step; the generic loop (NS == 0)
+// re-derives (kh, chunk) per lane and step -- ~25 vector instructions per MFMA, which made the kernel VALU-bound at a
+// quarter of its store-bandwidth floor.
+template <typename T, bool ALIGN4, bool STATS, int NS>
+__global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const RowPatchParams p) {
+    constexpr int CH = RpCfg<T>::CH, ES = (int)sizeof(T), NW = RP_FWD_WAVES;
+    constexpr int SS = 32 * ES + 16;                             // staged pixel row: this wave's 32 channels (+ pad)
+    constexpr int CPRO = 32 * ES / 16;                           // 16-B chunks per staged pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int WS = p.Kp * ES + 16;                               // weight row stride (odd # of 16-B slots)
     const int RING = p.KH + p.s;
-    unsigned char* Wl = smem;                                    // [64][WS]
+    unsigned char* Wl = smem;                                    // [Kp / (2 CH) k-steps][2 halves][2][32] x 16 B
     T* ring = (T*)(Wl + 64 * WS);                                // [RING + 1][PWE], last row all zero
-    unsigned char* stage = (unsigned char*)(ring + (size_t)(RING + 1) * p.PWE);   // [4 waves][32][64*ES+16]
+    unsigned char* stage = (unsigned char*)(ring + (size_t)(RING + 1) * p.PWE);   // [NW waves][32][SS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int half = wave & 1;                                   // channels half*32 .. half*32+31
     const T* x = (const T*)p.x;
     const T* wpk = (const T*)p.wpk;
     {
         const int cpr = p.Kp / CH;
-        for (int i = tid; i < 64 * cpr; i += 256) {
-            int r = i / cpr, c = i - r * cpr;
-            *(u32x4*)(Wl + r * WS + c * 16) = *(const u32x4*)(wpk + (size_t)r * p.Kp + c * CH);
+        // weights in MFMA-fragment order: the 16 bytes lane (l31, lh) of channel half h reads at k-step s sit at
+        // s*2048 + h*1024 + lh*512 + l31*16, so a wave's ds_read_b128 covers 1 KiB linearly (row-major rows of Kp
+        // elements put 4 lanes on every bank: the weight reads alone then cost more LDS cycles than the MFMAs)
+        for (int i = tid; i < 64 * cpr; i += 64 * NW) {
+            const int co = i / cpr, q = i - co * cpr;
+            *(u32x4*)(Wl + (q >> 1) * 2048 + (co >> 5) * 1024 + (q & 1) * 512 + (co & 31) * 16) =
+                *(const u32x4*)(wpk + (size_t)co * p.Kp + q * CH);
         }
-        for (int i = tid; i < p.PWE; i += 256) ring[(size_t)RING * p.PWE + i] = from_f32<T>(0.f);
+        for (int i = tid; i < p.PWE; i += 64 * NW) ring[(size_t)RING * p.PWE + i] = from_f32<T>(0.f);
     }
     const int nsteps = p.ksteps;                                 // MFMA k-steps that hold real taps (two chunks each)
     const int cps = p.Rp / CH;                                   // chunks per kh run
-    const int SS = 64 * ES + 16;
+    // NS > 0: this wave's weight fragments (its channel half, all k-steps) stay in registers for the whole workgroup --
+    // with them in LDS every MFMA needed 2 KiB of LDS reads and the kernel ran at the LDS port's rate, not the MFMA's
+    u32x4 wreg[NS > 0 ? NS : 1];
+    if constexpr (NS > 0) {
+        __syncthreads();
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) wreg[sidx] = *(const u32x4*)(Wl + sidx * 2048 + half * 1024 + lh * 512 + l31 * 16);
+    }
+    // bias of this lane's 16 output channels (4 groups of 4)
+    f32x4 breg[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = half * 32 + 8 * gq + 4 * lh + e;
+            breg[gq][e] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        }
     unsigned char* st = stage + wave * 32 * SS;
     const int row0 = blockIdx.x * p.rows_per_wg;
     const int nrows = min(p.rows_per_wg, p.rows_total - row0);
     const int cpr_in = p.PWE / CH, data0 = PATCH_A0 / CH, data1 = data0 + (p.W * p.Cin) / CH;
-    const int npf = p.s * cpr_in;                                // chunks the next output row adds
-    const bool incremental = npf <= 256 * RP_MAXPF;
+    const int segs = (cpr_in + 63) / 64;                         // 64-chunk segments per input row
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(rp_lds_u8*)ring;
+    const int nitems = 2 * ((p.Wo + 31) / 32);
     // STATS (Cout == 64): in the copy-out every lane always moves the same 16-byte channel group (lane % CPRO) of pixels
     // lane / CPRO + k * (64 / CPRO): its sums cover CH channels
     float sS[CH], sQ[CH], cnt = 0.f;
@@ -171,83 +226,119 @@ __global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams 
             rp_load_rows<T>(p, x, ring, n, oh * p.s - p.p, p.KH, RING);
             __syncthreads();
         }
-        const bool next_ok = incremental && rr + 1 < nrows && oh + 1 < p.Ho;
-        u32x4 pf[RP_MAXPF];
+        const bool next_ok = rr + 1 < nrows && oh + 1 < p.Ho;
         if (next_ok) {
-            const int ihn = oh * p.s - p.p + p.KH;               // first of the s rows row oh + 1 adds
-#pragma unroll
-            for (int t = 0; t < RP_MAXPF; ++t) {
-                const int i = tid + t * 256;
-                pf[t] = u32x4{0, 0, 0, 0};
-                if (i < npf) {
-                    const int r = i / cpr_in, c = i - r * cpr_in, ih = ihn + r;
-                    if ((unsigned)ih < (unsigned)p.H && c >= data0 && c < data1)
-                        pf[t] = *(const u32x4*)(x + ((size_t)(n * p.H + ih) * p.W) * p.Cin + (size_t)(c - data0) * CH);
+            // the s input rows that output row oh + 1 adds: wave-sized segments of 64 chunks, dealt to the waves
+            const int ihn = oh * p.s - p.p + p.KH;
+            for (int it = wave; it < p.s * segs; it += NW) {
+                const int r = it / segs, c = (it - r * segs) * 64 + lane, ih = ihn + r;
+                const int slot = (ihn + r + p.p) % RING;
+                unsigned char* rowl = (unsigned char*)(ring + (size_t)slot * p.PWE);
+                if (c < cpr_in) {
+                    if (!(RP_ABL & 1) && (unsigned)ih < (unsigned)p.H && c >= data0 && c < data1)
+                        rp_dma16(x + ((size_t)(n * p.H + ih) * p.W) * p.Cin + (size_t)(c - data0) * CH,
+                                 ring_lds + (uint32_t)((size_t)slot * p.PWE * ES) + (uint32_t)(c - lane) * 16);
+                    else
+                        *(u32x4*)(rowl + c * 16) = u32x4{0, 0, 0, 0};      // padding columns / rows outside the image
                 }
             }
         }
         const int base = (oh * p.s) % RING;                      // slot of this row's kh = 0
-        for (int c0 = wave * 32; c0 < p.Wo; c0 += 128) {
+        bool dma_done = false;
+        int offA[NS > 0 ? NS : 1], offB[NS > 0 ? NS : 1];        // byte offset in the ring of k-chunk 2s / 2s+1 (uniform)
+        if constexpr (NS > 0) {
+            int kh = 0, jc = 0, slot = base;
+#pragma unroll
+            for (int q = 0; q < 2 * NS; ++q) {
+                const int off = (kh < p.KH ? slot : RING) * (p.PWE * ES) + jc * 16;
+                if (q & 1) offB[q >> 1] = off; else offA[q >> 1] = off;
+                if (++jc == cps) {
+                    jc = 0;
+                    ++kh;
+                    if (++slot == RING) slot = 0;
+                }
+            }
+        }
+        for (int it = wave; it < nitems; it += NW) {
+            const int c0 = (it >> 1) * 32;
             const int ow = c0 + l31;
             const int owc = ow < p.Wo ? ow : p.Wo - 1;           // clamp: reads stay inside the ring row
             const int e0 = PATCH_A0 - p.p * p.Cin - p.lead + owc * p.s * p.Cin;
-            f32x16 acc[2];
+            f32x16 acc;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if constexpr (NS > 0) {
+                const unsigned char* arow = (const unsigned char*)ring;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                for (int sidx = 0; sidx < ((RP_ABL & 2) ? 1 : NS); ++sidx) {
+                    u32x4 fa;
+                    if (RP_ABL & 32) fa = u32x4{(unsigned)e0, (unsigned)sidx, 0x3f803f80u, 0x3f803f80u};
+                    else fa = read_chunk<T, ALIGN4>((const T*)(arow + (lh ? offB[sidx] : offA[sidx])), e0);
+                    if (RP_ABL & 128) acc[sidx & 15] += __builtin_bit_cast(float, fa[0] ^ fa[1] ^ fa[2] ^ fa[3] ^ wreg[sidx][0]);
+                    else RpMma<T>::run(acc, wreg[sidx], fa);     // transposed: rows = co, cols = pixels
+                }
+            } else {
             // this lane's k-chunk q = 2*step + lh walks (kh, chunk-in-run); fragments of step+1 are read before the
-            // MFMAs of step
+            // MFMA of step
             int kh = lh / cps, jc = lh - kh * cps;
             auto frag_a = [&]() {
                 int slot = kh < p.KH ? base + kh : RING;
                 slot = (slot >= RING && kh < p.KH) ? slot - RING : slot;
                 return read_chunk<T, ALIGN4>(ring + (size_t)slot * p.PWE, e0 + jc * CH);
             };
-            const unsigned char* wrow = Wl + l31 * WS + lh * 16;
+            const unsigned char* wrow = Wl + half * 1024 + lh * 512 + l31 * 16;
             u32x4 fa = frag_a();
-            u32x4 fb0 = *(const u32x4*)(wrow), fb1 = *(const u32x4*)(wrow + 32 * WS);
-            for (int sidx = 0; sidx < nsteps; ++sidx) {
-                const u32x4 ca = fa, cb0 = fb0, cb1 = fb1;
+            u32x4 fb = *(const u32x4*)(wrow);
+            for (int sidx = 0; sidx < ((RP_ABL & 2) ? 1 : nsteps); ++sidx) {
+                const u32x4 ca = fa, cb = fb;
                 if (sidx + 1 < nsteps) {
                     jc += 2;
                     while (jc >= cps) { jc -= cps; ++kh; }
-                    wrow += 32;
+                    wrow += 2048;
                     fa = frag_a();
-                    fb0 = *(const u32x4*)(wrow);
-                    fb1 = *(const u32x4*)(wrow + 32 * WS);
+                    fb = *(const u32x4*)(wrow);
                 }
-                RpMma<T>::run(acc[0], cb0, ca);                  // transposed: rows = co, cols = pixels
-                RpMma<T>::run(acc[1], cb1, ca);
+                RpMma<T>::run(acc, cb, ca);                      // transposed: rows = co, cols = pixels
             }
-            // lane (pixel l31, lh) holds channels j*32 + 8g + 4lh + {0..3} in regs 4g..4g+3
+            }
+            if (next_ok && !dma_done) {
+                dma_done = true;
+                rp_wait_vm0();        // before this item's output stores: waiting later would also wait for their round trip
+            }
+            if (RP_ABL & 8) continue;
+            if (RP_ABL & 64) {                                   // keep the MFMA loop alive with a token epilogue
+                float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int r = 0; r < 16; ++r) t += acc[r];
+                if (t == 12345.678f) ((float*)p.y)[0] = t;
+                continue;
+            }
+            // lane (pixel l31, lh) holds channels half*32 + 8g + 4lh + {0..3} in regs 4g..4g+3
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int col = j * 32 + 8 * gq + 4 * lh;
-                    float v[4];
+            for (int gq = 0; gq < 4; ++gq) {
+                const int col = 8 * gq + 4 * lh;                 // within this wave's half
+                float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * gq + e] + (p.bias ? p.bias[min(col + e, p.Cout - 1)] : 0.f);
-                    if constexpr (ES == 2) {
-                        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *(bf16x4*)(st + l31 * SS + col * 2) = o;
-                    } else {
-                        f32x4 o = {v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(st + l31 * SS + col * 4) = o;
-                    }
+                for (int e = 0; e < 4; ++e) v[e] = acc[4 * gq + e] + breg[gq][e];
+                if constexpr (ES == 2) {
+                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *(bf16x4*)(st + l31 * SS + col * 2) = o;
+                } else {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(st + l31 * SS + col * 4) = o;
                 }
+            }
             // wave-private staging: no workgroup barrier needed, only this wave's own LDS ordering
             __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
-            T* y = (T*)p.y + ((size_t)row * p.Wo + c0) * p.Cout;
+            T* y = (T*)p.y + ((size_t)row * p.Wo + c0) * p.Cout + half * 32;
             if (p.Cout == 64) {
-                constexpr int CPRO = 64 * ES / 16;               // 16-B chunks per output pixel
+#pragma unroll
                 for (int i = lane; i < 32 * CPRO; i += 64) {
-                    int pr = i / CPRO, c = i - pr * CPRO;
+                    const int pr = i / CPRO, c = i - pr * CPRO;
                     if (c0 + pr < p.Wo) {
                         const u32x4 v = *(const u32x4*)(st + pr * SS + c * 16);
-                        *(u32x4*)((unsigned char*)y + (size_t)pr * 64 * ES + c * 16) = v;
-                        if constexpr (STATS) {
+                        if (!(RP_ABL & 4)) rp_store16((unsigned char*)y + (size_t)pr * 64 * ES + c * 16, v);
+                        if constexpr (STATS && !(RP_ABL & 16)) {
                             Vec16<T> vv;
                             vv.v = __builtin_bit_cast(decltype(vv.v), v);
                             cnt += 1.f;
@@ -261,31 +352,27 @@ __global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams 
                     }
                 }
             } else {
-                for (int i = lane; i < 32 * p.Cout; i += 64) {
-                    int pr = i / p.Cout, c = i - pr * p.Cout;
+                const int nc = min(32, p.Cout - half * 32);      // this half's live channels (<= 0: none)
+                for (int i = lane; i < 32 * nc; i += 64) {
+                    int pr = i / nc, c = i - pr * nc;
                     if (c0 + pr < p.Wo) y[(size_t)pr * p.Cout + c] = *(const T*)(st + pr * SS + c * ES);
                 }
             }
         }
         if (next_ok) {
-            const int ihn = oh * p.s - p.p + p.KH;
-#pragma unroll
-            for (int t = 0; t < RP_MAXPF; ++t) {
-                const int i = tid + t * 256;
-                if (i < npf) {
-                    const int r = i / cpr_in, c = i - r * cpr_in;
-                    *(u32x4*)(ring + (size_t)((ihn + r + p.p) % RING) * p.PWE + c * CH) = pf[t];
-                }
-            }
-            __syncthreads();                                     // new rows visible; everyone is done with row oh
+            if (!dma_done) rp_wait_vm0();                        // a wave without an item in this row
+            // new rows visible, everyone done with row oh.  Only the LDS traffic is waited for: the output stores of this
+            // row stay in flight across the barrier (__syncthreads would drain them)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
         need_full = !next_ok;
         if (++oh == p.Ho) { oh = 0; ++n; }
     }
     if constexpr (STATS) {
         // lane -> (n, mean, M2) of its own values, then Chan merges: the 64 / CPRO lanes that share a channel group (xor
-        // shuffles), the 4 waves through LDS.  Fixed order: deterministic.
-        constexpr int CPRO = 64 * ES / 16;
+        // shuffles), the 4 waves of this channel half through LDS.  Fixed order: deterministic.
         float mean[CH], m2[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
@@ -310,11 +397,11 @@ __global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams 
             nn = nt;
         }
         __syncthreads();                                         // the stage area is free now
-        float* red = (float*)stage;                              // [4 waves][64 ch][3]
+        float* red = (float*)stage;                              // [NW waves][32 ch][3]
         if (lane < CPRO) {
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-                float* o = red + ((size_t)wave * 64 + lane * CH + e) * 3;
+                float* o = red + ((size_t)wave * 32 + lane * CH + e) * 3;
                 o[0] = nn; o[1] = mean[e]; o[2] = m2[e];
             }
         }
@@ -322,8 +409,8 @@ __global__ __launch_bounds__(256) void rowpatch_fwd_kernel(const RowPatchParams 
         if (tid < 64) {
             float na = 0.f, ma = 0.f, qa = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float* o = red + ((size_t)w * 64 + tid) * 3;
+            for (int w = (tid >> 5); w < NW; w += 2) {           // the waves of channel half tid / 32
+                const float* o = red + ((size_t)w * 32 + (tid & 31)) * 3;
                 const float nb = o[0], nt = na + nb, wb = nt > 0.f ? nb / nt : 0.f, d = o[1] - ma;
                 qa = qa + o[2] + d * d * na * wb;
                 ma = ma + d * wb;
@@ -500,7 +587,7 @@ __global__ void rowpatch_pack_kernel(const float* __restrict__ w, T* __restrict_
 }
 
 size_t rp_fwd_lds(const RowPatchParams& p, int es) {
-    return (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + p.s + 1) * p.PWE * es + (size_t)4 * 32 * (64 * es + 16);
+    return (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + p.s + 1) * p.PWE * es + (size_t)RP_FWD_WAVES * 32 * (32 * es + 16);
 }
 
 bool make_rp(const cnk_conv_desc* d, RowPatchParams* out) {
@@ -593,10 +680,17 @@ int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const f
     const int es = d->dtype == CNK_BF16 ? 2 : 4, ch = 16 / es;
     p.ksteps = ceil_div(p.KH * p.Rp, 2 * ch);
     size_t lds = rp_fwd_lds(p, es);
+#define RP_FWD_NS(TT, A4, NSV)                                                                                      \
+    do {                                                                                                           \
+        if (stats) hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, true, NSV>), dim3(grid), dim3(64 * RP_FWD_WAVES), lds, s, p); \
+        else hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, false, NSV>), dim3(grid), dim3(64 * RP_FWD_WAVES), lds, s, p);      \
+    } while (0)
 #define RP_FWD(TT, A4)                                                                                             \
     do {                                                                                                           \
-        if (stats) hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, true>), dim3(grid), dim3(256), lds, s, p);      \
-        else hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, false>), dim3(grid), dim3(256), lds, s, p);           \
+        const int ns = p.Kp / (2 * ch);                                                                            \
+        if (ns == 12 && p.Rp / ch >= 2) RP_FWD_NS(TT, A4, 12);                                                     \
+        else if (ns == 4 && p.Rp / ch >= 2) RP_FWD_NS(TT, A4, 4);                                                  \
+        else RP_FWD_NS(TT, A4, 0);                                                                                 \
     } while (0)
     if (d->dtype == CNK_BF16) {
         if (rp_align4(d, p)) RP_FWD(bf16, true);
@@ -604,6 +698,7 @@ int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const f
     } else {
         RP_FWD(float, true);
     }
+#undef RP_FWD_NS
 #undef RP_FWD
     CNK_CHECK_LAUNCH("rowpatch_fwd");
     return 0;
