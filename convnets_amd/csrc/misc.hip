@@ -42,7 +42,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ scale = nullptr,
                                                           const float* __restrict__ shift = nullptr, int relu = 0) {
     const int cols = p.C / VEC;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+    // blocks are dealt to the 8 XCDs round-robin: walk the tensor so that each XCD gets a CONTIGUOUS run of every grid
+    // sweep -- neighbouring output rows share input rows, which then hit in that XCD's L2 (r02c FETCH_SIZE: 626 MB per
+    // launch for a 411 MB input with the interleaved walk).  The stem pool itself is VALU-bound (9 taps x 8 channels of
+    // affine + ReLU + rounding + arg-max per thread): its time did not move.
+    const int g8 = gridDim.x & ~7;
+    const int lb = (int)blockIdx.x < g8 ? ((int)blockIdx.x & 7) * (g8 >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    for (int64_t i = (int64_t)lb * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t pix = fd_div((uint32_t)i, p.fd_cols), vc = (uint32_t)i - pix * cols;
         uint32_t t = fd_div(pix, p.fd_wo), wo = pix - t * p.Wo;
@@ -163,7 +169,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                                                           T* __restrict__ dx, PoolParams p,
                                                           int64_t total) {
     const int cols = p.C / VEC;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+    const int g8 = gridDim.x & ~7;                               // XCD-contiguous walk, as in maxpool_fwd_kernel
+    const int lb = (int)blockIdx.x < g8 ? ((int)blockIdx.x & 7) * (g8 >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    for (int64_t i = (int64_t)lb * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t pix = fd_div((uint32_t)i, p.fd_cols), vc = (uint32_t)i - pix * cols;
         uint32_t t = fd_div(pix, p.fd_w), w = pix - t * p.W;

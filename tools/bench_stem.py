@@ -42,9 +42,18 @@ def gather(i):
     assert lib.cnk_bn_bwd_maxpool(P(dys[j]), P(idxs[j]), P(xs[j]), P(gamma), P(beta), P(sm), P(si), P(dx), P(dg), P(db), 0, N, H, W, C, k, k, s, s, p, p, 1, code, P(ws), nws, st) == 0, lib.cnk_last_error()
 
 
-times = {'pair': [], 'gather': []}
+ypool = torch.empty(N, Ho, Wo, C, dtype=torch.bfloat16, device='cuda')
+ipool = torch.empty(N, Ho, Wo, C, dtype=torch.uint8, device='cuda')
+
+
+def poolfwd(i):
+    j = i % COP
+    assert lib.cnk_maxpool2d_fwd_bn(P(xs[j]), ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(ws.data_ptr() + 4 * C), 1, P(ypool), P(ipool), N, H, W, C, k, k, s, s, p, p, code, st) == 0
+
+
+times = {'pair': [], 'gather': [], 'poolfwd': []}
 for rnd in range(4):
-    for name, fn in (('pair', pair), ('gather', gather)):
+    for name, fn in (('pair', pair), ('gather', gather), ('poolfwd', poolfwd)):
         fn(0); fn(1)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
