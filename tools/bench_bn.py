@@ -1,44 +1,65 @@
-"""BN forward/backward through the C ABI at the ResNet-50 bs=256 shapes (tuning aid): time per call and
-algorithmic GB/s; per-kernel split comes from running it under rocprofv3 --kernel-trace --stats."""
-import ctypes, sys, os
+"""BN backward (unfused: reduce + final + apply) and BN statistics on the block-output shapes of ResNet-50 at batch 256, bf16,
+cold operands; two builds of libcnk interleaved in one process when CNK_LIB_B is given (A = the in-tree build).
+    [CNK_LIB_B=path/to/other/libcnk.so] python tools/bench_bn.py"""
+import ctypes, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from convnets_amd import ops, _lib
-lib = _lib.load()
+from convnets_amd import _lib
+libs = {'A': _lib.load()}
+if os.environ.get('CNK_LIB_B'):
+    b = ctypes.CDLL(os.environ['CNK_LIB_B'])
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(b, name)
+        fn.restype, fn.argtypes = res, args
+    libs['B'] = b
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+code = _lib.CNK_BF16
 N = 256
-P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-def timeit(fn, iters=20):
-    fn(); fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
-tot = {}
-for C, H, cnt in [(64, 112, 1), (64, 56, 6), (256, 56, 4), (128, 28, 8), (512, 28, 5), (256, 14, 12), (1024, 14, 7), (512, 7, 6), (2048, 7, 4)]:
+tot = {k: [0.0, 0.0] for k in libs}
+for C, H in ((256, 56), (512, 28), (1024, 14), (2048, 7)):
     M = N * H * H
-    x = torch.randn(M, C, device='cuda', dtype=torch.bfloat16)
-    res = torch.randn_like(x); y = torch.empty_like(x); dy = torch.randn_like(x); dx = torch.empty_like(x)
-    g, b = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda') * 0.1
-    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
-    sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
-    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-    ws = ops.workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
-    mask = torch.empty(lib.cnk_bn_mask_bytes(M, C, 1), dtype=torch.uint8, device='cuda')
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    nsl = (M + 127) // 128
-    part = torch.empty(nsl, C, 3, device='cuda')
-    part[:, :, 0] = 128; part[:, :, 1] = 0; part[:, :, 2] = 128
-    E = M * C * 2
-    for mode, r, mk in (('relu', None, None), ('add+relu', res, mask)):
-        f = lambda: _lib.check(lib.cnk_bn_fwd_train(P(x), P(g), P(b), P(r), P(y), P(mk), P(rm), P(rv), P(sm), P(si), P(part), nsl,
-                                                    M, C, 1e-5, 0.1, 1, 1, P(ws), ws.numel(), st))
-        w = lambda: _lib.check(lib.cnk_bn_bwd(P(dy), P(x), None, P(mk), P(g), P(b), P(sm), P(si), P(dx), None, P(dg), P(db), 1, None, 0,
-                                              M, C, 1, 1, P(ws), ws.numel(), st))
-        tf, tb = timeit(f), timeit(w)
-        nf = 2 + (1 if r is not None else 0)
-        print('bn C=%4d @%3d %-8s | fwd %7.1f us %5.0f GB/s | bwd %7.1f us %5.0f GB/s' % (C, H, mode, tf, nf * E / tf / 1e3, tb, 5 * E / tb / 1e3), flush=True)
-        if mode == 'relu' or C in (256, 512, 1024, 2048):
-            k = cnt if mode == 'relu' else {256: 3, 512: 4, 1024: 6, 2048: 3}.get(C, 0) if H in (56, 28, 14, 7) else 0
-            tot['fwd'] = tot.get('fwd', 0) + k * tf; tot['bwd'] = tot.get('bwd', 0) + k * tb
-print('weighted ResNet-50-like total: fwd %.2f ms  bwd %.2f ms' % (tot['fwd'] / 1e3, tot['bwd'] / 1e3))
+    per = M * C * 2
+    cop = max(2, min(8, int(1.2e9 // (3 * per)) + 1))
+    xs = [torch.randn(M, C, device='cuda').bfloat16() for _ in range(cop)]
+    dys = [torch.randn(M, C, device='cuda').bfloat16() for _ in range(cop)]
+    dx = torch.empty_like(xs[0])
+    gamma, beta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+    sm, si = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    lib0 = libs['A']
+    nws = lib0.cnk_bn_workspace_bytes(M, C)
+    ws = torch.empty(nws // 4 + 4, device='cuda')
+
+    def bwd(lib, i):
+        assert lib.cnk_bn_bwd(P(dys[i % cop]), P(xs[i % cop]), None, None, P(gamma), P(beta), P(sm), P(si), P(dx), None, P(dg), P(db), 0,
+                              None, 0, M, C, 0, code, P(ws), nws, st) == 0
+
+    def stats(lib, i):
+        assert lib.cnk_bn_fwd_train(P(xs[i % cop]), P(gamma), P(beta), None, None, None, None, None, P(sm), P(si), None, 0, M, C, 1e-5, 0.1,
+                                    0, code, P(ws), nws, st) == 0
+    out = []
+    for k, lib in libs.items():
+        pass
+    times = {(k, n): [] for k in libs for n in ('bwd', 'stats')}
+    for rnd in range(5):
+        for k, lib in libs.items():
+            for n, fn in (('bwd', bwd), ('stats', stats)):
+                fn(lib, 0); fn(lib, 1)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reps = 3 * cop
+                for i in range(reps):
+                    fn(lib, i + 2)
+                e1.record()
+                torch.cuda.synchronize()
+                times[(k, n)].append(e0.elapsed_time(e1) * 1000 / reps)
+    line = '%5d ch @%3d^2:' % (C, H)
+    for k in libs:
+        b_, s_ = statistics.median(times[(k, 'bwd')]), statistics.median(times[(k, 'stats')])
+        tot[k][0] += b_; tot[k][1] += s_
+        line += '   %s  backward %6.1f us (%.2f TB/s over 5 passes)  statistics %6.1f us (%.2f TB/s)' % (k, b_, 5 * per / b_ / 1e6, s_, per / s_ / 1e6)
+    print(line, flush=True)
+for k in libs:
+    print('sum %s: backward %.1f us, statistics %.1f us' % (k, tot[k][0], tot[k][1]))
