@@ -116,7 +116,8 @@ template <> struct RpMma<float> {
 #ifndef RP_ABL
 #define RP_ABL 0      // debug builds (tools/ablate_rp.sh): 1 no prefetch DMA, 2 one k-step, 4 no output stores, 8 no epilogue (k-loop
                       // dies with it), 16 no statistics sums, 64 token epilogue (k-loop stays),
-                      // 32 no A-fragment reads, 128 no MFMA (a VALU op consumes the fragments)
+                      // 32 no A-fragment reads, 128 no MFMA (a VALU op consumes the fragments); weight gradient: 256 no patch element
+                      // reads, 512 no MFMA, 1024 operands staged for the first row only
 #endif
 typedef __attribute__((address_space(3))) unsigned char rp_lds_u8;
 __device__ __forceinline__ void rp_dma16(const void* g, uint32_t lds_addr) {          // M0 saved / restored inside
@@ -443,15 +444,27 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     for (int i = tid; i < p.PWE; i += 256) patch[(size_t)p.KH * p.PWE + i] = from_f32<T>(0.f);
+    // column k' = nj*32 + lane%32 of block b: where its kh run starts inside the patch (element offset), once per kernel
+    // (the division by the run length used to sit in the innermost loop: ~40 VALU instructions per MFMA)
+    int koff[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int kp = ((wave + 4 * b) >> 1) * 32 + (lane & 31);
+        int kh = kp / p.Rp;
+        const int jj = kp - kh * p.Rp;
+        kh = kh < p.KH ? kh : p.KH;
+        koff[b] = kh * p.PWE + (PATCH_A0 - p.p * p.Cin - p.lead + jj);
+    }
     const int row0 = blockIdx.x * p.rows_per_wg;
     for (int rr = 0; rr < p.rows_per_wg; ++rr) {
         const int row = row0 + rr;
         if (row >= p.rows_total) break;
         const int n = row / p.Ho, oh = row - n * p.Ho;
         __syncthreads();
-        load_patch<T>(p, x, patch, n, oh * p.s - p.p, p.KH);
+        if (!(RP_ABL & 1024) || rr == 0) load_patch<T>(p, x, patch, n, oh * p.s - p.p, p.KH);
         // dy row -> LDS [px][64 co], zero beyond Wo / Cout
-        if (p.Cout == 64) {
+        if ((RP_ABL & 1024) && rr > 0) {
+        } else if (p.Cout == 64) {
             constexpr int CPR = 64 * ES / 16;
             for (int i = tid; i < WoPad * CPR; i += 256) {
                 int pr = i / CPR, c = i - pr * CPR;
@@ -488,23 +501,19 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
                             s16x8 w8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             bf16x8 fa = __builtin_bit_cast(bf16x8, w8);
                             // B: column k' = nj*32 + l31 of the virtual im2col, pixels prow..prow+7
-                            const int kp = nj * 32 + l31;
-                            int kh = kp / p.Rp;
-                            const int jj = kp - kh * p.Rp;
-                            kh = kh < p.KH ? kh : p.KH;
-                            const unsigned short* prw = (const unsigned short*)(patch + (size_t)kh * p.PWE) +
-                                                        (PATCH_A0 - p.p * p.Cin - p.lead + jj);
+                            const unsigned short* prw = (const unsigned short*)patch + koff[b];
                             const int stp = p.s * p.Cin;
                             unsigned short e[8];
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 int px = prow + u;
                                 px = px < p.Wo ? px : p.Wo - 1;   // dy is zero there; keep the read in range
-                                e[u] = prw[px * stp];
+                                e[u] = (RP_ABL & 256) ? (unsigned short)(px + u) : prw[px * stp];
                             }
                             u32x4 fbv = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
                                          (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, fbv), acc[b], 0, 0, 0);
+                            if (RP_ABL & 512) acc[b][ss] += __builtin_bit_cast(float, fbv[0] ^ fbv[1] ^ fbv[2] ^ fbv[3] ^ (unsigned)w8[0] ^ (unsigned)w8[5]);
+                            else acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, fbv), acc[b], 0, 0, 0);
                         }
                     }
                 }
@@ -519,11 +528,7 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
                         if (blk < nblk) {
                             const int mi = blk & 1, nj = blk >> 1;
                             float fa = *(const float*)(Dl + px * DS + (mi * 32 + l31) * 4);
-                            const int kp = nj * 32 + l31;
-                            int kh = kp / p.Rp;
-                            const int jj = kp - kh * p.Rp;
-                            kh = kh < p.KH ? kh : p.KH;
-                            float fb = ((const float*)(patch + (size_t)kh * p.PWE))[PATCH_A0 - p.p * p.Cin - p.lead + jj + pxc * p.s * p.Cin];
+                            float fb = ((const float*)patch)[koff[b] + pxc * p.s * p.Cin];
                             acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[b], 0, 0, 0);
                         }
                     }
@@ -547,24 +552,35 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
     }
 }
 
-// dw[co][ci][kh][kw] (+)= sum_wg slab[wg][co][kh*Rp + lead + kw*Cin + ci]; 4 lanes per element
+// dw[co][ci][kh][kw] (+)= sum_wg slab[wg][co][kh*Rp + lead + kw*Cin + ci]; LPE lanes per element, each sums every LPE-th
+// slab in slab order, then a fixed xor tree: deterministic.  (16 lanes: the ~1000 slabs of the stem are 50 MB and an
+// element per 4 lanes left the chip mostly idle -- 80 us.)
+template <int LPE>
 __global__ __launch_bounds__(256) void rowpatch_reduce_kernel(const float* __restrict__ slab,
                                                               float* __restrict__ dw, int nslabs,
                                                               int Cout, int Cin, int KH, int KW, int Rp,
                                                               int lead, int Kp, int accumulate) {
-    const int total = Cout * Cin * KH * KW, q = threadIdx.x & 3;
-    const int total_r = (total + 63) / 64 * 64;
-    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < total_r; i += (gridDim.x * blockDim.x) >> 2) {
+    const int total = Cout * Cin * KH * KW, q = threadIdx.x & (LPE - 1);
+    const int per_wave = 64 / LPE, total_r = (total + per_wave - 1) / per_wave * per_wave;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPE; i < total_r; i += (gridDim.x * blockDim.x) / LPE) {
         const bool live = i < total;
         int ii = live ? i : 0;
         int kw = ii % KW, r1 = ii / KW;
         int kh = r1 % KH, r2 = r1 / KH;
         int ci = r2 % Cin, co = r2 / Cin;
         const float* sp = slab + (size_t)co * Kp + kh * Rp + lead + kw * Cin + ci;
-        float a = 0.f;
-        for (int s = q; s < nslabs; s += 4) a += sp[(size_t)s * 64 * Kp];
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s = q;
+        for (; s + 3 * LPE < nslabs; s += 4 * LPE) {              // four independent loads in flight
+            a0 += sp[(size_t)s * 64 * Kp];
+            a1 += sp[(size_t)(s + LPE) * 64 * Kp];
+            a2 += sp[(size_t)(s + 2 * LPE) * 64 * Kp];
+            a3 += sp[(size_t)(s + 3 * LPE) * 64 * Kp];
+        }
+        for (; s < nslabs; s += LPE) a0 += sp[(size_t)s * 64 * Kp];
+        float a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+        for (int o = 1; o < LPE; o <<= 1) a += __shfl_xor(a, o, 64);
         if (q == 0 && live) dw[ii] = accumulate ? dw[ii] + a : a;
     }
 }
@@ -741,9 +757,15 @@ int rowpatch_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float*
 #undef RP_LAUNCH
     CNK_CHECK_LAUNCH("rowpatch_wgrad");
     int total = d->Cout * d->Cin * d->kh * d->kw;
-    int rgrid = ceil_div(total * 4, 256);
-    hipLaunchKernelGGL(rowpatch_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)ws, dw, grid, d->Cout,
-                       d->Cin, d->kh, d->kw, p.Rp, p.lead, p.Kp, accumulate);
+    if (grid >= 256) {
+        int rgrid = ceil_div(total * 16, 256);
+        hipLaunchKernelGGL(rowpatch_reduce_kernel<16>, dim3(rgrid), dim3(256), 0, s, (const float*)ws, dw, grid, d->Cout,
+                           d->Cin, d->kh, d->kw, p.Rp, p.lead, p.Kp, accumulate);
+    } else {
+        int rgrid = ceil_div(total * 4, 256);
+        hipLaunchKernelGGL(rowpatch_reduce_kernel<4>, dim3(rgrid), dim3(256), 0, s, (const float*)ws, dw, grid, d->Cout,
+                           d->Cin, d->kh, d->kw, p.Rp, p.lead, p.Kp, accumulate);
+    }
     CNK_CHECK_LAUNCH("rowpatch_reduce");
     return 0;
 }
