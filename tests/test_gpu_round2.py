@@ -564,3 +564,19 @@ def test_first_layer_conv_forward_and_bn_partials(N, Cin, H, W, Cout, k, s, p, d
     yd = y.double().cpu()
     assert ((tmean - yd.mean((0, 2, 3))).abs().max() / yd.abs().mean()).item() < 2e-6
     assert ((tvar - yd.var((0, 2, 3), unbiased=False)).abs() / tvar).max().item() < 2e-5
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(5, 3, 32, 32), (2, 1, 28, 28), (3, 4, 6, 10), (2, 2, 8, 8), (2, 3, 5, 7), (3, 5, 8, 8),
+                                   (64, 3, 224, 224)])
+def test_input_layout_handoff(shape, dtype):
+    """cnk_nchw_to_nhwc (the NCHW fp32 batch -> NHWC `dtype` hand-off, basemodel.py:185-188): the four-pixels-per-thread
+    kernel for <= 4 planes with H*W % 4 == 0, and the element-wise one otherwise (odd H*W, 5 planes): bit-exact."""
+    from convnets_amd import ops
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(shape, generator=g)
+    out = ops.nchw_to_nhwc(x.cuda(), tdt)
+    torch.cuda.synchronize()
+    assert out.shape == x.shape and out.dtype == tdt and out.is_contiguous(memory_format=CL)
+    assert torch.equal(out.cpu(), x.to(tdt))
