@@ -252,6 +252,18 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const cnk_pack_job* __r
     // (one conv image has < 2^31 elements: 32-bit index arithmetic)
     const uint32_t total = (uint32_t)R * (uint32_t)j.ntaps * (uint32_t)Cred;
     const uint32_t base = (uint32_t)lb * 1024u;
+    if (!j.transpose && j.groups <= 1 && KK == 1 && j.ntaps == 1 && j.dtype == CNK_BF16 && (total & 7u) == 0 &&
+        (((uintptr_t)j.w | (uintptr_t)j.out) & 15) == 0) {
+        // 1x1 forward image = the master's own order: a cast.  Eight elements per thread (two 16-byte loads, one 16-byte
+        // store) instead of an index decomposition and a 2-byte store per element.
+        const uint32_t i = base + threadIdx.x * 8;
+        if (threadIdx.x < 128 && i < total) {
+            const f32x4 a = *(const f32x4*)(j.w + i), b = *(const f32x4*)(j.w + i + 4);
+            bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+            *(bf16x8*)((bf16*)j.out + i) = o;
+        }
+        return;
+    }
     const uint32_t ucred = (uint32_t)Cred, utaps = (uint32_t)j.ntaps;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

@@ -456,10 +456,61 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
         koff[b] = kh * p.PWE + (PATCH_A0 - p.p * p.Cin - p.lead + jj);
     }
     const int row0 = blockIdx.x * p.rows_per_wg;
+    // Operands of output row r + 1 are loaded into registers BEFORE row r is computed and written to LDS after it: the
+    // load latency hides behind the MFMA loop (it used to sit between two barriers of every row).  PFX / PFD chunks of
+    // 16 bytes per thread for the KH patch rows / the dy row; shapes that need more take the synchronous path.
+    constexpr int PFX = 3, PFD = 4, CPRD = 64 * ES / 16;
+    const int cpr = p.PWE / CH, xchunks = p.KH * cpr, dchunks = WoPad * CPRD;
+    const bool pf = p.Cout == 64 && xchunks <= 256 * PFX && dchunks <= 256 * PFD && !(RP_ABL & 1024);
+    int xlds[PFX], xrow[PFX], xcol[PFX];                         // this thread's patch chunks: LDS element offset, kh row, column
+#pragma unroll
+    for (int t = 0; t < PFX; ++t) {
+        const int i = tid + t * 256, r = i / cpr, c = i - r * cpr;
+        const int d0 = PATCH_A0 / CH, d1 = d0 + (p.W * p.Cin) / CH;
+        xrow[t] = i < xchunks ? r : -1;
+        xcol[t] = (c >= d0 && c < d1) ? (c - d0) * CH : -1;       // element offset inside the input row, -1: padding column
+        xlds[t] = r * p.PWE + c * CH;
+    }
+    u32x4 xr[PFX], dr[PFD];
+    auto prefetch = [&](int row) {
+        const int n = row / p.Ho, oh = row - n * p.Ho, ih0 = oh * p.s - p.p;
+#pragma unroll
+        for (int t = 0; t < PFX; ++t) {
+            xr[t] = u32x4{0, 0, 0, 0};
+            const int ih = ih0 + xrow[t];
+            if (xrow[t] >= 0 && xcol[t] >= 0 && (unsigned)ih < (unsigned)p.H)
+                xr[t] = *(const u32x4*)(x + ((size_t)(n * p.H + ih) * p.W) * p.Cin + xcol[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < PFD; ++t) {
+            const int i = tid + t * 256, pr = i / CPRD, c = i - pr * CPRD;
+            dr[t] = u32x4{0, 0, 0, 0};
+            if (i < dchunks && pr < p.Wo) dr[t] = *(const u32x4*)(dy + ((size_t)row * p.Wo + pr) * 64 + c * CH);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int t = 0; t < PFX; ++t)
+            if (xrow[t] >= 0) *(u32x4*)(patch + xlds[t]) = xr[t];
+#pragma unroll
+        for (int t = 0; t < PFD; ++t) {
+            const int i = tid + t * 256, pr = i / CPRD, c = i - pr * CPRD;
+            if (i < dchunks) *(u32x4*)(Dl + pr * DS + c * 16) = dr[t];
+        }
+    };
+    if (pf && row0 < p.rows_total) {
+        prefetch(row0);
+        commit();
+    }
     for (int rr = 0; rr < p.rows_per_wg; ++rr) {
         const int row = row0 + rr;
         if (row >= p.rows_total) break;
         const int n = row / p.Ho, oh = row - n * p.Ho;
+        const bool more = rr + 1 < p.rows_per_wg && row + 1 < p.rows_total;
+        if (pf) {
+            __syncthreads();                                     // this row's operands are in LDS
+            if (more) prefetch(row + 1);
+        } else {
         __syncthreads();
         if (!(RP_ABL & 1024) || rr == 0) load_patch<T>(p, x, patch, n, oh * p.s - p.p, p.KH);
         // dy row -> LDS [px][64 co], zero beyond Wo / Cout
@@ -481,6 +532,7 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
             }
         }
         __syncthreads();
+        }
         for (int c0 = 0; c0 < WoPad; c0 += 32) {
             if constexpr (ES == 2) {
                 const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
@@ -534,6 +586,10 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
                     }
                 }
             }
+        }
+        if (pf && more) {
+            __syncthreads();                                     // every wave is done with this row's operands
+            commit();
         }
     }
     const int l31 = lane & 31, lh = lane >> 5;
