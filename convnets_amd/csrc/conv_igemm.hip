@@ -418,9 +418,13 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
         }
     };
     for (int ks = 0; ks < nk; ++ks) {
+#if !(CNK_ABLATE & 2)
         issue();
+#endif
         __syncthreads();                             // vmcnt(0) + barrier: the tile has landed
+#if !(CNK_ABLATE & 1)
         compute();
+#endif
         __syncthreads();                             // every wave is done reading the only buffer
     }
     if (nk == 0) __syncthreads();

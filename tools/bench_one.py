@@ -9,7 +9,10 @@ from convnets_amd import ops
 CL = torch.channels_last
 lib = _lib.load()
 N = 256
-for Cin, Cout, k, s, p, H in [(128, 128, 3, 1, 1, 28), (64, 64, 3, 1, 1, 56), (256, 256, 3, 1, 1, 14), (256, 1024, 1, 1, 0, 14), (512, 128, 1, 1, 0, 28)]:
+SHAPES = [(128, 128, 3, 1, 1, 28), (64, 64, 3, 1, 1, 56), (256, 256, 3, 1, 1, 14), (256, 1024, 1, 1, 0, 14), (512, 128, 1, 1, 0, 28)]
+if os.environ.get('ONE_SHAPES') == '1x1':
+    SHAPES = [(256, 1024, 1, 1, 0, 14), (1024, 256, 1, 1, 0, 14), (1024, 512, 1, 1, 0, 14), (512, 2048, 1, 1, 0, 7), (2048, 512, 1, 1, 0, 7), (512, 128, 1, 1, 0, 28), (128, 512, 1, 1, 0, 28)]
+for Cin, Cout, k, s, p, H in SHAPES:
     x = torch.randn(N, Cin, H, H, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=CL)
     w = torch.randn(Cout, Cin, k, k, device='cuda') * 0.05
     desc = ops.make_desc(x.shape, w.shape, (s, s), (p, p), _lib.CNK_BF16)
