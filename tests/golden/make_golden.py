@@ -335,7 +335,10 @@ def model_case(settings, out, name, cls, kind, in_size, bn, bs, data_seeds=(21,)
 # they take the first later batch that keeps 5e-6 of the mean magnitude clear in every ReLU input of <= 32768 elements
 # (fp32 evaluations of these nets agree to ~1e-6 of it).  resnet18: 1.5e-6 at the output ReLU of the first 256-channel
 # block (16 x 256 x 2 x 2), flipped by any evaluation whose rounding differs by 13 ulp.
-REDRAWN = {'resnet18': dict(data_seeds=tuple(range(21, 1300, 100)), min_margin=5e-6)}
+REDRAWN = {k: dict(data_seeds=tuple(range(21, 1300, 100)), min_margin=5e-6) for k in ('resnet26', 'resnet18')}   # resnet26
+# keeps seed 21 (1.2e-5).  vgg11 is NOT in the list: its tail is 512 x 1 x 1 (BN over the 16 samples of the batch), where this
+# path and torch-CPU differ by ~1e-5 of the magnitude, so no margin a batch offers protects it (seed 121, margin 9.6e-6, flipped
+# and moved 25 of 30 gradient tensors by 1-2e-2); it stays on the seed-21 batch, which both evaluate alike.
 
 
 def remake_model_case(settings, basemodel, resnet, vggnet, name):
