@@ -1,0 +1,312 @@
+// Dense 1x1 / stride-1 convolution as a plain GEMM with a deep LDS-DMA ring, bf16:  C[m][n] = sum_k A[m][k] * B[n][k]
+// (A = NHWC activations flattened to [M][K], B = the packed weight image [Nout][K]).  Sites served: the 1x1 convs of the
+// bottleneck blocks (/root/reference/src/resnet.py:165-178) at the 28x28 / 14x14 / 7x7 stages, forward, and their data
+// gradients when no side operand is fused into the epilogue.
+//
+// Why a second kernel next to igemm_gather_kernel (conv_igemm.hip): ablated builds of that kernel on these layers (DESIGN.md
+// section 9: full / loads only / MFMAs only) show that its single-buffer loop adds load time and MFMA time up, and that the
+// loads already run at the rate the L2 -> LDS path delivers (22 TB/s) because every 128 x 128 tile re-reads its A rows once
+// per column tile and its B rows once per row tile.  Here: 256 x 128 or 256 x 256 tiles (a quarter / half fewer L2 bytes per
+// flop) on ONE
+// 512-thread workgroup per CU, K in steps of 32 channels through a FOUR-stage ring filled by LDS-DMA three steps ahead, one
+// raw barrier per step, completions counted with s_waitcnt vmcnt(N) -- loads and MFMAs overlap inside the workgroup.
+//
+//   step k:  wait for this wave's three DMAs of stage k (6 younger ones may stay in flight) | s_barrier | issue stage k+3
+//            into the slot read in step k-1 | 8 ds_read_b128 of stage k | 8 v_mfma_f32_32x32x16_bf16
+//
+// LDS rows hold 32 channels (64 B) of one pixel / output channel; the 16-byte piece index is XOR-ed with (row >> 2) & 3 on
+// the DMA SOURCE address (the LDS image of a DMA is lane-linear), which makes the fragment reads conflict-free.
+// Every vector-memory operation of the loop is inline asm so that hipcc tracks none of them (cdna_hip_programming.md 5.7).
+// Epilogue: the wave's 64 x 64 block is staged as bf16 rows in the (now idle) ring and written with 16-byte row stores;
+// optional bias; optional BN statistics partials, one (n, mean, M2) record per 256-row tile and channel, of the ROUNDED
+// outputs, as igemm_epilogue emits them per 128-row tile.
+#include <cstdlib>
+
+#include "common.h"
+
+#ifndef G1_ABL
+#define G1_ABL 0      // debug builds (tools/ablate_g1.sh): 1 no MFMAs, 2 no DMAs, 4 no fragment reads
+#endif
+
+namespace {
+
+constexpr int G1_BM = 256, G1_KC = 32, G1_NST = 4;
+constexpr int G1_ROWB = G1_KC * 2;                                  // LDS row bytes
+constexpr int G1_ASTAGE = G1_BM * G1_ROWB;
+// NJ = 32-wide column blocks per wave: workgroup tile 256 x (64 NJ), wave tile 64 x (32 NJ)
+template <int NJ> struct G1Cfg {
+    static constexpr int BN = 64 * NJ;
+    static constexpr int BSTAGE = BN * G1_ROWB, STAGE = G1_ASTAGE + BSTAGE;
+    static constexpr int LDS = G1_NST * STAGE;                      // 96 KiB (NJ = 2) / 128 KiB (NJ = 4)
+    static constexpr int SS = 32 * NJ * 2 + 16;                     // staged row: the wave's 32 NJ channels + pad
+    static constexpr int BPW = BN / 16 / 8;                         // B pieces (1 KiB = 16 rows) per wave and stage
+    static constexpr int DMA_PER_WAVE = 2 + BPW;
+    static constexpr int CPR = 32 * NJ * 2 / 16;                    // 16-byte chunks per staged row
+};
+
+__device__ __attribute__((aligned(16))) unsigned int g1_zero16[4] = {0, 0, 0, 0};
+typedef __attribute__((address_space(3))) unsigned char g1_lds_u8;
+
+struct G1Params {
+    const bf16* a;          // [M][K]
+    const bf16* b;          // [Nout][K]
+    bf16* c;                // [M][Nout]
+    const float* bias;      // [Nout] or nullptr
+    float* stats;           // [tiles_m][Nout][3] or nullptr
+    int M, K, Nout, tiles_m, tiles_n, nk;
+};
+
+__device__ __forceinline__ void g1_dma16(const void* g, uint32_t lds_addr) {        // M0 saved / restored inside
+    unsigned keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+#define G1_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory")
+
+template <int NJ, bool STATS>
+__global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
+    using CFG = G1Cfg<NJ>;
+    constexpr int BN = CFG::BN, STAGE = CFG::STAGE, SS = CFG::SS, BPW = CFG::BPW, CPR = CFG::CPR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(g1_lds_u8*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;                        // 4 x 2 waves, 64 x (32 NJ) each
+    // XCD-aware order: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles (n fastest), so the column
+    // tiles of one row tile -- same A rows -- meet in one L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int m0 = tile_m * G1_BM, n0 = tile_n * BN;
+
+    // ---- DMA roles: a stage is pieces of 1 KiB (16 rows x 64 B): 16 A pieces, BN / 16 B pieces; wave w moves A pieces w and
+    // w + 8 and B pieces w (+ 8).  Lane -> (row in piece, physical 16-byte slot); the logical slot is XOR-swizzled.
+    const int prow = lane >> 2, pslot = lane & 3;
+    const unsigned char* asrc[2];
+    bool alive[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (wave + 8 * h) * 16 + prow;
+        const int logical = pslot ^ ((row >> 2) & 3);
+        alive[h] = m0 + row < p.M;
+        asrc[h] = alive[h] ? (const unsigned char*)(p.a + (size_t)(m0 + row) * p.K + logical * 8) : (const unsigned char*)g1_zero16;
+    }
+    const unsigned char* bsrc[BPW];
+#pragma unroll
+    for (int h = 0; h < BPW; ++h) {
+        const int row = (wave + 8 * h) * 16 + prow;
+        const int logical = pslot ^ ((row >> 2) & 3);
+        bsrc[h] = (const unsigned char*)(p.b + (size_t)(n0 + row) * p.K + logical * 8);
+    }
+    auto issue = [&](int k) {
+        const uint32_t sb = lds0 + (uint32_t)(k % G1_NST) * STAGE;
+        const size_t ko = (size_t)k * (G1_KC * 2);
+        if (G1_ABL & 2) return;
+        g1_dma16(alive[0] ? asrc[0] + ko : asrc[0], sb + (uint32_t)wave * 1024);
+        g1_dma16(alive[1] ? asrc[1] + ko : asrc[1], sb + (uint32_t)(wave + 8) * 1024);
+#pragma unroll
+        for (int h = 0; h < BPW; ++h) g1_dma16(bsrc[h] + ko, sb + G1_ASTAGE + (uint32_t)(wave + 8 * h) * 1024);
+    };
+
+    // ---- fragment byte offsets inside a stage (k-step s of the stage: logical slot 2s + lh)
+    int aoff[2][2], boff[NJ][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ra = wm * 64 + i * 32 + l31;
+            aoff[i][s] = ra * G1_ROWB + (((2 * s + lh) ^ ((ra >> 2) & 3)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int rb = wn * (32 * NJ) + j * 32 + l31;
+            boff[j][s] = G1_ASTAGE + rb * G1_ROWB + (((2 * s + lh) ^ ((rb >> 2) & 3)) << 4);
+        }
+    }
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- main loop: one barrier per step.  (A ping-pong variant -- two wave groups half a step apart, two barriers per step,
+    // fragments read in one phase and multiplied in the other, as conv_pp.hip does for the 3x3 -- measured 5-10 % slower
+    // here: with one tap per K chunk there is no register-only phase long enough to pay for the second barrier.)
+    const int nk = p.nk;
+#pragma unroll
+    for (int k = 0; k < G1_NST - 1; ++k)
+        if (k < nk) issue(k);
+    for (int k = 0; k < nk; ++k) {
+        const int rem = nk - 1 - k;                                 // stages issued after stage k
+        if (rem >= G1_NST - 2) G1_WAIT_VM(2 * CFG::DMA_PER_WAVE);
+        else if (rem == 1) G1_WAIT_VM(CFG::DMA_PER_WAVE);
+        else G1_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();                               // stage k is complete; everyone has left stage k-1
+        asm volatile("" ::: "memory");
+        if (k + G1_NST - 1 < nk) issue(k + G1_NST - 1);
+        const unsigned char* sb = smem + (k % G1_NST) * STAGE;
+        u32x4 fa[2][2], fb[NJ][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i][s] = (G1_ABL & 4) ? u32x4{(unsigned)aoff[i][s], (unsigned)k, 0x3f803f80u, 0x3f803f80u} : *(const u32x4*)(sb + aoff[i][s]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j][s] = (G1_ABL & 4) ? u32x4{(unsigned)boff[j][s], (unsigned)k, 0x3f803f80u, 0x3f803f80u} : *(const u32x4*)(sb + boff[j][s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (G1_ABL & 1) acc[i][j][s] += __builtin_bit_cast(float, fb[j][s][0] ^ fa[i][s][1]);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[j][s]),
+                                                                        __builtin_bit_cast(bf16x8, fa[i][s]), acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue.  Lane (pixel l31, half lh) of block (i, j) holds channels j*32 + 8g + 4lh + {0..3} in regs 4g..4g+3.
+    __syncthreads();                                                // the ring is idle: reuse it as staging
+    unsigned char* st = smem + wave * 32 * SS;                      // 32 rows x (32 NJ) channels per wave
+    float* red = (float*)(smem + 8 * 32 * SS);                      // [4 wm][BN][2]
+    const int chunk = lane % CPR, crow = lane / CPR;                // copy-out: CPR lanes per staged row
+    constexpr int RPI = 64 / CPR;                                   // rows per copy-out instruction
+    float s8[8], q8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int col = j * 32 + 8 * gq + 4 * lh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.bias[n0 + wn * (32 * NJ) + col + e];
+                }
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *(bf16x4*)(st + l31 * SS + col * 2) = o;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): wave-private staging
+#pragma unroll
+        for (int t = 0; t < 32 / RPI; ++t) {
+            const int r = crow + RPI * t, m = m0 + wm * 64 + i * 32 + r;
+            if (m < p.M) {
+                Vec16<bf16> v;
+                v.v = *(const decltype(v.v)*)(st + r * SS + chunk * 16);
+                *(decltype(v.v)*)(p.c + (size_t)m * p.Nout + n0 + wn * (32 * NJ) + chunk * 8) = v.v;
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = v.get(e);
+                        s8[e] += f;
+                        q8[e] += f * f;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                         // staged rows read before the next block overwrites them
+    }
+    if constexpr (STATS) {
+        // lanes with the same chunk hold the same 8 channels: xor tree over the higher lane bits, then the four row waves of
+        // a column half through LDS, in fixed order
+#pragma unroll
+        for (int off = CPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s8[e] += __shfl_xor(s8[e], off, 64);
+                q8[e] += __shfl_xor(q8[e], off, 64);
+            }
+        __syncthreads();                                            // every wave has finished with its staging block
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float* o = red + ((size_t)wm * BN + wn * (32 * NJ) + lane * 8 + e) * 2;
+                o[0] = s8[e]; o[1] = q8[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                S += red[((size_t)w * BN + tid) * 2];
+                Q += red[((size_t)w * BN + tid) * 2 + 1];
+            }
+            const int nvalid = min(G1_BM, p.M - m0);
+            const float mean = S / (float)nvalid;
+            const float m2 = Q - S * mean;
+            float* o = p.stats + ((size_t)tile_m * p.Nout + n0 + tid) * 3;
+            o[0] = (float)nvalid;
+            o[1] = mean;
+            o[2] = m2 > 0.f ? m2 : 0.f;
+        }
+    }
+}
+
+int g1_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+// shapes this kernel takes (dense 1x1 stride-1 GEMM, bf16): K a multiple of the 32-channel step, Nout of the 128-wide tile
+bool gemm1x1_shape_ok(int64_t M, int K, int Nout) {
+    return M > 0 && K >= 64 && K % G1_KC == 0 && Nout % 128 == 0 && M * (int64_t)(K > Nout ? K : Nout) < (1ll << 31);
+}
+
+// 0: not taken; 2 / 4: column blocks per wave (256 x 128 / 256 x 256 tiles).  CNK_GEMM1X1: 0 off, 1 by measurement
+// (tools/bench_g1.py, A/B in one process), 2 / 4 force that tile wherever the shape fits.
+int gemm1x1_pick(int64_t M, int K, int Nout) {
+    const int mode = g1_env("CNK_GEMM1X1", 1);
+    if (mode == 0 || !gemm1x1_shape_ok(M, K, Nout)) return 0;
+    if (mode == 4) return Nout % 256 == 0 ? 4 : 2;
+    if (mode == 2) return 2;
+    // by measurement (MI355X, batch 256): the deep layers whose K is long and whose 128 x 128 tiles under-fill the chip.
+    //   1024->256 @14x14  52 -> 43 us (256 x 256, 196 tiles)     1024->512 @14x14  82 -> 76 us (256 x 256, 392 tiles)
+    //   2048->512 @7x7    62 -> 44 us (256 x 128, 196 tiles)     everything with K <= 512 or at 28x28 / 56x56: the old kernel
+    const int64_t tm = (M + G1_BM - 1) / G1_BM;
+    if (K >= 1024 && Nout % 256 == 0 && tm * (Nout / 256) >= 150) return 4;
+    if (K >= 2048 && tm * (Nout / 128) >= 150 && tm * (Nout / 128) <= 300) return 2;
+    return 0;
+}
+
+int64_t gemm1x1_slices(int64_t M) { return (M + G1_BM - 1) / G1_BM; }
+
+template <int NJ>
+static int gemm1x1_launch_t(const G1Params& p0, double algo_flops, double algo_bytes, hipStream_t s) {
+    G1Params p = p0;
+    p.tiles_n = p.Nout / G1Cfg<NJ>::BN;
+    static bool attr_done = false;
+    if (!attr_done) {                                               // more than 64 KiB of dynamic LDS needs the opt-in
+        const hipError_t e1 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
+        const hipError_t e2 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
+        CNK_CHECK_ARG(e1 == hipSuccess && e2 == hipSuccess, "gemm1x1: cannot reserve %d bytes of LDS", G1Cfg<NJ>::LDS);
+        attr_done = true;
+    }
+    ProfScope kscope(CNK_KF_GATHER, s, algo_flops, algo_bytes);
+    const int grid = p.tiles_m * p.tiles_n;
+    if (p.stats) hipLaunchKernelGGL((gemm1x1_kernel<NJ, true>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
+    else hipLaunchKernelGGL((gemm1x1_kernel<NJ, false>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
+    CNK_CHECK_LAUNCH("gemm1x1");
+    return 0;
+}
+
+int gemm1x1_launch(int nj, const void* a, const void* b, void* c, const float* bias, float* stats, int64_t M, int K, int Nout,
+                   double algo_flops, double algo_bytes, hipStream_t s) {
+    G1Params p;
+    p.a = (const bf16*)a; p.b = (const bf16*)b; p.c = (bf16*)c; p.bias = bias; p.stats = stats;
+    p.M = (int)M; p.K = K; p.Nout = Nout;
+    p.tiles_m = (int)((M + G1_BM - 1) / G1_BM); p.tiles_n = 0; p.nk = K / G1_KC;
+    return nj == 4 ? gemm1x1_launch_t<4>(p, algo_flops, algo_bytes, s) : gemm1x1_launch_t<2>(p, algo_flops, algo_bytes, s);
+}

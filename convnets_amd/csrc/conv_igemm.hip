@@ -805,6 +805,13 @@ template <typename T, int BN> int launch_halo(const GatherParams& p, hipStream_t
     return 0;
 }
 
+// a 1x1 / stride-1 conv (or its data gradient) whose operand is the plain [M][C] matrix and whose output pixel is the row index
+static bool dense_1x1(const GatherParams& p) {
+    return p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.sm_h == 1 && p.sm_w == 1 && p.dm_h == 1 && p.dm_w == 1 &&
+           p.d_h0 == 0 && p.d_w0 == 0 && p.IH == p.OH && p.IW == p.OW && p.FH == p.OH && p.FW == p.OW &&
+           (p.Cpad == 0 || p.Cpad == p.C);
+}
+
 template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     int tiles_m = ceil_div(p.M, BM);
     constexpr int KS = 8 * ElemTraits<T>::PER16;
@@ -827,6 +834,9 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         a.algo_bytes = gather_bytes(p, sizeof(T));
         return pp3x3_launch(a, s);
     }
+    if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.addend && !p.bnf_x && !p.relu)
+        if (const int nj = gemm1x1_pick(p.M, p.C, p.Nout))
+            return gemm1x1_launch(nj, p.src, p.wpk, p.dst, p.bias, p.stats, p.M, p.C, p.Nout, gather_flops(p), gather_bytes(p, sizeof(T)), s);
     bool use128 = !p.chunked && pick_bn128(p.M, p.Nout);
     int bn = use128 ? 128 : 64;
     p.tiles_n = p.Nout / bn;
@@ -896,6 +906,9 @@ int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     if (pp_desc(d, CNK_PASS_FWD)) return pp3x3_slices(d->N, d->H, d->W, d->Cin, d->Cout, 0);
+    if (d->dtype == CNK_BF16 && conv_groups(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h == 1 && d->stride_w == 1 &&
+        d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 && gemm1x1_pick((int64_t)d->N * Ho * Wo, d->Cin, d->Cout))
+        return gemm1x1_slices((int64_t)d->N * Ho * Wo);
     return ceil_div(d->N * Ho * Wo, BM);
 }
 

@@ -591,3 +591,69 @@ def test_input_layout_handoff(shape, dtype):
     torch.cuda.synchronize()
     assert out.shape == x.shape and out.dtype == tdt and out.is_contiguous(memory_format=CL)
     assert torch.equal(out.cpu(), x.to(tdt))
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,bias', [
+    (16, 1024, 256, 14, False),     # 13 row tiles of 256 (the last one ragged: 3136 rows), 256 x 256 and 256 x 128 tiles
+    (8, 2048, 512, 7, True),        # 392 rows: two row tiles, the second 136 rows; bias
+    (4, 64, 128, 9, False),         # the shortest K the kernel takes (two 32-channel steps: the ring never fills)
+    (2, 96, 384, 5, True),          # K = 3 steps, Nout = 3 x 128 (not a multiple of 256: only the 256 x 128 tile fits)
+    (256, 1024, 256, 14, False),    # bench size: what the dispatch picks by itself
+])
+def test_dense_1x1_ring_gemm_matches_the_implicit_gemm_kernel(N, Cin, Cout, H, bias):
+    """conv_gemm1x1.hip (256 x 128 / 256 x 256 tiles, four-stage LDS-DMA ring) against igemm_gather_kernel on the same
+    operands -- forward with bias and BN statistics partials, plain data gradient: the outputs are bit-identical (same MFMA
+    order along K), the statistics agree after merging -- and against torch fp32 on the CPU for the small cases."""
+    import ctypes
+    import torch.nn.functional as F
+    from convnets_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, Cin, H, H, generator=g).bfloat16()
+    dy = torch.randn(N, Cout, H, H, generator=g).bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g).cuda() if bias else None
+    xg, dyg = x.cuda().contiguous(memory_format=CL), dy.cuda().contiguous(memory_format=CL)
+    desc = ops.make_desc(xg.shape, w.shape, (1, 1), (0, 0), _lib.CNK_BF16)
+    wf, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    M = N * H * H
+    res = {}
+    prev = os.environ.get('CNK_GEMM1X1')
+    try:
+        for mode in ('0', '2', '4', '1'):
+            os.environ['CNK_GEMM1X1'] = mode
+            nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+            assert nsl > 0
+            part = torch.full((nsl, Cout, 3), float('nan'), device='cuda')
+            y, dx = torch.empty_like(dyg), torch.empty_like(xg)
+            assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), P(b), P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
+            assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dx), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+            torch.cuda.synchronize()
+            pt = part.double()
+            assert torch.isfinite(pt).all()
+            n, mean, m2 = pt[:, :, 0], pt[:, :, 1], pt[:, :, 2]
+            tn = n.sum(0)
+            assert torch.all(tn == M)
+            tmean = (n * mean).sum(0) / tn
+            tvar = (m2.sum(0) + (n * (mean - tmean) ** 2).sum(0)) / tn
+            res[mode] = (y, dx, nsl, tmean, tvar)
+    finally:
+        if prev is None:
+            os.environ.pop('CNK_GEMM1X1', None)
+        else:
+            os.environ['CNK_GEMM1X1'] = prev
+    assert res['2'][2] == (M + 255) // 256 and res['0'][2] == (M + 127) // 128      # one record per row tile of either kernel
+    for mode in ('2', '4', '1'):
+        assert torch.equal(res[mode][0], res['0'][0]) and torch.equal(res[mode][1], res['0'][1])
+        assert ((res[mode][3] - res['0'][3]).abs().max() / res['0'][0].float().abs().mean()).item() < 1e-6
+        assert ((res[mode][4] - res['0'][4]).abs() / res['0'][4]).max().item() < 1e-5
+    yd = res['2'][0].double()
+    assert ((res['2'][3] - yd.mean((0, 2, 3))).abs().max() / yd.abs().mean()).item() < 2e-6      # statistics of the tensor it wrote
+    assert ((res['2'][4] - yd.var((0, 2, 3), unbiased=False)).abs() / res['2'][4]).max().item() < 2e-5
+    if M * Cin * Cout <= 2e9:
+        ref = F.conv2d(x.double(), w.bfloat16().double(), None if b is None else b.double().cpu())
+        assert rel_l2(host(res['2'][0]), ref.float().numpy()) < 4e-3
+        refdx = F.conv_transpose2d(dy.double(), w.bfloat16().double())
+        assert rel_l2(host(res['2'][1]), refdx.float().numpy()) < 4e-3
