@@ -277,7 +277,7 @@ int gemm1x1_pick(int64_t M, int K, int Nout) {
     //   2048->512 @7x7    62 -> 44 us (256 x 128, 196 tiles)     everything with K <= 512 or at 28x28 / 56x56: the old kernel
     const int64_t tm = (M + G1_BM - 1) / G1_BM;
     if (K >= 1024 && Nout % 256 == 0 && tm * (Nout / 256) >= 150) return 4;
-    if (K >= 2048 && tm * (Nout / 128) >= 150 && tm * (Nout / 128) <= 300) return 2;
+    if (K >= 1024 && tm * (Nout / 128) >= 96 && tm * (Nout / 128) <= 300) return 2;     // also batch 128: 1024->256 37 -> 28 us, 2048->512 57 -> 42
     return 0;
 }
 
