@@ -144,8 +144,16 @@ int pp3x3_launch(const PPArgs& a, hipStream_t s);
 // conv_gemm1x1.hip: dense 1x1 / stride-1 convolutions as a GEMM with a four-stage LDS-DMA ring (bf16)
 int gemm1x1_pick(int64_t M, int K, int Nout);          // 0: no; 2 / 4: column blocks per wave
 int64_t gemm1x1_slices(int64_t M);
-int gemm1x1_launch(int nj, const void* a, const void* b, void* c, const float* bias, float* stats, int64_t M, int K, int Nout,
-                   double algo_flops, double algo_bytes, hipStream_t s);
+struct G1Args {
+    const void* a; const void* b; void* c;            // [M][K], [Nout][K], [M][Nout]  (bf16)
+    const float* bias; float* stats;
+    const void* addend; const unsigned char* addend_mask;
+    const void* bnf_x; const float* bnf_mean; const float* bnf_invstd; const float* bnf_gamma; const float* bnf_beta;
+    const unsigned char* bnf_mask; float* bnf_partial; int bnf_relu, bnf_tile0;
+    int64_t M; int K, Nout;
+    double algo_flops, algo_bytes;
+};
+int gemm1x1_launch(int nj, const G1Args& a, hipStream_t s);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int conv_groups(const cnk_conv_desc* d) { return d->groups > 1 ? d->groups : 1; }

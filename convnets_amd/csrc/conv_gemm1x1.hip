@@ -53,6 +53,18 @@ struct G1Params {
     bf16* c;                // [M][Nout]
     const float* bias;      // [Nout] or nullptr
     float* stats;           // [tiles_m][Nout][3] or nullptr
+    // data-gradient epilogue (MODE 2), as igemm_epilogue: gradient addend (+ packed ReLU mask) and the first pass of the
+    // backward of the BN(+ReLU) layer that produced the tensor this gradient belongs to
+    const bf16* addend;
+    const unsigned char* addend_mask;
+    const bf16* bnf_x;
+    const float* bnf_mean;
+    const float* bnf_invstd;
+    const float* bnf_gamma;
+    const float* bnf_beta;
+    const unsigned char* bnf_mask;
+    float* bnf_partial;     // [bnf_tile0 + tiles_m][Nout][2]
+    int bnf_relu, bnf_tile0;
     int M, K, Nout, tiles_m, tiles_n, nk;
 };
 
@@ -64,8 +76,10 @@ __device__ __forceinline__ void g1_dma16(const void* g, uint32_t lds_addr) {    
 }
 #define G1_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory")
 
-template <int NJ, bool STATS>
+// MODE: 0 plain, 1 BN statistics partials of the output, 2 data-gradient side operands
+template <int NJ, int MODE>
 __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
+    constexpr bool STATS = MODE == 1, FULL = MODE == 2;
     using CFG = G1Cfg<NJ>;
     constexpr int BN = CFG::BN, STAGE = CFG::STAGE, SS = CFG::SS, BPW = CFG::BPW, CPR = CFG::CPR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -179,6 +193,21 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
     float s8[8], q8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+    // fused BN backward: coefficients of this lane's 8 channels
+    const bool bnf = FULL && p.bnf_x != nullptr;
+    const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
+    float bmu[8], bsc[8], bsf[8];
+    if constexpr (FULL) {
+        if (bnf) {
+            const int c0 = n0 + wn * (32 * NJ) + chunk * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bmu[e] = p.bnf_mean[c0 + e];
+                bsc[e] = bnf_remask ? p.bnf_gamma[c0 + e] * p.bnf_invstd[c0 + e] : 0.f;
+                bsf[e] = bnf_remask ? p.bnf_beta[c0 + e] - bmu[e] * bsc[e] : 0.f;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -197,12 +226,57 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
                 *(bf16x4*)(st + l31 * SS + col * 2) = o;
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): wave-private staging
+        // side operands of this block's rows, requested together ahead of the stores (which may alias them as far as the
+        // compiler knows: loads left inside the store loop would cost one latency per row group)
+        constexpr int NT = 32 / RPI;
+        Vec16<bf16> av[FULL ? NT : 1], xv[FULL ? NT : 1];
+        unsigned am[FULL ? NT : 1], km[FULL ? NT : 1];
+        if constexpr (FULL) {
 #pragma unroll
-        for (int t = 0; t < 32 / RPI; ++t) {
+            for (int t = 0; t < NT; ++t) {
+                const int r = crow + RPI * t, m = m0 + wm * 64 + i * 32 + r;
+                am[t] = km[t] = 0xFFu;
+                if (m < p.M) {
+                    const size_t go = (size_t)m * p.Nout + n0 + wn * (32 * NJ) + chunk * 8;      // element offset of this 16-byte vector
+                    if (p.addend) {
+                        av[t].v = *(const decltype(av[t].v)*)(p.addend + go);
+                        if (p.addend_mask) am[t] = p.addend_mask[go >> 3];
+                    }
+                    if (bnf) {
+                        xv[t].v = *(const decltype(xv[t].v)*)(p.bnf_x + go);
+                        if (p.bnf_relu && p.bnf_mask) km[t] = p.bnf_mask[go >> 3];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
             const int r = crow + RPI * t, m = m0 + wm * 64 + i * 32 + r;
             if (m < p.M) {
                 Vec16<bf16> v;
                 v.v = *(const decltype(v.v)*)(st + r * SS + chunk * 16);
+                if constexpr (FULL) {
+                    if (p.addend) {          // same rounding as a separate add kernel: round(round(conv) + addend)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v.set(e, v.get(e) + (((am[t] >> e) & 1u) ? av[t].get(e) : 0.f));
+                    }
+                    if (bnf) {
+                        // dx' = dx * ReLU-mask of the producing BN layer; s8 += dx', q8 += dx' * (x - mean)
+                        unsigned keep = km[t];
+                        if (bnf_remask) {
+                            keep = 0;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) keep |= (xv[t].get(e) * bsc[e] + bsf[e] > 0.f ? 1u : 0u) << e;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float dv = ((keep >> e) & 1u) ? v.get(e) : 0.f;
+                            v.set(e, dv);
+                            s8[e] += dv;
+                            q8[e] += dv * (xv[t].get(e) - bmu[e]);
+                        }
+                    }
+                }
                 *(decltype(v.v)*)(p.c + (size_t)m * p.Nout + n0 + wn * (32 * NJ) + chunk * 8) = v.v;
                 if constexpr (STATS) {
 #pragma unroll
@@ -216,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                         // staged rows read before the next block overwrites them
     }
-    if constexpr (STATS) {
+    if (STATS || bnf) {
         // lanes with the same chunk hold the same 8 channels: xor tree over the higher lane bits, then the four row waves of
         // a column half through LDS, in fixed order
 #pragma unroll
@@ -242,13 +316,20 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
                 S += red[((size_t)w * BN + tid) * 2];
                 Q += red[((size_t)w * BN + tid) * 2 + 1];
             }
-            const int nvalid = min(G1_BM, p.M - m0);
-            const float mean = S / (float)nvalid;
-            const float m2 = Q - S * mean;
-            float* o = p.stats + ((size_t)tile_m * p.Nout + n0 + tid) * 3;
-            o[0] = (float)nvalid;
-            o[1] = mean;
-            o[2] = m2 > 0.f ? m2 : 0.f;
+            if constexpr (FULL) {
+                const int c = n0 + tid;
+                float* o = p.bnf_partial + ((size_t)(p.bnf_tile0 + tile_m) * p.Nout + c) * 2;
+                o[0] = S;
+                o[1] = Q * p.bnf_invstd[c];
+            } else {
+                const int nvalid = min(G1_BM, p.M - m0);
+                const float mean = S / (float)nvalid;
+                const float m2 = Q - S * mean;
+                float* o = p.stats + ((size_t)tile_m * p.Nout + n0 + tid) * 3;
+                o[0] = (float)nvalid;
+                o[1] = mean;
+                o[2] = m2 > 0.f ? m2 : 0.f;
+            }
         }
     }
 }
@@ -289,24 +370,29 @@ static int gemm1x1_launch_t(const G1Params& p0, double algo_flops, double algo_b
     p.tiles_n = p.Nout / G1Cfg<NJ>::BN;
     static bool attr_done = false;
     if (!attr_done) {                                               // more than 64 KiB of dynamic LDS needs the opt-in
-        const hipError_t e1 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
-        const hipError_t e2 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
-        CNK_CHECK_ARG(e1 == hipSuccess && e2 == hipSuccess, "gemm1x1: cannot reserve %d bytes of LDS", G1Cfg<NJ>::LDS);
+        const hipError_t e0 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
+        const hipError_t e1 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
+        const hipError_t e2 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
+        CNK_CHECK_ARG(e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess, "gemm1x1: cannot reserve %d bytes of LDS", G1Cfg<NJ>::LDS);
         attr_done = true;
     }
     ProfScope kscope(CNK_KF_GATHER, s, algo_flops, algo_bytes);
     const int grid = p.tiles_m * p.tiles_n;
-    if (p.stats) hipLaunchKernelGGL((gemm1x1_kernel<NJ, true>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
-    else hipLaunchKernelGGL((gemm1x1_kernel<NJ, false>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
+    if (p.addend || p.bnf_x) hipLaunchKernelGGL((gemm1x1_kernel<NJ, 2>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
+    else if (p.stats) hipLaunchKernelGGL((gemm1x1_kernel<NJ, 1>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
+    else hipLaunchKernelGGL((gemm1x1_kernel<NJ, 0>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
     CNK_CHECK_LAUNCH("gemm1x1");
     return 0;
 }
 
-int gemm1x1_launch(int nj, const void* a, const void* b, void* c, const float* bias, float* stats, int64_t M, int K, int Nout,
-                   double algo_flops, double algo_bytes, hipStream_t s) {
-    G1Params p;
-    p.a = (const bf16*)a; p.b = (const bf16*)b; p.c = (bf16*)c; p.bias = bias; p.stats = stats;
-    p.M = (int)M; p.K = K; p.Nout = Nout;
-    p.tiles_m = (int)((M + G1_BM - 1) / G1_BM); p.tiles_n = 0; p.nk = K / G1_KC;
-    return nj == 4 ? gemm1x1_launch_t<4>(p, algo_flops, algo_bytes, s) : gemm1x1_launch_t<2>(p, algo_flops, algo_bytes, s);
+int gemm1x1_launch(int nj, const G1Args& a, hipStream_t s) {
+    G1Params p = {};
+    p.a = (const bf16*)a.a; p.b = (const bf16*)a.b; p.c = (bf16*)a.c; p.bias = a.bias; p.stats = a.stats;
+    p.addend = (const bf16*)a.addend; p.addend_mask = a.addend_mask;
+    p.bnf_x = (const bf16*)a.bnf_x; p.bnf_mean = a.bnf_mean; p.bnf_invstd = a.bnf_invstd; p.bnf_gamma = a.bnf_gamma;
+    p.bnf_beta = a.bnf_beta; p.bnf_mask = a.bnf_mask; p.bnf_partial = a.bnf_partial; p.bnf_relu = a.bnf_relu; p.bnf_tile0 = a.bnf_tile0;
+    p.M = (int)a.M; p.K = a.K; p.Nout = a.Nout;
+    p.tiles_m = (int)((a.M + G1_BM - 1) / G1_BM); p.tiles_n = 0; p.nk = a.K / G1_KC;
+    CNK_CHECK_ARG(!(p.stats && (p.addend || p.bnf_x)), "gemm1x1: statistics partials and data-gradient side operands are exclusive");
+    return nj == 4 ? gemm1x1_launch_t<4>(p, a.algo_flops, a.algo_bytes, s) : gemm1x1_launch_t<2>(p, a.algo_flops, a.algo_bytes, s);
 }

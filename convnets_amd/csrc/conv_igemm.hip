@@ -834,9 +834,17 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         a.algo_bytes = gather_bytes(p, sizeof(T));
         return pp3x3_launch(a, s);
     }
-    if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.addend && !p.bnf_x && !p.relu)
-        if (const int nj = gemm1x1_pick(p.M, p.C, p.Nout))
-            return gemm1x1_launch(nj, p.src, p.wpk, p.dst, p.bias, p.stats, p.M, p.C, p.Nout, gather_flops(p), gather_bytes(p, sizeof(T)), s);
+    if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.relu && !(p.stats && (p.addend || p.bnf_x)))
+        if (const int nj = gemm1x1_pick(p.M, p.C, p.Nout)) {
+            G1Args a = {};
+            a.a = p.src; a.b = p.wpk; a.c = p.dst; a.bias = p.bias; a.stats = p.stats;
+            a.addend = p.addend; a.addend_mask = p.addend_mask;
+            a.bnf_x = p.bnf_x; a.bnf_mean = p.bnf_mean; a.bnf_invstd = p.bnf_invstd; a.bnf_gamma = p.bnf_gamma; a.bnf_beta = p.bnf_beta;
+            a.bnf_mask = p.bnf_mask; a.bnf_partial = p.bnf_partial; a.bnf_relu = p.bnf_relu; a.bnf_tile0 = p.bnf_tile0;
+            a.M = p.M; a.K = p.C; a.Nout = p.Nout;
+            a.algo_flops = gather_flops(p); a.algo_bytes = gather_bytes(p, sizeof(T));
+            return gemm1x1_launch(nj, a, s);
+        }
     bool use128 = !p.chunked && pick_bn128(p.M, p.Nout);
     int bn = use128 ? 128 : 64;
     p.tiles_n = p.Nout / bn;
@@ -968,6 +976,10 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out /* [stride_h*stride_w]
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     if (d->stride_h * d->stride_w > 16 || d->Cin % (d->dtype == CNK_BF16 ? 8 : 4)) return 0;
     if (pp_desc(d, CNK_PASS_DGRAD)) return pp3x3_slices(d->N, d->H, d->W, d->Cout, d->Cin, 1);
+    if (d->dtype == CNK_BF16 && conv_groups(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h == 1 && d->stride_w == 1 &&
+        d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 &&
+        gemm1x1_pick((int64_t)d->N * d->H * d->W, d->Cout, d->Cin))
+        return gemm1x1_slices((int64_t)d->N * d->H * d->W);          // the ring GEMM (conv_gemm1x1.hip): one record per 256 rows
     DgradClass cls[16];
     int nc = dgrad_classes(d, cls);
     int64_t n = 0;

@@ -619,7 +619,12 @@ def test_dense_1x1_ring_gemm_matches_the_implicit_gemm_kernel(N, Cin, Cout, H, b
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     M = N * H * H
-    res = {}
+    res, fused = {}, {}
+    bnx = (torch.randn(N, H, H, Cin, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    addend = torch.randn(N, H, H, Cin, generator=g).bfloat16().cuda()
+    amask = torch.randint(0, 256, (N * H * H * Cin // 8,), generator=g, dtype=torch.uint8).cuda()
+    bmean, binv = (torch.randn(Cin, generator=g) * 0.1).cuda(), (torch.rand(Cin, generator=g) + 0.5).cuda()
+    bgam, bbeta = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
     prev = os.environ.get('CNK_GEMM1X1')
     try:
         for mode in ('0', '2', '4', '1'):
@@ -630,7 +635,17 @@ def test_dense_1x1_ring_gemm_matches_the_implicit_gemm_kernel(N, Cin, Cout, H, b
             y, dx = torch.empty_like(dyg), torch.empty_like(xg)
             assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), P(b), P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
             assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dx), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+            # the data gradient as the training step issues it: + gradient addend gated by a packed ReLU mask, and the
+            # first pass of the backward of the BN + ReLU layer that produced x (mask re-derived from bnx)
+            nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+            assert nb > 0
+            bpart = torch.full((nb, Cin, 2), float('nan'), device='cuda')
+            fuse = _lib.BnBwdFuse(bnx.data_ptr(), bmean.data_ptr(), binv.data_ptr(), bgam.data_ptr(), bbeta.data_ptr(), None, bpart.data_ptr(), 1)
+            dxf = torch.empty_like(xg)
+            assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dxf), P(addend), P(amask), ctypes.byref(fuse), None, 0, st) == 0, lib.cnk_last_error()
             torch.cuda.synchronize()
+            assert torch.isfinite(bpart).all()
+            fused[mode] = (dxf, bpart.double().sum(0))
             pt = part.double()
             assert torch.isfinite(pt).all()
             n, mean, m2 = pt[:, :, 0], pt[:, :, 1], pt[:, :, 2]
@@ -647,6 +662,8 @@ def test_dense_1x1_ring_gemm_matches_the_implicit_gemm_kernel(N, Cin, Cout, H, b
     assert res['2'][2] == (M + 255) // 256 and res['0'][2] == (M + 127) // 128      # one record per row tile of either kernel
     for mode in ('2', '4', '1'):
         assert torch.equal(res[mode][0], res['0'][0]) and torch.equal(res[mode][1], res['0'][1])
+        assert torch.equal(fused[mode][0], fused['0'][0])            # masked gradient: same element-wise arithmetic
+        assert ((fused[mode][1] - fused['0'][1]).abs().max() / fused['0'][1].abs().max()).item() < 1e-5      # sum dx', sum dx' (x - mean) invstd
         assert ((res[mode][3] - res['0'][3]).abs().max() / res['0'][0].float().abs().mean()).item() < 1e-6
         assert ((res[mode][4] - res['0'][4]).abs() / res['0'][4]).max().item() < 1e-5
     yd = res['2'][0].double()

@@ -18,7 +18,7 @@ if os.environ.get('G1_SHAPES'):
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 VARS = (('old', '0'), ('n128', '2'), ('n256', '4'))
-tot = {v: [0.0, 0.0] for v, _ in VARS}
+tot = {v: [0.0, 0.0, 0.0] for v, _ in VARS}
 for Cin, Cout, H in SHAPES:
     torch.manual_seed(5)
     per = (N * Cin * H * H + N * Cout * H * H) * 2
@@ -53,8 +53,15 @@ for Cin, Cout, H in SHAPES:
         yb = info['new'][0].double()
         msg += ', stats vs tensor: mean %.1e var %.1e' % (((info['new'][3] - yb.mean((0, 2, 3))).abs().max() / yb.abs().mean()).item(),
                                                           ((info['new'][4] - yb.var((0, 2, 3), unbiased=False)).abs() / info['new'][4]).max().item())
+    # the training step's data gradient: gradient addend + first pass of the producing BN(+ReLU) layer's backward fused in
+    mean, invstd = torch.zeros(Cin, device='cuda'), torch.ones(Cin, device='cuda')
+    gamma, beta = torch.ones(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
+    bpart = torch.zeros((N * H * H // 64 + 8) * Cin * 2, device='cuda')
+    bnx = [torch.randn(N, Cin, H, H, device='cuda').bfloat16().contiguous(memory_format=CL) for _ in range(min(copies, 4))]
+    fuses = [_lib.BnBwdFuse(b.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, bpart.data_ptr(), 1) for b in bnx]
     runs = {'fwd': lambda i: lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xs[i % copies]), P(wf), None, P(ys[i % copies]), P(part), None, 0, st),
-            'dgrad': lambda i: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[i % copies]), P(wd), P(xs[i % copies]), None, None, None, None, 0, st)}
+            'dgrad': lambda i: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[i % copies]), P(wd), P(xs[i % copies]), None, None, None, None, 0, st),
+            'dgbn': lambda i: lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(ys[i % copies]), P(wd), P(xs[i % copies]), None, None, ctypes.byref(fuses[i % len(fuses)]), None, 0, st)}
     times = {(v, k): [] for v, _ in VARS for k in runs}
     for rnd in range(5):
         for v, mode in VARS:
@@ -73,9 +80,9 @@ for Cin, Cout, H in SHAPES:
     fl = 2.0 * N * H * H * Cout * Cin
     line = '%4d->%4d @%3d' % (Cin, Cout, H)
     for v, _ in VARS:
-        f, d = statistics.median(times[(v, 'fwd')]), statistics.median(times[(v, 'dgrad')])
-        tot[v][0] += f; tot[v][1] += d
-        line += '  %s %5.1f / %5.1f' % (v, f, d)
-    print(line + '  us fwd / dgrad;  ' + msg, flush=True)
+        f, d, b = (statistics.median(times[(v, k)]) for k in ('fwd', 'dgrad', 'dgbn'))
+        tot[v][0] += f; tot[v][1] += d; tot[v][2] += b
+        line += '  %s %5.1f / %5.1f / %5.1f' % (v, f, d, b)
+    print(line + '  us fwd / dgrad / dgrad+BN;  ' + msg, flush=True)
 for v in tot:
-    print('sum %s: fwd %.1f us, dgrad %.1f us' % (v, tot[v][0], tot[v][1]))
+    print('sum %s: fwd %.1f us, dgrad %.1f us, dgrad with the BN backward fused %.1f us' % (v, tot[v][0], tot[v][1], tot[v][2]))
