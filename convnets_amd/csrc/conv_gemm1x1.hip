@@ -30,14 +30,15 @@
 
 namespace {
 
-constexpr int G1_BM = 256, G1_KC = 32, G1_NST = 4;
+constexpr int G1_BM = 256, G1_KC = 32;
 constexpr int G1_ROWB = G1_KC * 2;                                  // LDS row bytes
 constexpr int G1_ASTAGE = G1_BM * G1_ROWB;
 // NJ = 32-wide column blocks per wave: workgroup tile 256 x (64 NJ), wave tile 64 x (32 NJ)
 template <int NJ> struct G1Cfg {
     static constexpr int BN = 64 * NJ;
     static constexpr int BSTAGE = BN * G1_ROWB, STAGE = G1_ASTAGE + BSTAGE;
-    static constexpr int LDS = G1_NST * STAGE;                      // 96 KiB (NJ = 2) / 128 KiB (NJ = 4)
+    static constexpr int NST = 4;                                   // ring stages (a fifth one for the 256 x 128 tile measured no gain)
+    static constexpr int LDS = NST * STAGE;                         // 96 KiB (NJ = 2) / 128 KiB (NJ = 4)
     static constexpr int SS = 32 * NJ * 2 + 16;                     // staged row: the wave's 32 NJ channels + pad
     static constexpr int BPW = BN / 16 / 8;                         // B pieces (1 KiB = 16 rows) per wave and stage
     static constexpr int DMA_PER_WAVE = 2 + BPW;
@@ -81,7 +82,7 @@ template <int NJ, int MODE>
 __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
     constexpr bool STATS = MODE == 1, FULL = MODE == 2;
     using CFG = G1Cfg<NJ>;
-    constexpr int BN = CFG::BN, STAGE = CFG::STAGE, SS = CFG::SS, BPW = CFG::BPW, CPR = CFG::CPR;
+    constexpr int BN = CFG::BN, STAGE = CFG::STAGE, SS = CFG::SS, BPW = CFG::BPW, CPR = CFG::CPR, NST = CFG::NST, DPW = CFG::DMA_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(g1_lds_u8*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
         bsrc[h] = (const unsigned char*)(p.b + (size_t)(n0 + row) * p.K + logical * 8);
     }
     auto issue = [&](int k) {
-        const uint32_t sb = lds0 + (uint32_t)(k % G1_NST) * STAGE;
+        const uint32_t sb = lds0 + (uint32_t)(k % NST) * STAGE;
         const size_t ko = (size_t)k * (G1_KC * 2);
         if (G1_ABL & 2) return;
         g1_dma16(alive[0] ? asrc[0] + ko : asrc[0], sb + (uint32_t)wave * 1024);
@@ -154,17 +155,18 @@ __global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
     // here: with one tap per K chunk there is no register-only phase long enough to pay for the second barrier.)
     const int nk = p.nk;
 #pragma unroll
-    for (int k = 0; k < G1_NST - 1; ++k)
+    for (int k = 0; k < NST - 1; ++k)
         if (k < nk) issue(k);
     for (int k = 0; k < nk; ++k) {
-        const int rem = nk - 1 - k;                                 // stages issued after stage k
-        if (rem >= G1_NST - 2) G1_WAIT_VM(2 * CFG::DMA_PER_WAVE);
-        else if (rem == 1) G1_WAIT_VM(CFG::DMA_PER_WAVE);
+        const int rem = nk - 1 - k;                                 // stages issued after stage k: min(rem, NST - 2) stay in flight
+        if (rem >= NST - 2) G1_WAIT_VM((NST - 2) * DPW);
+        else if (rem == 2) G1_WAIT_VM(2 * DPW);
+        else if (rem == 1) G1_WAIT_VM(DPW);
         else G1_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();                               // stage k is complete; everyone has left stage k-1
         asm volatile("" ::: "memory");
-        if (k + G1_NST - 1 < nk) issue(k + G1_NST - 1);
-        const unsigned char* sb = smem + (k % G1_NST) * STAGE;
+        if (k + NST - 1 < nk) issue(k + NST - 1);
+        const unsigned char* sb = smem + (k % NST) * STAGE;
         u32x4 fa[2][2], fb[NJ][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
