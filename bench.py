@@ -220,7 +220,9 @@ def main():
     if graphed is not None:
         # one captured hipGraph launch per step; per-kernel events cannot be read inside a replay, so the
         # dominant kernel's launch durations are measured on eager steps AFTER the timed region
-        for _ in range(2):
+        # the W warm-up steps above ran eagerly (capture needs them); the clocks and the caches then sit through the capture,
+        # so the replays get W untimed steps of their own (first replays after a capture run ~2 % slow)
+        for _ in range(max(2, args.warmup)):
             graphed.replay()
         sync()
         t0 = time.perf_counter()
