@@ -142,7 +142,7 @@ bool pp3x3_ok(int N, int H, int W, int C, int Nout, int dgrad, int fused);
 int64_t pp3x3_slices(int N, int H, int W, int C, int Nout, int dgrad);
 int pp3x3_launch(const PPArgs& a, hipStream_t s);
 // conv_gemm1x1.hip: dense 1x1 / stride-1 convolutions as a GEMM with a four-stage LDS-DMA ring (bf16)
-int gemm1x1_pick(int64_t M, int K, int Nout);          // 0: no; 2 / 4: column blocks per wave
+int gemm1x1_pick(int64_t M, int K, int Nout, int full);          // 0: no; 2 / 4: column blocks per wave
 int64_t gemm1x1_slices(int64_t M);
 struct G1Args {
     const void* a; const void* b; void* c;            // [M][K], [Nout][K], [M][Nout]  (bf16)

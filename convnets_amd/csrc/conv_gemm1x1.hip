@@ -3,6 +3,8 @@
 // bottleneck blocks (/root/reference/src/resnet.py:165-178) at the 28x28 / 14x14 / 7x7 stages, forward, and their data
 // gradients when no side operand is fused into the epilogue.
 //
+// (256 x 128 tiles keep three stages = 72 KiB and run two workgroups per CU; 256 x 256 tiles four stages, one workgroup.)
+//
 // Why a second kernel next to igemm_gather_kernel (conv_igemm.hip): ablated builds of that kernel on these layers (DESIGN.md
 // section 9: full / loads only / MFMAs only) show that its single-buffer loop adds load time and MFMA time up, and that the
 // loads already run at the rate the L2 -> LDS path delivers (22 TB/s) because every 128 x 128 tile re-reads its A rows once
@@ -37,8 +39,8 @@ constexpr int G1_ASTAGE = G1_BM * G1_ROWB;
 template <int NJ> struct G1Cfg {
     static constexpr int BN = 64 * NJ;
     static constexpr int BSTAGE = BN * G1_ROWB, STAGE = G1_ASTAGE + BSTAGE;
-    static constexpr int NST = 4;                                   // ring stages (a fifth one for the 256 x 128 tile measured no gain)
-    static constexpr int LDS = NST * STAGE;                         // 96 KiB (NJ = 2) / 128 KiB (NJ = 4)
+    static constexpr int NST = NJ == 2 ? 3 : 4;                     // ring stages
+    static constexpr int LDS = NST * STAGE;                         // 72 KiB (NJ = 2: two workgroups per CU) / 128 KiB (NJ = 4)
     static constexpr int SS = 32 * NJ * 2 + 16;                     // staged row: the wave's 32 NJ channels + pad
     static constexpr int BPW = BN / 16 / 8;                         // B pieces (1 KiB = 16 rows) per wave and stage
     static constexpr int DMA_PER_WAVE = 2 + BPW;
@@ -79,7 +81,7 @@ __device__ __forceinline__ void g1_dma16(const void* g, uint32_t lds_addr) {    
 
 // MODE: 0 plain, 1 BN statistics partials of the output, 2 data-gradient side operands
 template <int NJ, int MODE>
-__global__ __launch_bounds__(512) void gemm1x1_kernel(const G1Params p) {
+__global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 2 : 1) void gemm1x1_kernel(const G1Params p) {
     constexpr bool STATS = MODE == 1, FULL = MODE == 2;
     using CFG = G1Cfg<NJ>;
     constexpr int BN = CFG::BN, STAGE = CFG::STAGE, SS = CFG::SS, BPW = CFG::BPW, CPR = CFG::CPR, NST = CFG::NST, DPW = CFG::DMA_PER_WAVE;
@@ -348,19 +350,24 @@ bool gemm1x1_shape_ok(int64_t M, int K, int Nout) {
     return M > 0 && K >= 64 && K % G1_KC == 0 && Nout % 128 == 0 && M * (int64_t)(K > Nout ? K : Nout) < (1ll << 31);
 }
 
-// 0: not taken; 2 / 4: column blocks per wave (256 x 128 / 256 x 256 tiles).  CNK_GEMM1X1: 0 off, 1 by measurement
-// (tools/bench_g1.py, A/B in one process), 2 / 4 force that tile wherever the shape fits.
-int gemm1x1_pick(int64_t M, int K, int Nout) {
+// 0: not taken; 2 / 4: column blocks per wave (256 x 128 / 256 x 256 tiles).  full: the launch carries data-gradient side
+// operands (MODE 2: its registers allow one workgroup per CU).  CNK_GEMM1X1: 0 off, 1 by measurement (tools/bench_g1.py, A/B
+// in one process on MI355X), 2 / 4 force that tile wherever the shape fits.
+int gemm1x1_pick(int64_t M, int K, int Nout, int full) {
     const int mode = g1_env("CNK_GEMM1X1", 1);
     if (mode == 0 || !gemm1x1_shape_ok(M, K, Nout)) return 0;
     if (mode == 4) return Nout % 256 == 0 ? 4 : 2;
     if (mode == 2) return 2;
-    // by measurement (MI355X, batch 256): the deep layers whose K is long and whose 128 x 128 tiles under-fill the chip.
-    //   1024->256 @14x14  52 -> 43 us (256 x 256, 196 tiles)     1024->512 @14x14  82 -> 76 us (256 x 256, 392 tiles)
-    //   2048->512 @7x7    62 -> 44 us (256 x 128, 196 tiles)     everything with K <= 512 or at 28x28 / 56x56: the old kernel
-    const int64_t tm = (M + G1_BM - 1) / G1_BM;
-    if (K >= 1024 && Nout % 256 == 0 && tm * (Nout / 256) >= 150) return 4;
-    if (K >= 1024 && tm * (Nout / 128) >= 96 && tm * (Nout / 128) <= 300) return 2;     // also batch 128: 1024->256 37 -> 28 us, 2048->512 57 -> 42
+    const int64_t tm = (M + G1_BM - 1) / G1_BM, t2 = tm * (Nout / 128), t4 = Nout % 256 == 0 ? tm * (Nout / 256) : 0;
+    // long K, enough 256 x 256 tiles:   1024->256 @14x14 50 -> 41 us, 1024->512 78 -> 74, data gradient of 256->1024 with the BN
+    // backward fused 65 -> 56
+    if (K >= 1024 && t4 >= 150) return 4;
+    if (full) return (K >= 1024 && t2 >= 96 && t2 <= 300) ? 2 : 0;      // fused data gradients: 512->2048 @7x7 68 -> 51 us; batch 128: 256->1024 @14x14 44 -> 34
+    // long K, few tiles:   2048->512 @7x7 62 -> 44 us; batch 128: 1024->256 @14x14 37 -> 28
+    if (K >= 1024 && t2 >= 96 && t2 <= 300) return 2;
+    // 256 x 128 tiles, two workgroups per CU:   512->256 @28x28 94 -> 88 us, 256->1024 @14x14 57 -> 54, 512->2048 @7x7 46 -> 45.7;
+    // narrower outputs (512->128) and shorter K (128->512, 64->256) stay on the 128 x 128 kernel
+    if (K >= 256 && Nout >= 256 && t2 >= 256) return 2;
     return 0;
 }
 

@@ -835,7 +835,7 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         return pp3x3_launch(a, s);
     }
     if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.relu && !(p.stats && (p.addend || p.bnf_x)))
-        if (const int nj = gemm1x1_pick(p.M, p.C, p.Nout)) {
+        if (const int nj = gemm1x1_pick(p.M, p.C, p.Nout, p.addend || p.bnf_x)) {
             G1Args a = {};
             a.a = p.src; a.b = p.wpk; a.c = p.dst; a.bias = p.bias; a.stats = p.stats;
             a.addend = p.addend; a.addend_mask = p.addend_mask;
@@ -915,7 +915,7 @@ int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     if (pp_desc(d, CNK_PASS_FWD)) return pp3x3_slices(d->N, d->H, d->W, d->Cin, d->Cout, 0);
     if (d->dtype == CNK_BF16 && conv_groups(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h == 1 && d->stride_w == 1 &&
-        d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 && gemm1x1_pick((int64_t)d->N * Ho * Wo, d->Cin, d->Cout))
+        d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 && gemm1x1_pick((int64_t)d->N * Ho * Wo, d->Cin, d->Cout, 0))
         return gemm1x1_slices((int64_t)d->N * Ho * Wo);
     return ceil_div(d->N * Ho * Wo, BM);
 }
@@ -978,7 +978,7 @@ int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     if (pp_desc(d, CNK_PASS_DGRAD)) return pp3x3_slices(d->N, d->H, d->W, d->Cout, d->Cin, 1);
     if (d->dtype == CNK_BF16 && conv_groups(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h == 1 && d->stride_w == 1 &&
         d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 &&
-        gemm1x1_pick((int64_t)d->N * d->H * d->W, d->Cout, d->Cin))
+        gemm1x1_pick((int64_t)d->N * d->H * d->W, d->Cout, d->Cin, 1))
         return gemm1x1_slices((int64_t)d->N * d->H * d->W);          // the ring GEMM (conv_gemm1x1.hip): one record per 256 rows
     DgradClass cls[16];
     int nc = dgrad_classes(d, cls);
