@@ -79,9 +79,11 @@ __device__ __forceinline__ void g1_dma16(const void* g, uint32_t lds_addr) {    
 }
 #define G1_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory")
 
-// MODE: 0 plain, 1 BN statistics partials of the output, 2 data-gradient side operands
+// MODE: 0 plain, 1 BN statistics partials of the output, 2 data-gradient side operands.  (The second launch-bounds argument is
+// waves per SIMD: 4 = two 256 x 128 workgroups per CU; MODE 2 needs 151 registers -- squeezed into 128 it spilled and its
+// fused data gradients got 25-50 % slower, so it keeps one workgroup per CU.)
 template <int NJ, int MODE>
-__global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 2 : 1) void gemm1x1_kernel(const G1Params p) {
+__global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_kernel(const G1Params p) {
     constexpr bool STATS = MODE == 1, FULL = MODE == 2;
     using CFG = G1Cfg<NJ>;
     constexpr int BN = CFG::BN, STAGE = CFG::STAGE, SS = CFG::SS, BPW = CFG::BPW, CPR = CFG::CPR, NST = CFG::NST, DPW = CFG::DMA_PER_WAVE;
