@@ -1,27 +1,28 @@
-// Dense 1x1 / stride-1 convolution as a plain GEMM with a deep LDS-DMA ring, bf16:  C[m][n] = sum_k A[m][k] * B[n][k]
+// Dense 1x1 / stride-1 convolution as a plain GEMM with an LDS-DMA ring, bf16:  C[m][n] = sum_k A[m][k] * B[n][k]
 // (A = NHWC activations flattened to [M][K], B = the packed weight image [Nout][K]).  Sites served: the 1x1 convs of the
-// bottleneck blocks (/root/reference/src/resnet.py:165-178) at the 28x28 / 14x14 / 7x7 stages, forward, and their data
-// gradients when no side operand is fused into the epilogue.
-//
-// (256 x 128 tiles keep three stages = 72 KiB and run two workgroups per CU; 256 x 256 tiles four stages, one workgroup.)
+// bottleneck blocks (/root/reference/src/resnet.py:165-178) on the 28x28 / 14x14 / 7x7 maps: forward (bias, BN statistics
+// partials) and data gradient (gradient addend + mask, fused BN-backward reduction), wherever gemm1x1_pick measured it ahead.
 //
 // Why a second kernel next to igemm_gather_kernel (conv_igemm.hip): ablated builds of that kernel on these layers (DESIGN.md
 // section 9: full / loads only / MFMAs only) show that its single-buffer loop adds load time and MFMA time up, and that the
 // loads already run at the rate the L2 -> LDS path delivers (22 TB/s) because every 128 x 128 tile re-reads its A rows once
-// per column tile and its B rows once per row tile.  Here: 256 x 128 or 256 x 256 tiles (a quarter / half fewer L2 bytes per
-// flop) on ONE
-// 512-thread workgroup per CU, K in steps of 32 channels through a FOUR-stage ring filled by LDS-DMA three steps ahead, one
-// raw barrier per step, completions counted with s_waitcnt vmcnt(N) -- loads and MFMAs overlap inside the workgroup.
+// per column tile and its B rows once per row tile.  Here a 512-thread workgroup owns a 256 x 128 or 256 x 256 tile (a quarter
+// / half fewer L2 bytes per flop) and walks K in steps of 32 channels through a ring of LDS stages filled by LDS-DMA NST - 1
+// steps ahead, with one raw barrier per step and completions counted by s_waitcnt vmcnt(N):
 //
-//   step k:  wait for this wave's three DMAs of stage k (6 younger ones may stay in flight) | s_barrier | issue stage k+3
-//            into the slot read in step k-1 | 8 ds_read_b128 of stage k | 8 v_mfma_f32_32x32x16_bf16
+//   step k:  wait for this wave's DMAs of stage k (those of the NST - 2 younger stages stay in flight) | s_barrier |
+//            issue stage k + NST - 1 into the slot read in step k-1 | the stage's ds_read_b128s | its MFMAs
+//
+//   256 x 128: three stages = 72 KiB, 101 VGPRs  -> TWO workgroups per CU, whose barrier stalls and MFMA bursts interleave
+//   256 x 256: four stages = 128 KiB             -> one workgroup per CU, for long K with few tiles
 //
 // LDS rows hold 32 channels (64 B) of one pixel / output channel; the 16-byte piece index is XOR-ed with (row >> 2) & 3 on
 // the DMA SOURCE address (the LDS image of a DMA is lane-linear), which makes the fragment reads conflict-free.
 // Every vector-memory operation of the loop is inline asm so that hipcc tracks none of them (cdna_hip_programming.md 5.7).
-// Epilogue: the wave's 64 x 64 block is staged as bf16 rows in the (now idle) ring and written with 16-byte row stores;
-// optional bias; optional BN statistics partials, one (n, mean, M2) record per 256-row tile and channel, of the ROUNDED
-// outputs, as igemm_epilogue emits them per 128-row tile.
+// Epilogue: a wave's 64 x (64 | 128) block is staged 32 rows at a time as bf16 in the (now idle) ring and written with
+// 16-byte row stores; the per-channel sums (BN statistics of the ROUNDED outputs, one (n, mean, M2) record per 256-row tile;
+// or the two sums of the fused BN backward) ride on that copy-out, as in igemm_epilogue.  Outputs are bit-identical to
+// igemm_gather_kernel's (same MFMA order along K).
 #include <cstdlib>
 
 #include "common.h"
