@@ -141,6 +141,42 @@ def load():
     return _lib
 
 
+class switches:
+    """Test / A-B hook: the library resolves its CNK_* switches once, when it is loaded (csrc/common.h CnkSwitches).
+    `with switches(CNK_PP_CFG='2'): ...` sets the variables, makes the library re-resolve them
+    (cnk_debug_reload_switches, exported but not part of include/cnk.h) and restores both on exit."""
+
+    def __init__(self, **env):
+        self.env = env
+        self.prev = {}
+
+    def __enter__(self):
+        for k, v in self.env.items():
+            self.prev[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        reload_switches()
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        reload_switches()
+        return False
+
+
+def reload_switches():
+    lib = load()
+    fn = lib.cnk_debug_reload_switches
+    fn.restype, fn.argtypes = None, []
+    fn()
+
+
 class CnkError(RuntimeError):
     pass
 

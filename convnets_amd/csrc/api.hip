@@ -2,6 +2,7 @@
 // optional HIP-event timing.  No allocation, no synchronisation (except cnk_prof_collect).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -97,6 +98,36 @@ int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dty
 int nchw_to_nhwc_dispatch(const float* x, void* y, int N, int C, int H, int W, int dtype, hipStream_t s);
 int adam_dispatch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step, const float* bias_dev, hipStream_t s);
 void adam_bias_corrections(float b1, float b2, int step, float* out);
+
+// ---- A/B switches: read once at load (common.h) ------------------------------------------------------
+static CnkSwitches read_switches() {
+    auto env = [](const char* name, int dflt) {
+        const char* e = getenv(name);
+        return (e && *e) ? atoi(e) : dflt;
+    };
+    CnkSwitches w;
+    w.pp3x3 = env("CNK_PP3X3", 1);
+    w.pp_cfg = env("CNK_PP_CFG", -1);
+    w.pp_full = env("CNK_PP_FULL", -1);
+    w.gemm1x1 = env("CNK_GEMM1X1", 1);
+    w.igemm_halo = env("CNK_IGEMM_HALO", 1);
+    w.igemm_halo_pf = env("CNK_IGEMM_HALO_PF", -1);
+    w.rowpatch_stats = env("CNK_ROWPATCH_STATS", 1);
+    w.wgrad_big = env("CNK_WGRAD_BIG", 1);
+    w.wgrad3 = env("CNK_WGRAD3", 1);
+    w.bn_pool_elementwise = getenv("CNK_BN_POOL_ELEMENTWISE") ? 1 : 0;
+    w.bn_fused_final = env("CNK_BN_FUSED_FINAL", 1);
+    return w;
+}
+static CnkSwitches g_switches = read_switches();          // dynamic initialiser: runs when the library is loaded
+const CnkSwitches& cnk_sw() { return g_switches; }
+// test hook (not in include/cnk.h): re-resolve the table after os.environ changed.  Not thread-safe against
+// concurrent launches -- callers are single-threaded A/B scripts and tests.
+extern "C" void cnk_debug_reload_switches() { g_switches = read_switches(); }
+
+static std::atomic<int64_t> g_counters[CNK_CNT_MAX];
+void cnk_count(int id) { g_counters[id].fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t cnk_debug_counter(int id) { return id >= 0 && id < CNK_CNT_MAX ? g_counters[id].load(std::memory_order_relaxed) : -1; }
 
 // ---- error text -----------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -310,9 +341,7 @@ int cnk_pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int3
 
 int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d) {
     if (igemm_supported(d, CNK_PASS_FWD)) return igemm_fwd_stat_slices(d);
-    const char* e = getenv("CNK_ROWPATCH_STATS");            // A/B switch, read per call
-    const bool rp_stats = !(e && atoi(e) == 0);
-    return rp_stats && rowpatch_supported(d) ? rowpatch_fwd_stat_slices(d) : 0;
+    return cnk_sw().rowpatch_stats && rowpatch_supported(d) ? rowpatch_fwd_stat_slices(d) : 0;
 }
 
 int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream) {

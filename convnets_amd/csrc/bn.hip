@@ -10,6 +10,7 @@
 //                   pass 2  bn_bwd_apply  dx = a*(dy' - b1 - xhat*b2); optional dresidual = dy'
 // Algorithmic bytes: forward 3*E*s (x twice, y once), backward reads dy,x(,y) twice + writes dx.
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -252,6 +253,156 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     float sc = gamma[c] * invstd;
     scale[c] = sc;
     shift[c] = beta[c] - ma * sc;
+}
+
+// ---- merge + finalisation of a long partial list in ONE launch (round 3) -----------------------------------------------
+// bn_premerge + bn_finalize (or bn_bwd_final) were two dependent ~6 us launches in front of every BN streaming pass whose
+// partials come from a conv epilogue with >= 1024 row tiles.  Here the merge blocks publish their share with write-through
+// (sc1) stores, drain them, and draw a ticket; the block that draws the last ticket of its 64-channel group merges the
+// shares in share order (fixed summation order: the result does not depend on which block is last) and finalises.
+// No release fence anywhere (MI355X_MICROARCH.md: an agent-scope release is an L2 write-back -- round 2's attempt with
+// __threadfence() in every block of the STREAMING pass lost 1.4 ms per step); the last block of a group runs one acquire
+// (L1 invalidate of its own CU) and reads the shares with sc1 loads.  cdna_hip_programming.md 5, "Projection GEMM" item 2.
+// Tickets live in a __device__ array (zero at module load), 64 slots handed out round-robin by the host so that launches in
+// flight on different streams never share a counter; the last block resets its counter for the slot's next user.
+constexpr int BNF_SLOTS = 64, BNF_GROUPS = 64;
+__device__ unsigned int bn_tickets[BNF_SLOTS * BNF_GROUPS];
+
+struct BnFinalFwd {
+    static constexpr int NV = 3;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var; float* save_mean; float* save_invstd; float* scale; float* shift;
+    float eps, momentum;
+    __device__ __forceinline__ void operator()(int c, int64_t M, float /*n*/, float ma, float qa) const {
+        float var = qa / (float)M;
+        float invstd = rsqrtf(var + eps);
+        invstd = invstd * (1.5f - 0.5f * (var + eps) * invstd * invstd);      // as bn_finalize_kernel
+        save_mean[c] = ma;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            float unb = M > 1 ? qa / (float)(M - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ma;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        }
+        float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - ma * sc;
+    }
+};
+struct BnFinalBwd {
+    static constexpr int NV = 2;
+    const float* gamma; const float* invstd;
+    float* dgamma; float* dbeta; float* coefA; float* coefB1; float* coefB2;
+    int accumulate;
+    __device__ __forceinline__ void operator()(int c, int64_t M, float a, float b, float) const {
+        dbeta[c] = accumulate ? dbeta[c] + a : a;
+        dgamma[c] = accumulate ? dgamma[c] + b : b;
+        coefA[c] = gamma[c] * invstd[c];
+        coefB1[c] = a / (float)M;
+        coefB2[c] = b / (float)M;
+    }
+};
+
+template <class FIN>
+__global__ __launch_bounds__(256) void bn_merge_final_kernel(const float* __restrict__ partial, int slices, int C, int64_t M,
+                                                             float* __restrict__ out, int slot, const FIN fin) {
+    constexpr int NV = FIN::NV;
+    __shared__ float sh[NV][4][64];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int shares = gridDim.y;
+    const int per = (slices + shares - 1) / shares;
+    const int s0 = blockIdx.y * per, s1 = min(slices, s0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        int s = s0 + wave;
+        for (; s + 28 < s1; s += 32) {                 // eight independent records in flight per lane
+            float v[8][NV];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[u][k] = partial[((size_t)(s + 4 * u) * C + c) * NV + k];
+            if constexpr (NV == 3) {
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) chan_merge(v[u][0], v[u][1], v[u][2], v[u + 1][0], v[u + 1][1], v[u + 1][2]);
+                chan_merge(v[0][0], v[0][1], v[0][2], v[2][0], v[2][1], v[2][2]);
+                chan_merge(v[4][0], v[4][1], v[4][2], v[6][0], v[6][1], v[6][2]);
+                chan_merge(v[0][0], v[0][1], v[0][2], v[4][0], v[4][1], v[4][2]);
+                chan_merge(a0, a1, a2, v[0][0], v[0][1], v[0][2]);
+            } else {
+                a0 += ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) + ((v[4][0] + v[5][0]) + (v[6][0] + v[7][0]));
+                a1 += ((v[0][1] + v[1][1]) + (v[2][1] + v[3][1])) + ((v[4][1] + v[5][1]) + (v[6][1] + v[7][1]));
+            }
+        }
+        for (; s < s1; s += 4) {
+            const float* o = partial + ((size_t)s * C + c) * NV;
+            if constexpr (NV == 3) chan_merge(a0, a1, a2, o[0], o[1], o[2]);
+            else { a0 += o[0]; a1 += o[1]; }
+        }
+    }
+    sh[0][wave][lane] = a0;
+    sh[1][wave][lane] = a1;
+    if constexpr (NV == 3) sh[2][wave][lane] = a2;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        if constexpr (NV == 3) {
+            for (int w = 1; w < 4; ++w) chan_merge(a0, a1, a2, sh[0][w][lane], sh[1][w][lane], sh[2][w][lane]);
+        } else {
+            a0 = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
+            a1 = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+        }
+        // publish: write-through stores (global_store_dword sc1), visible device-wide once drained
+        float* o = out + ((size_t)blockIdx.y * C + c) * NV;
+        __hip_atomic_store(o + 0, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (NV == 3) __hip_atomic_store(o + 2, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores ...
+    __syncthreads();                                          // ... before the one lane that signals for all of them
+    unsigned int* ticket = bn_tickets + slot * BNF_GROUPS + blockIdx.x;
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t == (unsigned)shares - 1u;
+        if (is_last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the slot's next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!is_last) return;
+    // the last block of this channel group: merge the shares in share order (wave w: shares w, w+4, ...), sc1 loads only
+    a0 = a1 = a2 = 0.f;
+    if (c < C) {
+        for (int s = wave; s < shares; s += 16) {
+            float v[4][NV];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int ss = s + 4 * u;
+                    v[u][k] = ss < shares ? __hip_atomic_load(out + ((size_t)ss * C + c) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (NV == 3) chan_merge(a0, a1, a2, v[u][0], v[u][1], v[u][2]);
+                else { a0 += v[u][0]; a1 += v[u][1]; }
+            }
+        }
+    }
+    sh[0][wave][lane] = a0;
+    sh[1][wave][lane] = a1;
+    if constexpr (NV == 3) sh[2][wave][lane] = a2;
+    __syncthreads();
+    if (wave != 0 || c >= C) return;
+    if constexpr (NV == 3) {
+        for (int w = 1; w < 4; ++w) chan_merge(a0, a1, a2, sh[0][w][lane], sh[1][w][lane], sh[2][w][lane]);
+    } else {
+        a0 = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
+        a1 = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+    }
+    fin(c, M, a0, a1, a2);
 }
 
 __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rmean,
@@ -868,6 +1019,27 @@ static int bn_premerge(const float*& partial, int& slices, int C, float* scratch
     return 0;
 }
 
+// One launch for merge + finalisation (bn_merge_final_kernel) when the list is long enough to need two levels.
+// Returns 1 when taken (done), 0 when the caller should run the two-kernel path, < 0 on error.
+static std::atomic<unsigned> g_bnf_slot{0};
+template <class FIN>
+static int bn_merge_final(const float* partial, int slices, int C, int64_t M, float* scratch, int64_t scratch_floats,
+                          const FIN& fin, hipStream_t s) {
+    if (!cnk_sw().bn_fused_final || slices < 1024 || ceil_div(C, 64) > BNF_GROUPS) return 0;
+    const int shares = slices >= 2048 ? 64 : 32;          // ~sqrt(slices): merge depth == finalisation depth
+    if ((int64_t)shares * C * FIN::NV > scratch_floats) return 0;
+    const int slot = (int)(g_bnf_slot.fetch_add(1, std::memory_order_relaxed) % BNF_SLOTS);
+    hipLaunchKernelGGL((bn_merge_final_kernel<FIN>), dim3(ceil_div(C, 64), shares), dim3(256), 0, s, partial, slices, C, M,
+                       scratch, slot, fin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cnk_set_error("bn_merge_final: launch failed: %s", hipGetErrorString(e));
+        return -2;
+    }
+    cnk_count(CNK_CNT_BN_FUSED_FINAL);
+    return 1;
+}
+
 template <typename T, int VEC>
 static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* res,
                           void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si,
@@ -885,12 +1057,21 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
         CNK_CHECK_LAUNCH("bn_stats");
         partial = own;
         slices = g.slices;
-    } else if (int rc = bn_premerge<3>(partial, slices, C, ws + ws_partials_off(C), (int64_t)g.slices * C * 3, s)) {
-        return rc;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, slices, C,
-                       M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
-    CNK_CHECK_LAUNCH("bn_finalize");
+    int fused_final = 0;
+    if (ext_partial) {
+        const BnFinalFwd fin = {gamma, beta, rm, rv, sm, si, scale, shift, eps, mom};
+        fused_final = bn_merge_final(partial, slices, C, M, ws + ws_partials_off(C), (int64_t)g.slices * C * 3, fin, s);
+        if (fused_final < 0) return -fused_final;
+        if (!fused_final)
+            if (int rc = bn_premerge<3>(partial, slices, C, ws + ws_partials_off(C), (int64_t)g.slices * C * 3, s)) return rc;
+    }
+    if (!fused_final) {
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, slices, C,
+                           M, gamma, beta, rm, rv, sm, si, scale, shift, eps, mom);
+        CNK_CHECK_LAUNCH("bn_finalize");
+        cnk_count(CNK_CNT_BN_FINAL_LAUNCH);
+    }
     if (!y) return 0;                        // statistics only: scale | shift stay at ws[0..C) | ws[C..2C) for the caller
     const dim3 grid(g.slices, g.colgroups);
 #define CNK_BN_APPLY(R, A, W)                                                                              \
@@ -961,10 +1142,15 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
     const int act = (!relu || ext_partial) ? ACT_NONE : mask ? ACT_BITS : y ? ACT_Y : ACT_REMASK;
     const dim3 grid(g.slices, g.colgroups);
     int nslices = g.slices;
+    int fused_final = 0;
     if (ext_partial) {
         const float* ep = ext_partial;
         nslices = (int)ext_slices;
-        if (int rc = bn_premerge<2>(ep, nslices, C, partial, (int64_t)g.slices * C * 3, s)) return rc;
+        const BnFinalBwd fin = {gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate};
+        fused_final = bn_merge_final(ep, nslices, C, M, partial, (int64_t)g.slices * C * 3, fin, s);
+        if (fused_final < 0) return -fused_final;
+        if (!fused_final)
+            if (int rc = bn_premerge<2>(ep, nslices, C, partial, (int64_t)g.slices * C * 3, s)) return rc;
         partial = const_cast<float*>(ep);
     } else {
 #define CNK_BN_RED(A)                                                                                       \
@@ -979,9 +1165,12 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
 #undef CNK_BN_RED
     CNK_CHECK_LAUNCH("bn_bwd_reduce");
     }
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, nslices,
-                       C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
-    CNK_CHECK_LAUNCH("bn_bwd_final");
+    if (!fused_final) {
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, nslices,
+                           C, M, gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate);
+        CNK_CHECK_LAUNCH("bn_bwd_final");
+        cnk_count(CNK_CNT_BN_FINAL_LAUNCH);
+    }
 #define CNK_BN_BAPP(A, W)                                                                                     \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, A, W>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \
                        (const T*)y, (T*)dx, (T*)dres, mask, beta, sm, si, coefA, coefB1, coefB2, M, C, g)
@@ -1256,7 +1445,7 @@ static int bn_bwd_pool_t(const void* dy, const unsigned char* idx, const void* x
     float* coefB2 = ws + 3 * C;
     float* partial = ws + ws_partials_off(C);
     PoolCell pc;
-    const bool cell = make_pool_cell(pc, H, W, kh, kw, sh, sw, ph, pw) && !getenv("CNK_BN_POOL_ELEMENTWISE");
+    const bool cell = make_pool_cell(pc, H, W, kh, kw, sh, sw, ph, pw) && !cnk_sw().bn_pool_elementwise;
     if (cell) {
         const int64_t cells = (int64_t)N * pc.cells_h * pc.cells_w;
         SliceGeom gc = make_geom(cells, C, VEC);

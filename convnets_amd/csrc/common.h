@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/cnk.h"
 
 typedef __bf16 bf16;
@@ -34,6 +35,61 @@ void cnk_set_error(const char* fmt, ...);
             cnk_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
             return 2;                                                       \
         }                                                                   \
+    } while (0)
+
+// ---- A/B switches (host; api.hip) ----------------------------------------------------------------
+// Every CNK_* environment switch of the library is resolved ONCE, when libcnk.so is loaded, into this table; a
+// slice / workspace query and the launch it sizes therefore always see the same choice, and no launch
+// path calls getenv.  In-process A/B runs (tests/, tools/bench_*.py) change os.environ and then call the test hook
+// cnk_debug_reload_switches() (exported, deliberately not part of include/cnk.h).
+struct CnkSwitches {
+    int pp3x3;                 // CNK_PP3X3 (1): ping-pong 3x3 core on / off
+    int pp_cfg;                // CNK_PP_CFG (-1): force configuration 0..3 of conv_pp.hip where it fits
+    int pp_full;               // CNK_PP_FULL (-1): 1 / 0 force the fused data gradients onto / off the ping-pong core
+    int gemm1x1;               // CNK_GEMM1X1 (1): 0 off, 1 by rule, 2 / 4 force that tile
+    int igemm_halo;            // CNK_IGEMM_HALO (1)
+    int igemm_halo_pf;         // CNK_IGEMM_HALO_PF (-1): 0 / 1 force the plain / weight-prefetching halo kernel
+    int rowpatch_stats;        // CNK_ROWPATCH_STATS (1)
+    int wgrad_big;             // CNK_WGRAD_BIG (1)
+    int wgrad3;                // CNK_WGRAD3 (1)
+    int bn_pool_elementwise;   // CNK_BN_POOL_ELEMENTWISE (0)
+    int bn_fused_final;        // CNK_BN_FUSED_FINAL (1): finalisation of the BN partials inside the merge launch
+};
+const CnkSwitches& cnk_sw();
+
+// Launch counters per kernel variant (test hook cnk_debug_counter(id), exported, not part of include/cnk.h): a parity
+// test that forces a configuration asserts through these that the configuration actually ran.
+enum {
+    CNK_CNT_PP_A = 0, CNK_CNT_PP_A1 = 1, CNK_CNT_PP_B = 2, CNK_CNT_PP_C = 3,      // conv_pp.hip configurations
+    CNK_CNT_HALO = 4, CNK_CNT_HALO_PF = 5, CNK_CNT_GATHER = 6, CNK_CNT_G1_2 = 7, CNK_CNT_G1_4 = 8,
+    CNK_CNT_PP_FULL = 9,                                                          // ping-pong launches with the FULL epilogue
+    CNK_CNT_BN_FUSED_FINAL = 10, CNK_CNT_BN_FINAL_LAUNCH = 11,
+    CNK_CNT_MAX = 32
+};
+void cnk_count(int id);
+
+// ---- opt-in for more than 64 KiB of dynamic LDS ------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one static object of this type per
+// kernel instantiation remembers the devices already set (a bit per device, atomic: launches come from the Python main
+// thread and from autograd's device thread), and the return code is checked.
+struct LdsOptIn {
+    std::atomic<uint64_t> done{0};
+    hipError_t ensure(const void* fn, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+        return e;
+    }
+};
+#define CNK_LDS_OPTIN(kernel, bytes, name)                                                              \
+    do {                                                                                                \
+        static LdsOptIn optin__;                                                                        \
+        const hipError_t oe__ = optin__.ensure((const void*)(kernel), (bytes));                         \
+        CNK_CHECK_ARG(oe__ == hipSuccess, "%s: cannot reserve %d bytes of LDS: %s", name, (int)(bytes), \
+                      hipGetErrorString(oe__));                                                         \
     } while (0)
 
 // ---- profiling hooks (host; api.hip) ------------------------------------------------------------

@@ -341,11 +341,6 @@ __global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_ke
     }
 }
 
-int g1_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 }  // namespace
 
 // shapes this kernel takes (dense 1x1 stride-1 GEMM, bf16): K a multiple of the 32-channel step, Nout of the 128-wide tile
@@ -354,23 +349,33 @@ bool gemm1x1_shape_ok(int64_t M, int K, int Nout) {
 }
 
 // 0: not taken; 2 / 4: column blocks per wave (256 x 128 / 256 x 256 tiles).  full: the launch carries data-gradient side
-// operands (MODE 2: its registers allow one workgroup per CU).  CNK_GEMM1X1: 0 off, 1 by measurement (tools/bench_g1.py, A/B
-// in one process on MI355X), 2 / 4 force that tile wherever the shape fits.
+// operands (MODE 2: its registers allow one workgroup per CU).  CNK_GEMM1X1: 0 off, 1 by rule, 2 / 4 force that tile
+// wherever the shape fits.
+//
+// The rule is stated in WORK PER CU (256 CUs, one or two resident workgroups each), not in batch-specific tile counts:
+//   * the ring pays off when its fill / drain (3 steps) is amortised over a long K loop: >= 32 steps of 32 channels;
+//   * a 256 x 256 tile needs >= 0.59 tiles per CU (else most CUs idle and the 128 x 128 kernel's finer grain wins);
+//   * 256 x 128 tiles with a long K loop are taken for 0.375 .. 1.17 tiles per CU (one, partly filled round of the
+//     chip: the old kernel's 128-row tiles would make several rounds), with or without the fused epilogue;
+//   * with a medium K loop (>= 8 steps) and >= 256 output channels, 256 x 128 tiles are taken once there is at least one
+//     per CU: two workgroups then share a CU and cover each other's barrier stalls.
+// Measured on MI355X (tools/bench_g1.py, A/B in one process) at batch 256 and 128; tests/test_gpu_round3.py sweeps the
+// batch 32 .. 256 for equal results whatever this picks.
+constexpr int G1_CUS = 256;
 int gemm1x1_pick(int64_t M, int K, int Nout, int full) {
-    const int mode = g1_env("CNK_GEMM1X1", 1);
+    const int mode = cnk_sw().gemm1x1;
     if (mode == 0 || !gemm1x1_shape_ok(M, K, Nout)) return 0;
     if (mode == 4) return Nout % 256 == 0 ? 4 : 2;
     if (mode == 2) return 2;
     const int64_t tm = (M + G1_BM - 1) / G1_BM, t2 = tm * (Nout / 128), t4 = Nout % 256 == 0 ? tm * (Nout / 256) : 0;
-    // long K, enough 256 x 256 tiles:   1024->256 @14x14 50 -> 41 us, 1024->512 78 -> 74, data gradient of 256->1024 with the BN
-    // backward fused 65 -> 56
-    if (K >= 1024 && t4 >= 150) return 4;
-    if (full) return (K >= 1024 && t2 >= 96 && t2 <= 300) ? 2 : 0;      // fused data gradients: 512->2048 @7x7 68 -> 51 us; batch 128: 256->1024 @14x14 44 -> 34
-    // long K, few tiles:   2048->512 @7x7 62 -> 44 us; batch 128: 1024->256 @14x14 37 -> 28
-    if (K >= 1024 && t2 >= 96 && t2 <= 300) return 2;
-    // 256 x 128 tiles, two workgroups per CU:   512->256 @28x28 94 -> 88 us, 256->1024 @14x14 57 -> 54, 512->2048 @7x7 46 -> 45.7;
-    // narrower outputs (512->128) and shorter K (128->512, 64->256) stay on the 128 x 128 kernel
-    if (K >= 256 && Nout >= 256 && t2 >= 256) return 2;
+    const int ksteps = K / G1_KC;
+    const bool long_k = ksteps >= 32, one_round2 = t2 * 8 >= 3 * G1_CUS && t2 * 64 <= 75 * G1_CUS;
+    if (long_k && t4 * 128 >= 75 * G1_CUS) return 4;             // 1024->256 @14x14 50 -> 41 us, 1024->512 78 -> 74, fused dgrad of 256->1024 65 -> 56
+    if (full) return (long_k && one_round2) ? 2 : 0;           // fused data gradients: 512->2048 @7x7 68 -> 51 us; batch 128: 256->1024 @14x14 44 -> 34
+    if (long_k && one_round2) return 2;                        // 2048->512 @7x7 62 -> 44 us; batch 128: 1024->256 @14x14 37 -> 28
+    // 512->256 @28x28 94 -> 88 us, 256->1024 @14x14 57 -> 54, 512->2048 @7x7 46 -> 45.7; narrower outputs (512->128) and
+    // shorter K (128->512, 64->256) stay on the 128 x 128 kernel
+    if (ksteps >= 8 && Nout >= 256 && t2 >= G1_CUS) return 2;
     return 0;
 }
 
@@ -380,16 +385,13 @@ template <int NJ>
 static int gemm1x1_launch_t(const G1Params& p0, double algo_flops, double algo_bytes, hipStream_t s) {
     G1Params p = p0;
     p.tiles_n = p.Nout / G1Cfg<NJ>::BN;
-    static bool attr_done = false;
-    if (!attr_done) {                                               // more than 64 KiB of dynamic LDS needs the opt-in
-        const hipError_t e0 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
-        const hipError_t e1 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
-        const hipError_t e2 = hipFuncSetAttribute((const void*)gemm1x1_kernel<NJ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G1Cfg<NJ>::LDS);
-        CNK_CHECK_ARG(e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess, "gemm1x1: cannot reserve %d bytes of LDS", G1Cfg<NJ>::LDS);
-        attr_done = true;
-    }
+    // more than 64 KiB of dynamic LDS needs the opt-in (per device, common.h)
+    CNK_LDS_OPTIN((gemm1x1_kernel<NJ, 0>), G1Cfg<NJ>::LDS, "gemm1x1");
+    CNK_LDS_OPTIN((gemm1x1_kernel<NJ, 1>), G1Cfg<NJ>::LDS, "gemm1x1");
+    CNK_LDS_OPTIN((gemm1x1_kernel<NJ, 2>), G1Cfg<NJ>::LDS, "gemm1x1");
     ProfScope kscope(CNK_KF_GATHER, s, algo_flops, algo_bytes);
     const int grid = p.tiles_m * p.tiles_n;
+    cnk_count(NJ == 4 ? CNK_CNT_G1_4 : CNK_CNT_G1_2);
     if (p.addend || p.bnf_x) hipLaunchKernelGGL((gemm1x1_kernel<NJ, 2>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
     else if (p.stats) hipLaunchKernelGGL((gemm1x1_kernel<NJ, 1>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);
     else hipLaunchKernelGGL((gemm1x1_kernel<NJ, 0>), dim3(grid), dim3(512), G1Cfg<NJ>::LDS, s, p);

@@ -741,6 +741,7 @@ template <typename T, int BN, bool EDGE = false> int launch_gather(const GatherP
     if (red > epi) epi = red;
     size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
     ProfScope kscope(CNK_KF_GATHER, s, gather_flops(p), gather_bytes(p, sizeof(T)));
+    cnk_count(CNK_CNT_GATHER);
     hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
@@ -752,14 +753,7 @@ static bool pick_bn128(int M, int Nout) {
     return (Nout % 128 == 0) && ((int64_t)tiles_m * (Nout / 128) >= 512);
 }
 
-static int igemm_halo_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CNK_IGEMM_HALO");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
-}
+static int igemm_halo_enabled() { return cnk_sw().igemm_halo != 0; }
 
 // Which halo kernel: the plain one runs three workgroups per CU, the weight-prefetching one two
 // (80 KiB of LDS each) but each of them ~1.16x faster than a third of a CU.  With T tiles on 256 CUs
@@ -767,12 +761,8 @@ static int igemm_halo_enabled() {
 // saves a round (measured: 256->256 @14x14, 784 tiles: 776 vs 687 TFLOP/s; every other ResNet
 // shape is faster on the plain kernel).  CNK_IGEMM_HALO_PF=0/1 forces one of them.
 static bool igemm_halo_pf(int tiles, int bn) {
-    static int forced = -2;
-    if (forced == -2) {
-        const char* e = getenv("CNK_IGEMM_HALO_PF");
-        forced = e ? (e[0] == '0' ? 0 : 1) : -1;
-    }
-    if (forced >= 0) return forced == 1;
+    const int forced = cnk_sw().igemm_halo_pf;
+    if (forced >= 0) return forced != 0;
     if (bn != 128 || tiles <= 768) return false;
     return ceil_div(tiles, 512) * 2 * 1.16 < ceil_div(tiles, 768) * 3;
 }
@@ -797,6 +787,7 @@ static bool halo_shape(const GatherParams& p) {
 template <typename T, int BN> int launch_halo(const GatherParams& p, hipStream_t s) {
     const size_t lds = halo_lds<T, BN>(p);
     ProfScope kscope(CNK_KF_HALO, s, gather_flops(p), gather_bytes(p, sizeof(T)));
+    cnk_count(igemm_halo_pf(p.tiles_total, BN) ? CNK_CNT_HALO_PF : CNK_CNT_HALO);
     if (igemm_halo_pf(p.tiles_total, BN))
         hipLaunchKernelGGL((igemm_halo3x3_pf_kernel<T, BN>), dim3(p.tiles_total), dim3(256), lds, s, p);
     else

@@ -636,16 +636,11 @@ static size_t pp_lds_bytes(int H, int W, const PPGeom& g) {
     return (size_t)2 * pp_npg(H, W, g) * 1024 + (size_t)3 * g.bstage + 8 * PP_EPI + 1024 + 128;
 }
 
-static int pp_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // Configuration for a shape (-1: not taken): bf16 3x3 taps within +-1 on an output grid equal to the source grid,
 // channel counts on the 64 grid, a patch that fits the 56 prefetch slots and LDS, tensors below 2 GiB, >= 8 tiles.
 // CNK_PP3X3=0 turns the core off; CNK_PP_CFG=0..3 forces a configuration where it fits (tools/bench_pp.py A/B runs).
 static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
-    const int enabled = pp_env("CNK_PP3X3", 1), forced = pp_env("CNK_PP_CFG", -1);      // read per call: in-process A/B runs
+    const int enabled = cnk_sw().pp3x3, forced = cnk_sw().pp_cfg;
     if (!enabled) return -1;
     if (C % 64 || Nout % 64) return -1;
     const long long M = (long long)N * H * W;
@@ -657,13 +652,16 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
         return (M + g.bm - 1) / g.bm * (Nout / g.bn) >= 8;
     };
     if (forced >= 0 && forced < 4 && fits(forced) && !(dgrad && forced >= 2)) return forced;      // (bench / test runs only)
-    // wide outputs: 256 x 256 tiles while they still give every CU a tile, else 512 x 128, else 256 x 128
+    // Rule in work per CU (one persistent workgroup per CU, 256 CUs): the biggest tile -- 256 x 256, then 512 x 128, both
+    // with the cheaper 128 x 64 wave tile -- as long as its tiles cover at least 5/8 of the CUs; below that the 256 x 128
+    // tile's finer grain fills the chip better (7x7 layers at batch 256: 98 big tiles, 141 vs 75 us).
+    constexpr int PP_CUS = 256;
     const int order[4] = {3, 2, 0, 1};
     for (int c : order) {
         if (!fits(c)) continue;
         const PPGeom& g = PP_GEOM[c];
         const long long tiles = (M + g.bm - 1) / g.bm * (Nout / g.bn);
-        if ((c == 3 || c == 2) && tiles < 160) continue;          // too few big tiles: smaller ones fill the chip better
+        if ((c == 3 || c == 2) && tiles * 8 < 5 * PP_CUS) continue;
         // the data gradient's full epilogue (addend, fused BN backward) does not fit the registers beside 128
         // accumulators: 64 x 64 wave tiles there
         if ((c == 3 || c == 2) && dgrad) continue;
@@ -673,7 +671,8 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
         // per-wave epilogue stalls both groups, the halo kernel hides its epilogue behind two other workgroups:
         // 136 vs 114 us at 28x28, 94 vs 92 at 14x14, 76 vs 83 at 7x7 -- taken only when every workgroup has ONE tile.
         if (c == 1) continue;
-        if (dgrad && fused && tiles > 256) continue;
+        if (dgrad && fused && cnk_sw().pp_full == 0) continue;
+        if (dgrad && fused && tiles > 256 && cnk_sw().pp_full != 1) continue;
         return c;
     }
     return -1;
@@ -691,11 +690,7 @@ int64_t pp3x3_slices(int N, int H, int W, int C, int Nout, int dgrad) {
 template <class CFG> static int pp_launch_cfg(const PPParams& p, int mode, size_t lds, hipStream_t s) {
 #define PP_LAUNCH(MODEV)                                                                                                   \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)pp3x3_kernel<CFG, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
+        CNK_LDS_OPTIN((pp3x3_kernel<CFG, MODEV>), 160 * 1024, "pp3x3");                                                    \
         hipLaunchKernelGGL((pp3x3_kernel<CFG, MODEV>), dim3(p.nwg), dim3(512), lds, s, p);                                 \
     } while (0)
     if (mode == PP_EPI_FULL) PP_LAUNCH(PP_EPI_FULL);
@@ -731,6 +726,8 @@ int pp3x3_launch(const PPArgs& a, hipStream_t s) {
     const size_t lds = pp_lds_bytes(a.H, a.W, g);
     const int mode = (a.bias || a.addend || a.bnf_x || a.relu) ? PP_EPI_FULL : (a.stats ? PP_EPI_STATS : PP_EPI_PLAIN);
     ProfScope kscope(CNK_KF_HALO, s, 2.0 * p.M * (double)a.Nout * a.C * 9, a.algo_bytes);
+    cnk_count(CNK_CNT_PP_A + c);
+    if (mode == PP_EPI_FULL) cnk_count(CNK_CNT_PP_FULL);
     switch (c) {
         case 0: return pp_launch_cfg<CfgA>(p, mode, lds, s);
         case 1: return pp_launch_cfg<CfgA1>(p, mode, lds, s);

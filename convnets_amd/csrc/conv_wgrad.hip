@@ -315,16 +315,12 @@ template <typename T, int BMW, int BNW, int WM = 2, int WN = 2> int launch_wgrad
     constexpr int KP = WgCfg<T>::KP;
     size_t lds = 2 * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));   // double-buffered
     int grid = p.splits * p.tiles_co * p.ntaps * p.tiles_ci;
+    // algorithmic bytes: dy and x read once, dw written once (the split-K slabs are implementation traffic: the PMC
+    // passes show them, the roofline does not credit them -- ADVICE r02)
     ProfScope kscope(CNK_KF_WGRAD, s, 2.0 * p.M * p.Cout * (double)(p.diag ? BNW : p.Cin) * p.ntaps,
                      ((double)p.M * p.Cout + (double)p.N * p.H * p.W * p.Cin) * sizeof(T) +
-                         (double)p.splits * p.Cout * p.ntaps * (p.diag ? BNW : p.Cin) * sizeof(float));
-    if (lds > 64 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
-    }
+                         (double)p.Cout * p.ntaps * (p.diag ? BNW : p.Cin) * sizeof(float));
+    if (lds > 64 * 1024) CNK_LDS_OPTIN((wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN>), 160 * 1024, "wgrad_mfma");
     hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN>), dim3(grid), dim3(64 * WM * WN), lds, s, p);
     CNK_CHECK_LAUNCH("wgrad_mfma");
     return 0;
@@ -402,8 +398,7 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
     // (CNK_WGRAD_BIG=0: the 128x128 tiles, for in-process A/B runs)
     int slots = 512;                                         // resident workgroups: 2 per CU (80 KiB LDS each) ...
     {
-        const char* e = getenv("CNK_WGRAD_BIG");
-        const bool big = !(e && e[0] == '0') && d->dtype == CNK_BF16 && *bmw == 128 && *bnw == 128;
+        const bool big = cnk_sw().wgrad_big && d->dtype == CNK_BF16 && *bmw == 128 && *bnw == 128;
         if (big && d->Cout % 256 == 0) { *bmw = 256; slots = 256; }            // ... or 1 (112 KiB)
         else if (big && d->Cin % 256 == 0) { *bnw = 256; slots = 256; }
     }

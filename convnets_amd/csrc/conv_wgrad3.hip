@@ -314,10 +314,7 @@ static int w3_max_new_rows(int H, int W, int kp) {
 }
 
 // CNK_WGRAD3=0 turns the kernel off (A/B runs, tools/bench_wgrad.py)
-static bool w3_enabled() {
-    const char* e = getenv("CNK_WGRAD3");
-    return !(e && e[0] == '0');
-}
+static bool w3_enabled() { return cnk_sw().wgrad3 != 0; }
 
 static void w3_plan(const cnk_conv_desc* d, bool* big, int* splits, int* ksteps, int* per_split) {
     *big = d->Cout % 128 == 0;
@@ -378,14 +375,12 @@ int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, i
     const int grid = p.splits * p.tiles_co * p.tiles_ci;
     {
         ProfScope kscope(CNK_KF_WGRAD, s, 2.0 * p.M * d->Cout * (double)d->Cin * 9,
-                         ((double)p.M * d->Cout + (double)p.M * d->Cin) * 2 + (double)p.splits * d->Cout * 9 * d->Cin * sizeof(float));
+                         ((double)p.M * d->Cout + (double)p.M * d->Cin) * 2 + (double)d->Cout * 9 * d->Cin * sizeof(float));      // slabs not credited
         if (big) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<W3Big>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            CNK_LDS_OPTIN((wgrad3x3_kernel<W3Big>), 160 * 1024, "wgrad3x3");
             hipLaunchKernelGGL((wgrad3x3_kernel<W3Big>), dim3(grid), dim3(W3Big::NT), W3Big::LDS_BYTES, s, p);
         } else {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<W3Small>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            CNK_LDS_OPTIN((wgrad3x3_kernel<W3Small>), 160 * 1024, "wgrad3x3");
             hipLaunchKernelGGL((wgrad3x3_kernel<W3Small>), dim3(grid), dim3(W3Small::NT), W3Small::LDS_BYTES, s, p);
         }
         CNK_CHECK_LAUNCH("wgrad3x3");

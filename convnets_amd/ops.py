@@ -185,6 +185,8 @@ class BnRecord:
 
 
 BN_BWD_FUSE = os.environ.get('CNK_BN_BWD_FUSE', '1') != '0'
+# the same fusion for the stride-1 3x3 convs only (A/B switch, DESIGN.md: break-even per layer, see there)
+BN_BWD_FUSE_3X3 = os.environ.get('CNK_BN_BWD_FUSE_3X3', '1') != '0'
 FUSE_COUNTS = {'bn_bwd_fused': 0, 'bn_bwd_unfused': 0}      # which backward path ran (tests read this)
 
 
@@ -428,7 +430,8 @@ class Conv2dFn(torch.autograd.Function):
                 # first pass of that layer's backward in this epilogue (BnRecord)
                 rec, fuse, partial = ctx.bn_rec, None, None
                 if rec is not None and (ctx.link is None or ctx.link.final) and rec.x is not None \
-                        and rec.x.shape == x.shape and rec.x.dtype == x.dtype:
+                        and rec.x.shape == x.shape and rec.x.dtype == x.dtype \
+                        and (BN_BWD_FUSE_3X3 or desc.kh != 3 or desc.stride_h != 1):
                     slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
                     if slices > 0:
                         partial = torch.empty((slices, desc.Cin, 2), dtype=torch.float32, device=x.device)

@@ -470,14 +470,11 @@ def test_bn_backward_through_maxpool_gather(N, C, H, W, k, s, p, relu, dtype):
         # fp32 order of the per-slice sums; the element-wise kernels share its slices and agree bit for bit
         assert rel_l2(host(dx), host(dx_pair)) < 2e-6
         assert rel_l2(host(dg), host(dg_pair)) < 2e-6 and rel_l2(host(db), host(db_pair)) < 2e-6
-        os.environ['CNK_BN_POOL_ELEMENTWISE'] = '1'
-        try:
+        with _lib.switches(CNK_BN_POOL_ELEMENTWISE='1'):
             ex, eg, eb = torch.empty_like(x), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
             assert lib.cnk_bn_bwd_maxpool(P(dyp), P(idx), P(x), P(gamma), P(beta), P(sm), P(si), P(ex), P(eg), P(eb), 0, N, H, W,
                                           C, k, k, s, s, p, p, relu, code, P(ws), nws, st) == 0, lib.cnk_last_error()
             torch.cuda.synchronize()
-        finally:
-            del os.environ['CNK_BN_POOL_ELEMENTWISE']
         assert torch.equal(ex, dx_pair) and torch.equal(eg, dg_pair) and torch.equal(eb, db_pair)
     else:
         assert rel_l2(host(dx), host(dx_pair)) < 6e-3
@@ -625,10 +622,8 @@ def test_dense_1x1_ring_gemm_matches_the_implicit_gemm_kernel(N, Cin, Cout, H, b
     amask = torch.randint(0, 256, (N * H * H * Cin // 8,), generator=g, dtype=torch.uint8).cuda()
     bmean, binv = (torch.randn(Cin, generator=g) * 0.1).cuda(), (torch.rand(Cin, generator=g) + 0.5).cuda()
     bgam, bbeta = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
-    prev = os.environ.get('CNK_GEMM1X1')
-    try:
-        for mode in ('0', '2', '4', '1'):
-            os.environ['CNK_GEMM1X1'] = mode
+    for mode in ('0', '2', '4', '1'):
+        with _lib.switches(CNK_GEMM1X1=mode):
             nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
             assert nsl > 0
             part = torch.full((nsl, Cout, 3), float('nan'), device='cuda')
@@ -654,11 +649,6 @@ def test_dense_1x1_ring_gemm_matches_the_implicit_gemm_kernel(N, Cin, Cout, H, b
             tmean = (n * mean).sum(0) / tn
             tvar = (m2.sum(0) + (n * (mean - tmean) ** 2).sum(0)) / tn
             res[mode] = (y, dx, nsl, tmean, tvar)
-    finally:
-        if prev is None:
-            os.environ.pop('CNK_GEMM1X1', None)
-        else:
-            os.environ['CNK_GEMM1X1'] = prev
     assert res['2'][2] == (M + 255) // 256 and res['0'][2] == (M + 127) // 128      # one record per row tile of either kernel
     for mode in ('2', '4', '1'):
         assert torch.equal(res[mode][0], res['0'][0]) and torch.equal(res[mode][1], res['0'][1])

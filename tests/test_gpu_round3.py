@@ -1,0 +1,437 @@
+"""GPU parity (-m gpu), round-3 additions:
+  * the ping-pong 3x3 core (csrc/conv_pp.hip; reference sites src/resnet.py:171, src/vggnet.py:69) per CONFIGURATION
+    (256x128 / 512x128 / 256x256 tiles) and per EPILOGUE mode (plain, BN statistics, the full data-gradient epilogue
+    with gradient addend + packed ReLU mask + fused BN backward) against torch fp64 on the CPU from the bf16-rounded
+    operands, against the tensor the kernel itself wrote (statistics), and bit for bit against the r01 halo kernel
+    wherever the K steps are the same 64 channels -- with a launch counter asserting that the forced configuration
+    is the one that ran;
+  * BASELINE-size (bs 256) unforced checks of the layers whose dispatch lands on those configurations;
+  * AlexNet at its BASELINE size (224x224, bs 128, fp32: the 11x11/4 direct kernel at N = 128) as a property step;
+  * a batch sweep N in {32 .. 256}: whatever the work-per-CU dispatch rules choose, the results stay the same.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+# csrc/common.h launch counters
+CNT_PP = {0: 0, 1: 1, 2: 2, 3: 3}
+CNT_HALO, CNT_HALO_PF, CNT_GATHER, CNT_G1_2, CNT_G1_4, CNT_PP_FULL = 4, 5, 6, 7, 8, 9
+PP_WROWS = {0: 64, 1: 64, 2: 128, 3: 128}          # rows of one statistics slice per configuration (PPCfg::WROWS)
+
+
+def host(t):
+    return t.detach().float().cpu().contiguous().numpy()
+
+
+def _lib_and_counter():
+    from convnets_amd import _lib
+    lib = _lib.load()
+    cnt = lib.cnk_debug_counter
+    cnt.restype, cnt.argtypes = ctypes.c_int64, [ctypes.c_int]
+    return _lib, lib, cnt
+
+
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _merge_stats(part, M):
+    pt = part.double()
+    assert torch.isfinite(pt).all()
+    n, mean, m2 = pt[:, :, 0], pt[:, :, 1], pt[:, :, 2]
+    tn = n.sum(0)
+    assert torch.all(tn == M)
+    tmean = (n * mean).sum(0) / tn
+    tvar = (m2.sum(0) + (n * (mean - tmean) ** 2).sum(0)) / tn
+    return tmean, tvar
+
+
+def _nhwc(t):                       # logical NCHW (any memory format) -> [N, H, W, C] values on the CPU, fp64
+    return t.detach().permute(0, 2, 3, 1).double().cpu().contiguous()
+
+
+# (N, C, H, W): every shape passes pp_pick's fits() for the configurations it is paired with below
+PP_SHAPES = {
+    'n16_256_14': (16, 256, 14, 14),        # M = 3136 = 12 x 256 + 64: ragged last row tile for every configuration
+    'n8_128_28': (8, 128, 28, 28),          # two 64-channel chunks (four 32-channel ones), long rows
+    'n48_512_7': (48, 512, 7, 7),           # 7x7: a tile spans five images, eight chunks
+    'n16_128_9x13': (16, 128, 9, 13),       # odd, non-square image: row wraps at every 13th pixel
+}
+PP_FWD_CASES = [(0, 'n16_256_14'), (0, 'n8_128_28'), (0, 'n48_512_7'), (0, 'n16_128_9x13'),
+                (2, 'n16_256_14'), (2, 'n8_128_28'), (2, 'n48_512_7'),
+                (3, 'n16_256_14'), (3, 'n48_512_7')]
+
+
+def _operands(shape, seed):
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=g).bfloat16()
+    dy = torch.randn(N, C, H, W, generator=g).bfloat16()
+    w = torch.randn(C, C, 3, 3, generator=g) * (1.0 / math.sqrt(9 * C))
+    return x, dy, w
+
+
+@pytest.mark.parametrize('cfg,shape', PP_FWD_CASES)
+def test_pingpong_forward_per_configuration(cfg, shape):
+    """Forward with BN statistics partials (epilogue STATS) and without (PLAIN), configuration forced."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    N, C, H, W = PP_SHAPES[shape]
+    M = N * H * W
+    x, _, w = _operands(PP_SHAPES[shape], 100 + cfg)
+    xg = x.cuda().contiguous(memory_format=CL)
+    desc = ops.make_desc(xg.shape, w.shape, (1, 1), (1, 1), _lib.CNK_BF16)
+    wf, _ = ops.PackedWeights().get(w.cuda(), desc, True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = F.conv2d(x.double(), w.bfloat16().double(), padding=1)
+    with _lib.switches(CNK_PP3X3='1', CNK_PP_CFG=str(cfg)):
+        nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+        assert nsl == (M + PP_WROWS[cfg] - 1) // PP_WROWS[cfg], 'the forced configuration does not take this shape'
+        part = torch.full((nsl, C, 3), float('nan'), device='cuda')
+        y, y2 = torch.empty_like(xg), torch.empty_like(xg)
+        c0 = cnt(CNT_PP[cfg])
+        assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
+        assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(y2), None, None, 0, st) == 0, lib.cnk_last_error()
+        torch.cuda.synchronize()
+        assert cnt(CNT_PP[cfg]) - c0 == 2, 'configuration %d did not run' % cfg
+    assert torch.equal(y, y2)                                       # PLAIN and STATS epilogues write the same rows
+    assert rel_l2(host(y), ref.float().numpy()) < 4e-3
+    tmean, tvar = _merge_stats(part, M)
+    yd = y.double()
+    assert ((tmean - yd.mean((0, 2, 3))).abs().max() / yd.abs().mean()).item() < 2e-6      # statistics of the tensor it wrote
+    assert ((tvar - yd.var((0, 2, 3), unbiased=False)).abs() / tvar).max().item() < 2e-5
+    if cfg == 0:
+        # 64-channel K steps: same MFMA order as the r01 halo kernel => the same bits
+        with _lib.switches(CNK_PP3X3='0'):
+            yh = torch.empty_like(xg)
+            h0 = cnt(CNT_HALO) + cnt(CNT_HALO_PF)
+            assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(yh), None, None, 0, st) == 0, lib.cnk_last_error()
+            torch.cuda.synchronize()
+            assert cnt(CNT_HALO) + cnt(CNT_HALO_PF) - h0 == 1
+        assert torch.equal(y, yh)
+
+
+def _dgrad_reference(dy, w, addend, amask_bits, bnx, keep_bits, mean, invstd):
+    """fp64 restatement of the data-gradient epilogue (conv_pp.hip pp_epilogue FULL == conv_igemm.hip igemm_epilogue):
+    the accumulator is rounded to bf16, the (mask-gated) addend is added and the sum rounded again, the BN layer's ReLU
+    mask zeroes elements, and the per-channel sums of d' and d' * (x - mean) * invstd are taken over the result."""
+    dx = F.conv_transpose2d(dy.double(), w.bfloat16().double(), padding=1)
+    v = _nhwc(dx.float().bfloat16())                                       # [N, H, W, C]
+    if addend is not None:
+        a = addend.double().cpu()
+        if amask_bits is not None:
+            a = a * amask_bits
+        v = (v + a).float().bfloat16().double()
+    if keep_bits is not None:
+        v = v * keep_bits
+    s1 = v.sum((0, 1, 2))
+    s2 = (v * (bnx.double().cpu() - mean.double().cpu())).sum((0, 1, 2)) * invstd.double().cpu() if bnx is not None else None
+    return v, s1, s2
+
+
+def _unpack_bits(mask_bytes, shape_nhwc):
+    b = mask_bytes.cpu().numpy()
+    bits = np.unpackbits(b[:, None], axis=1, bitorder='little').reshape(shape_nhwc)     # bit e of byte k = channel 8k + e
+    return torch.from_numpy(bits.astype(np.float64))
+
+
+@pytest.mark.parametrize('shape', ['n16_256_14', 'n8_128_28', 'n48_512_7', 'n16_128_9x13'])
+@pytest.mark.parametrize('maskmode', ['bits', 'remask'])
+def test_pingpong_data_gradient_full_epilogue(shape, maskmode):
+    """Configuration 0 (the only one the data gradients use): plain data gradient, and the data gradient as the training
+    step issues it -- gradient addend gated by a packed ReLU mask + the first pass of the producing BN layer's backward
+    (mask from saved bits or re-derived from x*scale+shift) -- on the ping-pong core, against fp64 and against the halo
+    kernel (bit-identical dx, sums to fp32 summation order)."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    N, C, H, W = PP_SHAPES[shape]
+    M = N * H * W
+    x, dy, w = _operands(PP_SHAPES[shape], 7)
+    g = torch.Generator().manual_seed(19)
+    dyg = dy.cuda().contiguous(memory_format=CL)
+    desc = ops.make_desc(dyg.shape, w.shape, (1, 1), (1, 1), _lib.CNK_BF16)
+    _, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bnx = (torch.randn(N, H, W, C, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    addend = torch.randn(N, H, W, C, generator=g).bfloat16().cuda()
+    amask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).cuda()
+    kmask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).cuda()
+    bmean, binv = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    bgam, bbeta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out = {}
+    for name, env in (('pp', dict(CNK_PP3X3='1', CNK_PP_CFG='0', CNK_PP_FULL='1')), ('halo', dict(CNK_PP3X3='0'))):
+        with _lib.switches(**env):
+            nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+            assert nb == (M + (64 if name == 'pp' else 128) - 1) // (64 if name == 'pp' else 128)
+            bpart = torch.full((nb, C, 2), float('nan'), device='cuda')
+            fuse = _lib.BnBwdFuse(bnx.data_ptr(), bmean.data_ptr(), binv.data_ptr(), bgam.data_ptr(), bbeta.data_ptr(),
+                                  kmask.data_ptr() if maskmode == 'bits' else None, bpart.data_ptr(), 1)
+            dxp, dxf = torch.empty_like(dyg), torch.empty_like(dyg)
+            c0, f0 = cnt(CNT_PP[0]), cnt(CNT_PP_FULL)
+            assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dxp), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+            assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dxf), P(addend), P(amask), ctypes.byref(fuse), None, 0, st) == 0, lib.cnk_last_error()
+            torch.cuda.synchronize()
+            if name == 'pp':
+                assert cnt(CNT_PP[0]) - c0 == 2 and cnt(CNT_PP_FULL) - f0 == 1, 'the ping-pong core did not run'
+            else:
+                assert cnt(CNT_PP[0]) == c0
+            assert torch.isfinite(bpart).all()
+            out[name] = (dxp, dxf, bpart.double().sum(0))
+    # bit-identical between the two kernels
+    assert torch.equal(out['pp'][0], out['halo'][0])
+    assert torch.equal(out['pp'][1], out['halo'][1])
+    assert ((out['pp'][2] - out['halo'][2]).abs().max() / out['halo'][2].abs().max()).item() < 1e-5
+    # fp64 reference
+    shp = (N, H, W, C)
+    abits = _unpack_bits(amask, shp)
+    if maskmode == 'bits':
+        keep = _unpack_bits(kmask, shp)
+    else:
+        sc = (bgam * binv).double().cpu()
+        sf = bbeta.double().cpu() - bmean.double().cpu() * sc
+        # the kernel evaluates x*scale+shift in fp32: elements within rounding of zero may flip; compare around them
+        act = bnx.double().cpu() * sc + sf
+        keep = (act > 0).double()
+        unsure = act.abs() < 1e-5 * (bnx.double().cpu().abs() * sc.abs() + sf.abs() + 1e-30)
+        assert unsure.float().mean().item() < 1e-4
+    vplain, _, _ = _dgrad_reference(dy, w, None, None, None, None, None, None)
+    assert rel_l2(_nhwc(out['pp'][0]).float().numpy(), vplain.float().numpy()) < 4e-3
+    v, s1, s2 = _dgrad_reference(dy, w, addend, abits, bnx, keep, bmean, binv)
+    assert rel_l2(_nhwc(out['pp'][1]).float().numpy(), v.float().numpy()) < 4e-3
+    got = out['pp'][2].cpu()
+    assert ((got[:, 0] - s1).abs().max() / s1.abs().max()).item() < 5e-3
+    assert ((got[:, 1] - s2).abs().max() / s2.abs().max()).item() < 5e-3
+    # the sums must be those of the tensor the kernel wrote (fp32 sums of bf16 values: tight)
+    wrote = _nhwc(out['pp'][1])
+    assert ((got[:, 0] - wrote.sum((0, 1, 2))).abs().max() / wrote.abs().sum((0, 1, 2)).max()).item() < 1e-5
+    q = (wrote * (bnx.double().cpu() - bmean.double().cpu())).sum((0, 1, 2)) * binv.double().cpu()
+    assert ((got[:, 1] - q).abs().max() / q.abs().max()).item() < 1e-4
+
+
+# BASELINE-size layers whose dispatch lands on the 512x128 / 256x256 forward tiles and the 256x128 data gradient
+@pytest.mark.parametrize('C,H,fwd_cfgs', [(128, 28, (2,)), (256, 14, (3,)), (512, 7, (0,))])
+def test_fullsize_3x3_layers_on_their_dispatched_configuration(C, H, fwd_cfgs):
+    """bs 256, unforced: the forward must land on the ping-pong configuration the benchmark times, the plain data gradient
+    on configuration 0; y / dx against torch fp32 on the CPU from the bf16-rounded operands."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    N = 256
+    x, dy, w = _operands((N, C, H, H), 3)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    yr = F.conv2d(x.float(), w.bfloat16().float(), padding=1)
+    dxr = F.conv_transpose2d(dy.float(), w.bfloat16().float(), padding=1)
+    xg, dyg = x.cuda().contiguous(memory_format=CL), dy.cuda().contiguous(memory_format=CL)
+    desc = ops.make_desc(xg.shape, w.shape, (1, 1), (1, 1), _lib.CNK_BF16)
+    wf, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with _lib.switches(CNK_PP3X3=None, CNK_PP_CFG=None, CNK_PP_FULL=None):
+        nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+        part = torch.full((nsl, C, 3), float('nan'), device='cuda')
+        y, dx = torch.empty_like(xg), torch.empty_like(xg)
+        before = [cnt(i) for i in range(4)]
+        assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
+        mid = [cnt(i) for i in range(4)]
+        assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dx), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+        torch.cuda.synchronize()
+        after = [cnt(i) for i in range(4)]
+    ran_fwd = [i for i in range(4) if mid[i] > before[i]]
+    ran_dg = [i for i in range(4) if after[i] > mid[i]]
+    assert len(ran_fwd) == 1 and ran_fwd[0] in fwd_cfgs, 'forward ran on %s' % ran_fwd
+    assert ran_dg == [0], 'data gradient ran on %s' % ran_dg
+    assert nsl == (N * H * H + PP_WROWS[ran_fwd[0]] - 1) // PP_WROWS[ran_fwd[0]]
+    assert rel_l2(host(y), yr.numpy()) < 4e-3
+    assert rel_l2(host(dx), dxr.numpy()) < 4e-3
+    tmean, tvar = _merge_stats(part, N * H * H)
+    yd = y.double()
+    assert ((tmean - yd.mean((0, 2, 3))).abs().max() / yd.abs().mean()).item() < 2e-6
+    assert ((tvar - yd.var((0, 2, 3), unbiased=False)).abs() / tvar).max().item() < 2e-5
+
+
+def test_fullsize_alexnet_fp32_step_properties():
+    """BASELINE config 2: AlexNet 224x224, bs 128, fp32 (11x11/4 direct kernel at N = 128, 5x5 and 3x3 implicit GEMM, the
+    split-K fp32 head).  Size-independent properties of real steps: initial loss 128*ln(1000), finite gradients, moving
+    weights, the loss goes down."""
+    import convnets_amd as ca
+    torch.manual_seed(21)
+    s = ca.Settings(kind=0, input_size=(3, 224, 224), num_classes=1000, batch_size=128, mixed_precision=False, learning_rate=1e-4,
+                    dropout_rate=0)
+    model = ca.AlexNet(s).cuda()
+    model.init_optimizer()
+    model.train()
+    gen = torch.Generator(device='cuda').manual_seed(21)
+    x = torch.randn(128, 3, 224, 224, generator=gen, device='cuda')
+    y = torch.randint(0, 1000, (128,), generator=gen, device='cuda')
+    before = model.optimizer.flat_p.clone()
+    loss1, correct = model.train_batch((x, y))
+    torch.cuda.synchronize()
+    assert abs(float(loss1) - 128 * math.log(1000)) < 0.05 * 128 * math.log(1000)
+    assert 0 <= int(correct) <= 128
+    gflat = model.optimizer.flat_g
+    assert bool(torch.isfinite(gflat).all()) and float(gflat.abs().max()) > 0
+    assert float((model.optimizer.flat_p - before).abs().max()) > 5e-5
+    for _ in range(3):
+        lossn, _ = model.train_batch((x, y))
+    assert float(lossn) < float(loss1)
+    # first-layer check at full size against torch fp32 on the CPU: 11x11 / stride 4 at N = 128
+    conv1 = [m for m in model.modules() if isinstance(m, torch.nn.Conv2d)][0]
+    assert conv1.kernel_size == (11, 11) and conv1.stride == (4, 4)
+    with torch.no_grad():
+        xc = x[:128].contiguous(memory_format=CL)
+        yg = conv1(xc)
+        torch.cuda.synchronize()
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        yc = F.conv2d(x[:128].cpu(), conv1.weight.detach().cpu(), None if conv1.bias is None else conv1.bias.detach().cpu(),
+                      stride=conv1.stride, padding=conv1.padding)
+    assert rel_l2(host(yg), yc.numpy()) < 1e-5
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('kind,Cin,Cout,H', [('3x3', 128, 128, 28), ('3x3', 256, 256, 14), ('1x1', 1024, 256, 14), ('1x1', 512, 2048, 7),
+                                             ('1x1', 512, 256, 28)])
+def test_dispatch_rules_batch_sweep(kind, Cin, Cout, H):
+    """The tile choices (pp_pick, gemm1x1_pick) are rules in work per CU (tiles per CU, K steps), not batch-256 windows:
+    whatever they choose at N in {32, 64, 96, 128, 192, 256}, forward (with statistics) and data gradient equal the
+    reference kernels' results -- bit for bit for the 1x1 ring GEMM and the 64-channel-step 3x3 configuration, within
+    bf16 accumulation-order noise (<= 2e-3) for the 32-channel-step 3x3 tiles."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    k, pad = (3, 1) if kind == '3x3' else (1, 0)
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / math.sqrt(k * k * Cin))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for N in (32, 64, 96, 128, 192, 256):
+        xg = torch.randn(N, Cin, H, H, generator=g).bfloat16().cuda().contiguous(memory_format=CL)
+        dyg = torch.randn(N, Cout, H, H, generator=g).bfloat16().cuda().contiguous(memory_format=CL)
+        desc = ops.make_desc(xg.shape, w.shape, (1, 1), (pad, pad), _lib.CNK_BF16)
+        wf, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+        M = N * H * H
+        res = {}
+        for name, env in (('rule', dict(CNK_PP3X3=None, CNK_PP_CFG=None, CNK_GEMM1X1=None)), ('base', dict(CNK_PP3X3='0', CNK_GEMM1X1='0'))):
+            with _lib.switches(**env):
+                nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+                part = torch.full((nsl, Cout, 3), float('nan'), device='cuda')
+                y, dx = torch.empty_like(dyg), torch.empty_like(xg)
+                c0 = [cnt(i) for i in range(10)]
+                assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
+                c1 = [cnt(i) for i in range(10)]
+                assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dx), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+                torch.cuda.synchronize()
+                fwd_on = [i for i in range(10) if c1[i] > c0[i]]
+                res[name] = (y, dx, _merge_stats(part, M), fwd_on)
+        y, dx, (tm, tv), fwd_on = res['rule']
+        yb, dxb, (bm, bv), _ = res['base']
+        same_order = not (2 in fwd_on or 3 in fwd_on)          # the 32-channel-step 3x3 tiles accumulate in another order
+        if same_order:
+            assert torch.equal(y, yb), (N, fwd_on)
+        else:
+            assert rel_l2(host(y), host(yb)) < 2e-3, (N, fwd_on)
+        assert torch.equal(dx, dxb), N
+        assert ((tm - bm).abs().max() / yb.float().abs().mean()).item() < (1e-6 if same_order else 1e-4)
+        assert ((tv - bv).abs() / bv).max().item() < (1e-5 if same_order else 1e-3)
+
+
+@pytest.mark.parametrize('slices,C,M', [(6272, 64, 802816), (6272, 256, 802816), (1568, 512, 200704), (3136, 128, 401408), (1100, 72, 140800)])
+def test_bn_partials_merged_and_finalised_in_one_launch(slices, C, M):
+    """csrc/bn.hip bn_merge_final_kernel: long BN partial lists are merged AND finalised by one launch
+    (write-through stores, a ticket per 64-channel group, the last block finalises) instead of bn_premerge + bn_finalize /
+    bn_bwd_final.  Hand-off test as MI355X_MICROARCH.md prescribes: many launches back to back on the SAME scratch with
+    DIFFERENT data each (a stale share is the previous launch's data and shows), consumer L1-warm, a streaming kernel
+    running beside it on a second stream (uneven load), every output word checked: against an fp64 merge, bit for bit
+    between repeated launches, and against the two-launch path (CNK_BN_FUSED_FINAL=0)."""
+    _lib, lib, cnt = _lib_and_counter()
+    g = torch.Generator(device='cuda').manual_seed(slices + C)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nws = lib.cnk_bn_workspace_bytes(M, C)
+    ws = torch.empty(nws, dtype=torch.uint8, device='cuda')
+    rows = M // slices
+    assert rows * slices == M
+    NB = 6
+    parts, expect = [], []
+    for b in range(NB):
+        p = torch.empty(slices, C, 3, device='cuda')
+        p[:, :, 0] = rows
+        p[:, :, 1] = torch.randn(slices, C, generator=g, device='cuda') * (0.5 + b) + b
+        p[:, :, 2] = (torch.rand(slices, C, generator=g, device='cuda') + 0.5) * rows * (1 + b)
+        parts.append(p)
+        pd = p.double()
+        mean = pd[:, :, 1].mean(0)
+        var = (pd[:, :, 2].sum(0) + rows * ((pd[:, :, 1] - mean) ** 2).sum(0)) / M
+        expect.append((mean, var))
+    gamma, beta = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda')
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device='cuda')
+
+    def run(fused, reps):
+        outs = []
+        with _lib.switches(CNK_BN_FUSED_FINAL='1' if fused else '0'):
+            c0 = cnt(10)
+            for r in range(reps):
+                b = r % NB
+                sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+                rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+                if r % 3 == 0:
+                    with torch.cuda.stream(side):
+                        big.mul_(1.0001)                      # streaming traffic beside the merge (uneven load)
+                assert lib.cnk_bn_fwd_train(P(parts[b]), P(gamma), P(beta), None, None, None, P(rm), P(rv), P(sm), P(si), P(parts[b]), slices,
+                                            M, C, 1e-5, 0.1, 1, _lib.CNK_BF16, P(ws), nws, st) == 0, lib.cnk_last_error()
+                coef = ws.view(torch.float32)[:2 * C].clone()       # scale | shift, read in stream order
+                outs.append((b, sm, si, rm, rv, coef))
+            torch.cuda.synchronize()
+            assert (cnt(10) - c0 == reps) == fused, 'fused finalisation ran %d of %d times' % (cnt(10) - c0, reps)
+        return outs
+
+    fused = run(True, 120)
+    plain = run(False, NB)
+    first = {}
+    for b, sm, si, rm, rv, coef in fused:
+        mean, var = expect[b]
+        assert ((sm.double() - mean).abs().max() / mean.abs().max()).item() < 2e-6
+        assert ((1.0 / si.double() ** 2 - 1e-5 - var).abs() / var).max().item() < 2e-5
+        inv = si.double()
+        assert ((coef[:C].double() - gamma.double() * inv).abs().max() / (gamma.double() * inv).abs().max()).item() < 1e-6
+        assert ((coef[C:].double() - (beta.double() - sm.double() * gamma.double() * inv)).abs().max()).item() < 1e-4
+        assert ((rm.double() - 0.1 * mean).abs().max() / mean.abs().max()).item() < 2e-6
+        key = first.setdefault(b, (sm, si, rm, rv, coef))
+        for a, c in zip(key, (sm, si, rm, rv, coef)):
+            assert torch.equal(a, c), 'repeated launches differ (a stale share was read)'
+    for b, sm, si, rm, rv, coef in plain:
+        assert ((sm - first[b][0]).abs().max() / first[b][0].abs().max()).item() < 1e-6
+        assert ((si - first[b][1]).abs() / first[b][1]).max().item() < 1e-5
+    # backward: the same launch finalises dgamma / dbeta and the apply coefficients (cnk_bn_bwd with ext_partial)
+    if C % 8:
+        return
+    x = torch.randn(M, C, device='cuda', generator=g).bfloat16()
+    dy = torch.randn(M, C, device='cuda', generator=g).bfloat16()
+    sm, si = torch.randn(C, device='cuda') * 0.1, torch.rand(C, device='cuda') + 0.5
+    bparts = [torch.randn(slices, C, 2, device='cuda', generator=g) * (1 + b) for b in range(3)]
+    res = {}
+    for fused_on in (True, False):
+        with _lib.switches(CNK_BN_FUSED_FINAL='1' if fused_on else '0'):
+            c0 = cnt(10)
+            for r in range(9 if fused_on else 3):
+                b = r % 3
+                dx, dg, db = torch.empty_like(x), torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+                assert lib.cnk_bn_bwd(P(dy), P(x), None, None, P(gamma), P(beta), P(sm), P(si), P(dx), None, P(dg), P(db), 0,
+                                      P(bparts[b]), slices, M, C, 1, _lib.CNK_BF16, P(ws), nws, st) == 0, lib.cnk_last_error()
+                torch.cuda.synchronize()
+                want_b, want_g = bparts[b][:, :, 0].double().sum(0), bparts[b][:, :, 1].double().sum(0)
+                assert ((db.double() - want_b).abs().max() / want_b.abs().max()).item() < 1e-5
+                assert ((dg.double() - want_g).abs().max() / want_g.abs().max()).item() < 1e-5
+                assert bool(torch.isfinite(dx.float()).all())
+                prev = res.setdefault((fused_on, b), (dx, dg, db))
+                assert all(torch.equal(a, c) for a, c in zip(prev, (dx, dg, db)))
+            assert (cnt(10) - c0 > 0) == fused_on
+    for b in range(3):
+        assert rel_l2(host(res[(True, b)][0]), host(res[(False, b)][0])) < 1e-3          # bf16 dx from coefficients equal to ~1e-7

@@ -33,6 +33,7 @@ for Cin, Cout, H in SHAPES:
     info = {}
     for v, mode in VARS:
         os.environ['CNK_GEMM1X1'] = mode
+        _lib.reload_switches()
         nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
         yo, dxo = torch.empty_like(ys[0]), torch.empty_like(xs[0])
         assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xs[0]), P(wf), None, P(yo), P(part), None, 0, st) == 0, lib.cnk_last_error()
@@ -66,6 +67,8 @@ for Cin, Cout, H in SHAPES:
     for rnd in range(5):
         for v, mode in VARS:
             os.environ['CNK_GEMM1X1'] = mode
+            _lib.reload_switches()
+        _lib.reload_switches()
             for k, run in runs.items():
                 run(0); run(1)
                 torch.cuda.synchronize()

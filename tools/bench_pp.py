@@ -29,8 +29,13 @@ sha = lambda t: hashlib.sha1(t.detach().cpu().contiguous().view(torch.uint8).num
 def select(v):
     os.environ.pop('CNK_PP_CFG', None)
     os.environ['CNK_PP3X3'] = '0' if v == 'old' else '1'
+    os.environ.pop('CNK_PP_FULL', None)
+    if v.endswith('f'):                      # "autof" / "0f": fused data gradients forced onto the ping-pong core
+        os.environ['CNK_PP_FULL'] = '1'
+        v = v[:-1]
     if v not in ('old', 'auto'):
         os.environ['CNK_PP_CFG'] = v
+    _lib.reload_switches()                   # the library resolves its switches at load (csrc/common.h)
 
 
 tot = {v: {'fwd': 0.0, 'dgrad': 0.0, 'dgbn': 0.0} for v in VARIANTS}

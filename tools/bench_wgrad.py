@@ -34,13 +34,13 @@ for Cin, Cout, k, s, p, H in SHAPES:
     desc = ops.make_desc(xs[0].shape, (Cout, Cin, k, k), (s, s), (p, p), _lib.CNK_BF16)
     nws = 0
     for mode in (0, 1):
-        os.environ[VAR] = str(mode)
+        os.environ[VAR] = str(mode); _lib.reload_switches()
         nws = max(nws, lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), 2))
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device='cuda')
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     res, us = {}, {}
     for mode in (0, 1, 0, 1):
-        os.environ[VAR] = str(mode)
+        os.environ[VAR] = str(mode); _lib.reload_switches()
         dw = torch.zeros(Cout, Cin, k, k, device='cuda')
         run = lambda i: lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dys[i % copies]), P(xs[i % copies]), P(dw), None, 0, P(ws), nws, st)
         for i in range(2):
