@@ -273,7 +273,17 @@ struct BnFinalFwd {
     const float* gamma; const float* beta;
     float* running_mean; float* running_var; float* save_mean; float* save_invstd; float* scale; float* shift;
     float eps, momentum;
-    __device__ __forceinline__ void operator()(int c, int64_t M, float /*n*/, float ma, float qa) const {
+    struct Pre { float g, b, rm, rv; };
+    // the channel's parameters, requested together with the shares (not one dependent round trip each at the end)
+    __device__ __forceinline__ Pre pre(int c) const {
+        Pre q;
+        q.g = gamma[c]; q.b = beta[c];
+        const float* rmp = running_mean ? running_mean : gamma;      // unconditional loads (always-valid address)
+        const float* rvp = running_var ? running_var : gamma;
+        q.rm = rmp[c]; q.rv = rvp[c];
+        return q;
+    }
+    __device__ __forceinline__ void operator()(int c, int64_t M, const Pre& q, float /*n*/, float ma, float qa) const {
         float var = qa / (float)M;
         float invstd = rsqrtf(var + eps);
         invstd = invstd * (1.5f - 0.5f * (var + eps) * invstd * invstd);      // as bn_finalize_kernel
@@ -281,12 +291,12 @@ struct BnFinalFwd {
         save_invstd[c] = invstd;
         if (running_mean) {
             float unb = M > 1 ? qa / (float)(M - 1) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ma;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+            running_mean[c] = (1.f - momentum) * q.rm + momentum * ma;
+            running_var[c] = (1.f - momentum) * q.rv + momentum * unb;
         }
-        float sc = gamma[c] * invstd;
+        float sc = q.g * invstd;
         scale[c] = sc;
-        shift[c] = beta[c] - ma * sc;
+        shift[c] = q.b - ma * sc;
     }
 };
 struct BnFinalBwd {
@@ -294,10 +304,16 @@ struct BnFinalBwd {
     const float* gamma; const float* invstd;
     float* dgamma; float* dbeta; float* coefA; float* coefB1; float* coefB2;
     int accumulate;
-    __device__ __forceinline__ void operator()(int c, int64_t M, float a, float b, float) const {
-        dbeta[c] = accumulate ? dbeta[c] + a : a;
-        dgamma[c] = accumulate ? dgamma[c] + b : b;
-        coefA[c] = gamma[c] * invstd[c];
+    struct Pre { float g, is, dg, db; };
+    __device__ __forceinline__ Pre pre(int c) const {
+        Pre q;
+        q.g = gamma[c]; q.is = invstd[c]; q.dg = dgamma[c]; q.db = dbeta[c];      // dgamma / dbeta are valid buffers either way
+        return q;
+    }
+    __device__ __forceinline__ void operator()(int c, int64_t M, const Pre& q, float a, float b, float) const {
+        dbeta[c] = accumulate ? q.db + a : a;
+        dgamma[c] = accumulate ? q.dg + b : b;
+        coefA[c] = q.g * q.is;
         coefB1[c] = a / (float)M;
         coefB2[c] = b / (float)M;
     }
@@ -372,23 +388,25 @@ __global__ __launch_bounds__(256) void bn_merge_final_kernel(const float* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!is_last) return;
-    // the last block of this channel group: merge the shares in share order (wave w: shares w, w+4, ...), sc1 loads only
+    // the last block of this channel group: merge the shares in share order (wave w: shares w, w+4, ...), sc1 loads only,
+    // all of a wave's <= 16 shares requested at once (one round trip, not shares/16)
     a0 = a1 = a2 = 0.f;
+    typename FIN::Pre q = {};
+    if (wave == 0 && c < C) q = fin.pre(c);
     if (c < C) {
-        for (int s = wave; s < shares; s += 16) {
-            float v[4][NV];
+        float v[16][NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 16; ++u) {
+            const int ss = wave + 4 * u, sc = ss < shares ? ss : shares - 1;       // unconditional loads (clamped address)
 #pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    const int ss = s + 4 * u;
-                    v[u][k] = ss < shares ? __hip_atomic_load(out + ((size_t)ss * C + c) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                }
+            for (int k = 0; k < NV; ++k)
+                v[u][k] = __hip_atomic_load(out + ((size_t)sc * C + c) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if constexpr (NV == 3) chan_merge(a0, a1, a2, v[u][0], v[u][1], v[u][2]);
-                else { a0 += v[u][0]; a1 += v[u][1]; }
-            }
+        for (int u = 0; u < 16; ++u) {
+            const bool on = wave + 4 * u < shares;
+            if constexpr (NV == 3) chan_merge(a0, a1, a2, on ? v[u][0] : 0.f, v[u][1], v[u][2]);      // n == 0: no-op
+            else { a0 += on ? v[u][0] : 0.f; a1 += on ? v[u][1] : 0.f; }
         }
     }
     sh[0][wave][lane] = a0;
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(256) void bn_merge_final_kernel(const float* __rest
         a0 = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
         a1 = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
     }
-    fin(c, M, a0, a1, a2);
+    fin(c, M, q, a0, a1, a2);
 }
 
 __global__ void bn_eval_coef_kernel(const float* gamma, const float* beta, const float* rmean,
@@ -494,6 +512,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
             xv[u].load(x + off + u * rstep);
             if constexpr (HAS_RES) rv[u].load(res + off + u * rstep);
         }
+        // keep the ROWS_U rows' loads together IN FRONT of the arithmetic: hipcc's occupancy-driven scheduler otherwise sinks
+        // each load to its use to save registers (67-76 VGPRs, one or two loads in flight per lane; round 3, from the .s)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < ROWS_U; ++u)
             bn_apply_row<T, VEC, HAS_RES, RELU, WMASK>(xv[u], rv[u], sc, sh, y + off + u * rstep,
@@ -751,6 +772,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             if constexpr (ACT == ACT_BITS) aux[u] = mask[(m + (int64_t)u * g.rpb) * g.cols + vcol];
             if constexpr (ACT == ACT_Y) yv[u].load(y + off + u * rstep);
         }
+        __builtin_amdgcn_sched_barrier(0);          // loads of all ROWS_U rows stay in front of the arithmetic (see bn_apply_kernel)
 #pragma unroll
         for (int u = 0; u < ROWS_U; ++u)
             bn_bwd_row<T, VEC, ACT, WRES>(dv[u], xv[u], yv[u], aux[u], ka, kb1, kmu, kis, ksf,
@@ -1026,7 +1048,7 @@ template <class FIN>
 static int bn_merge_final(const float* partial, int slices, int C, int64_t M, float* scratch, int64_t scratch_floats,
                           const FIN& fin, hipStream_t s) {
     if (!cnk_sw().bn_fused_final || slices < 1024 || ceil_div(C, 64) > BNF_GROUPS) return 0;
-    const int shares = slices >= 2048 ? 64 : 32;          // ~sqrt(slices): merge depth == finalisation depth
+    const int shares = slices >= 2048 ? 64 : 32;          // ~sqrt(slices); <= 64: bn_merge_final_kernel reads 16 shares per wave
     if ((int64_t)shares * C * FIN::NV > scratch_floats) return 0;
     const int slot = (int)(g_bnf_slot.fetch_add(1, std::memory_order_relaxed) % BNF_SLOTS);
     hipLaunchKernelGGL((bn_merge_final_kernel<FIN>), dim3(ceil_div(C, 64), shares), dim3(256), 0, s, partial, slices, C, M,

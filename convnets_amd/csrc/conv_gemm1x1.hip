@@ -203,15 +203,24 @@ __global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_ke
     // fused BN backward: coefficients of this lane's 8 channels
     const bool bnf = FULL && p.bnf_x != nullptr;
     const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
-    float bmu[8], bsc[8], bsf[8];
+    float bmu[8], bsc[8], bsf[8], is_fin = 0.f;
     if constexpr (FULL) {
         if (bnf) {
+            if (tid < BN) is_fin = p.bnf_invstd[n0 + tid];           // for the partial store at the end (not behind the row stores)
             const int c0 = n0 + wn * (32 * NJ) + chunk * 8;
+            // unconditional, back-to-back loads (absent gamma / beta read the mean array): per-element "load or zero" selects
+            // made hipcc branch around each load and wait for it alone (see igemm_epilogue)
+            const float* gp = bnf_remask ? p.bnf_gamma : p.bnf_mean;
+            const float* bp = bnf_remask ? p.bnf_beta : p.bnf_mean;
+            float mu[8], gm[8], is[8], bt[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mu[e] = p.bnf_mean[c0 + e]; gm[e] = gp[c0 + e]; is[e] = p.bnf_invstd[c0 + e]; bt[e] = bp[c0 + e]; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                bmu[e] = p.bnf_mean[c0 + e];
-                bsc[e] = bnf_remask ? p.bnf_gamma[c0 + e] * p.bnf_invstd[c0 + e] : 0.f;
-                bsf[e] = bnf_remask ? p.bnf_beta[c0 + e] - bmu[e] * bsc[e] : 0.f;
+                const float sc = gm[e] * is[e];
+                bmu[e] = mu[e];
+                bsc[e] = bnf_remask ? sc : 0.f;
+                bsf[e] = bnf_remask ? bt[e] - mu[e] * sc : 0.f;
             }
         }
     }
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_ke
                 const int c = n0 + tid;
                 float* o = p.bnf_partial + ((size_t)(p.bnf_tile0 + tile_m) * p.Nout + c) * 2;
                 o[0] = S;
-                o[1] = Q * p.bnf_invstd[c];
+                o[1] = Q * is_fin;
             } else {
                 const int nvalid = min(G1_BM, p.M - m0);
                 const float mean = S / (float)nvalid;

@@ -27,6 +27,9 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int MAX_TAPS = 32;
+// LDS header of the implicit-GEMM kernels: row_dst[BM], then the (dh, dw) tap table of the gather kernel -- p.dh[t] with a
+// run-time t is a VECTOR load from the kernarg segment whose wait (vmcnt, in order) sat in front of every K step's DMAs
+constexpr int IG_HDR = (BM + MAX_TAPS) * (int)sizeof(int);
 
 struct GatherParams {
     const void* src;
@@ -105,7 +108,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     constexpr int RPP = 256 / CPR;                   // rows per pass
     constexpr int NP = BM / RPP;                     // passes
     constexpr int GP = NP > 4 ? 4 : NP;              // passes whose side loads are in flight together
-    unsigned char* Cs = smem + BM * sizeof(int);
+    unsigned char* Cs = smem + IG_HDR;
     unsigned char* dst = (unsigned char*)p.dst;
     const int crow = tid / CPR, cc = tid - crow * CPR;
     const int ncols = EDGE ? p.Nout - tile_n * BN : BN;          // valid columns of this n-tile
@@ -142,16 +145,26 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 }
             }
     // fused BN backward (dgrad only): per-thread coefficients of this thread's PER16 channels
-    float bmu[PER16], bsc[PER16], bsf[PER16];
+    float bmu[PER16], bsc[PER16], bsf[PER16], is_fin = 0.f;
     const bool bnf = p.bnf_x != nullptr;
     const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
+    if (bnf && tid < BN && (!EDGE || tid < ncols)) is_fin = p.bnf_invstd[tile_n * BN + tid];      // for the partial store at the end
     if (bnf && colok) {
+        // all four coefficient vectors requested back to back and unconditionally (an absent gamma / beta reads the mean
+        // array instead): a per-element "load or zero" select made hipcc branch around every load and wait vmcnt(0) after
+        // each -- 8 dependent L2 round trips per tile (cdna_hip_programming.md 5, trap (c))
         const int c0 = tile_n * BN + cc * PER16;
+        const float* gp = bnf_remask ? p.bnf_gamma : p.bnf_mean;
+        const float* bp = bnf_remask ? p.bnf_beta : p.bnf_mean;
+        float mu[PER16], gm[PER16], is[PER16], bt[PER16];
+#pragma unroll
+        for (int e = 0; e < PER16; ++e) { mu[e] = p.bnf_mean[c0 + e]; gm[e] = gp[c0 + e]; is[e] = p.bnf_invstd[c0 + e]; bt[e] = bp[c0 + e]; }
 #pragma unroll
         for (int e = 0; e < PER16; ++e) {
-            bmu[e] = p.bnf_mean[c0 + e];
-            bsc[e] = bnf_remask ? p.bnf_gamma[c0 + e] * p.bnf_invstd[c0 + e] : 0.f;
-            bsf[e] = bnf_remask ? p.bnf_beta[c0 + e] - bmu[e] * bsc[e] : 0.f;
+            const float sc = gm[e] * is[e];
+            bmu[e] = mu[e];
+            bsc[e] = bnf_remask ? sc : 0.f;
+            bsf[e] = bnf_remask ? bt[e] - mu[e] * sc : 0.f;
         }
     }
     if (!p.addend && !bnf) {
@@ -276,7 +289,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 const int c = tile_n * BN + tid;
                 float* o = p.bnf_partial + ((size_t)(p.bnf_tile0 + tile_m) * p.Nout + c) * 2;
                 o[0] = S;
-                o[1] = Q * p.bnf_invstd[c];
+                o[1] = Q * is_fin;
             } else {
                 const int nvalid = min(BM, p.M - tile_m * BM);
                 const float mean = S / (float)nvalid;
@@ -300,7 +313,8 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     constexpr int B_LOADS = BN / 32;                 // 16-B chunks per thread for the B tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* row_dst = (int*)smem;                       // [128] dst pixel per tile row (-1: none)
-    unsigned char* As = smem + BM * sizeof(int);     // [128][128 B]
+    int* tap_tab = row_dst + BM;                     // [MAX_TAPS] (dh << 16) | (dw & 0xffff)
+    unsigned char* As = smem + IG_HDR;               // [128][128 B]
     unsigned char* Bs = As + BM * 128;               // [BN][128 B]
 
     // XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
@@ -344,6 +358,10 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
             v = (img * p.FH + oh * p.dm_h + p.d_h0) * p.FW + ow * p.dm_w + p.d_w0;
         }
         row_dst[tid] = v;
+    }
+    if (tid >= BM && tid < BM + MAX_TAPS) {
+        const int t = tid - BM;
+        tap_tab[t] = t < p.ntaps ? (((int)p.dh[t]) << 16) | (((int)p.dw[t]) & 0xffff) : 0;
     }
 
     const T* src = (const T*)p.src;
@@ -397,7 +415,8 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     auto issue = [&]() {
         const int t = ld_t, cb = (cs0 + ld_cs) * KSTEP;
         if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
-        const int dh = p.dh[t], dw = p.dw[t];
+        const int tp = tap_tab[t];                   // LDS (uniform address: broadcast), lgkmcnt only
+        const int dh = tp >> 16, dw = (int)(short)(tp & 0xffff);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = lrow + 32 * i;
@@ -417,6 +436,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
         }
     };
+    __syncthreads();                                 // tap table (and row_dst) written
     for (int ks = 0; ks < nk; ++ks) {
 #if !(CNK_ABLATE & 2)
         issue();
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(256, 3) void igemm_halo3x3_kernel(const GatherParam
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* row_dst = (int*)smem;
     const int W = p.IW, NP = BM + 2 * W + 2, NPG = (NP + 7) >> 3;
-    unsigned char* Ps = smem + BM * sizeof(int);         // [NPG*8][128 B] pixel patch
+    unsigned char* Ps = smem + IG_HDR;                   // [NPG*8][128 B] pixel patch
     unsigned char* Bs = Ps + NPG * 8 * 128;              // [BN][128 B]
     int bid = blockIdx.x;
     {
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo3x3_pf_kernel(const GatherPa
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* row_dst = (int*)smem;
     const int W = p.IW, NP = BM + 2 * W + 2, NPG = (NP + 7) >> 3;
-    unsigned char* Ps = smem + BM * sizeof(int);         // [NPG*8][128 B]
+    unsigned char* Ps = smem + IG_HDR;                   // [NPG*8][128 B]
     unsigned char* Bs = Ps + NPG * 8 * 128;              // [3][BN][128 B]
     int bid = blockIdx.x;
     {
@@ -739,7 +759,7 @@ template <typename T, int BN, bool EDGE = false> int launch_gather(const GatherP
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
     size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);     // aliases the staged tile
     if (red > epi) epi = red;
-    size_t lds = BM * sizeof(int) + (pipe > epi ? pipe : epi);
+    size_t lds = IG_HDR + (pipe > epi ? pipe : epi);
     ProfScope kscope(CNK_KF_GATHER, s, gather_flops(p), gather_bytes(p, sizeof(T)));
     cnk_count(CNK_CNT_GATHER);
     hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE>), dim3(p.tiles_total), dim3(256), lds, s, p);
@@ -772,7 +792,7 @@ template <typename T, int BN> size_t halo_lds(const GatherParams& p) {
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
     size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);
     if (red > epi) epi = red;
-    return BM * sizeof(int) + (pipe > epi ? pipe : epi);
+    return IG_HDR + (pipe > epi ? pipe : epi);
 }
 
 // 3x3 taps within +-1, stride 1, output grid == source grid ("same" conv or its data gradient)

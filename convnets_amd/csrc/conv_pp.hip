@@ -333,21 +333,32 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
     for (int j = 0; j < NJ; ++j) {
         const int cb = C0 + j * 32;                                  // first channel of this column block
         __builtin_amdgcn_sched_barrier(0);                           // keep the column blocks apart (register pressure)
-        float s8[8], q8[8], bmu[8], bsc[8], bsf[8];
+        float s8[8], q8[8], bmu[8], bsc[8], bsf[8], is_fin = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s8[e] = q8[e] = bmu[e] = bsc[e] = bsf[e] = 0.f;
         if (MODE == PP_EPI_FULL) {
             if (bnf) {
+                // unconditional, back-to-back loads (absent gamma / beta read the mean array): per-element "load or zero"
+                // selects made hipcc branch around each load and wait for it alone (see igemm_epilogue)
+                const float* gp = bnf_remask ? p.bnf_gamma : p.bnf_mean;
+                const float* bp = bnf_remask ? p.bnf_beta : p.bnf_mean;
+                const int ch0 = cb + cc * 8;
+                float mu[8], gm[8], is[8], bt[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { mu[e] = p.bnf_mean[ch0 + e]; gm[e] = gp[ch0 + e]; is[e] = p.bnf_invstd[ch0 + e]; bt[e] = bp[ch0 + e]; }
+                // invstd of the channel this lane finalises below: fetched HERE -- a load in front of the partial store would
+                // be waited for with vmcnt(0), i.e. behind every row store of the column block (the counter retires in order)
+                is_fin = p.bnf_invstd[cb + (lane & 31)];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int ch = cb + cc * 8 + e;
-                    bmu[e] = p.bnf_mean[ch];
-                    bsc[e] = bnf_remask ? p.bnf_gamma[ch] * p.bnf_invstd[ch] : 0.f;
-                    bsf[e] = bnf_remask ? p.bnf_beta[ch] - bmu[e] * bsc[e] : 0.f;
+                    const float sc = gm[e] * is[e];
+                    bmu[e] = mu[e];
+                    bsc[e] = bnf_remask ? sc : 0.f;
+                    bsf[e] = bnf_remask ? bt[e] - mu[e] * sc : 0.f;
                 }
             }
             // the coefficient loads above are hipcc's own (waited for by hipcc, ahead of every asm operation below)
-            asm volatile("" : "+v"(bmu[0]), "+v"(bsc[0]), "+v"(bsf[0]));
+            asm volatile("" : "+v"(bmu[0]), "+v"(bsc[0]), "+v"(bsf[0]), "+v"(is_fin));
         }
 #pragma unroll
         for (int ib = 0; ib < MI / 2; ++ib) {
@@ -474,7 +485,7 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
             const int slice = st.tile_m * CFG::GM + st.wm;
             if (lane < 32 && nvalid > 0) {
                 if (bnf) {
-                    pp_store8(p.bnf_partial + ((size_t)(p.bnf_tile0 + slice) * p.Nout + ch) * 2, S, Q * p.bnf_invstd[ch]);
+                    pp_store8(p.bnf_partial + ((size_t)(p.bnf_tile0 + slice) * p.Nout + ch) * 2, S, Q * is_fin);
                 } else {
                     const float mean = S / (float)nvalid;
                     float m2 = Q - S * mean;

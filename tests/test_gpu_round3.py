@@ -121,11 +121,11 @@ def test_pingpong_forward_per_configuration(cfg, shape):
         assert torch.equal(y, yh)
 
 
-def _dgrad_reference(dy, w, addend, amask_bits, bnx, keep_bits, mean, invstd):
+def _dgrad_reference(dy, w, addend, amask_bits, bnx, keep_bits, mean, invstd, padding=1):
     """fp64 restatement of the data-gradient epilogue (conv_pp.hip pp_epilogue FULL == conv_igemm.hip igemm_epilogue):
     the accumulator is rounded to bf16, the (mask-gated) addend is added and the sum rounded again, the BN layer's ReLU
     mask zeroes elements, and the per-channel sums of d' and d' * (x - mean) * invstd are taken over the result."""
-    dx = F.conv_transpose2d(dy.double(), w.bfloat16().double(), padding=1)
+    dx = F.conv_transpose2d(dy.double(), w.bfloat16().double(), padding=padding)
     v = _nhwc(dx.float().bfloat16())                                       # [N, H, W, C]
     if addend is not None:
         a = addend.double().cpu()
@@ -435,3 +435,49 @@ def test_bn_partials_merged_and_finalised_in_one_launch(slices, C, M):
             assert (cnt(10) - c0 > 0) == fused_on
     for b in range(3):
         assert rel_l2(host(res[(True, b)][0]), host(res[(False, b)][0])) < 1e-3          # bf16 dx from coefficients equal to ~1e-7
+
+
+@pytest.mark.parametrize('style,N,Cin,Cout,H', [('c1', 8, 256, 64, 14), ('c1', 5, 512, 128, 9), ('c3', 8, 64, 256, 14), ('c3', 3, 128, 256, 11),
+                                                ('c1', 2, 256, 256, 7)])
+def test_1x1_data_gradients_with_their_training_step_epilogues(style, N, Cin, Cout, H):
+    """The 1x1 data gradients exactly as the bottleneck blocks issue them, at op level against fp64 (round 3: the epilogue's
+    coefficient loads were restructured).  c1: conv1 of a bottleneck (src/resnet.py:170): gradient addend + packed mask +
+    fused BN backward with saved mask bits; c3: conv3 (:172): fused BN backward, mask re-derived."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    g = torch.Generator().manual_seed(Cin + H)
+    M = N * H * H
+    dy = torch.randn(N, Cout, H, H, generator=g).bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (1.0 / math.sqrt(Cout))
+    dyg = dy.cuda().contiguous(memory_format=CL)
+    desc = ops.make_desc((N, Cin, H, H), w.shape, (1, 1), (0, 0), _lib.CNK_BF16)
+    _, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bnx = (torch.randn(N, H, H, Cin, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    addend = torch.randn(N, H, H, Cin, generator=g).bfloat16().cuda() if style == 'c1' else None
+    amask = torch.randint(0, 256, (M * Cin // 8,), generator=g, dtype=torch.uint8).cuda() if style == 'c1' else None
+    kmask = torch.randint(0, 256, (M * Cin // 8,), generator=g, dtype=torch.uint8).cuda() if style == 'c1' else None
+    bmean, binv = (torch.randn(Cin, generator=g) * 0.1).cuda(), (torch.rand(Cin, generator=g) + 0.5).cuda()
+    bgam, bbeta = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+    nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+    assert nb > 0
+    bpart = torch.full((nb, Cin, 2), float('nan'), device='cuda')
+    fuse = _lib.BnBwdFuse(bnx.data_ptr(), bmean.data_ptr(), binv.data_ptr(), bgam.data_ptr(), bbeta.data_ptr(),
+                          kmask.data_ptr() if kmask is not None else None, bpart.data_ptr(), 1)
+    dx = torch.empty(N, Cin, H, H, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=CL)
+    assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dx), P(addend), P(amask), ctypes.byref(fuse), None, 0, st) == 0, lib.cnk_last_error()
+    torch.cuda.synchronize()
+    assert torch.isfinite(bpart).all()
+    shp = (N, H, H, Cin)
+    if style == 'c1':
+        abits, keep = _unpack_bits(amask, shp), _unpack_bits(kmask, shp)
+    else:
+        abits = None
+        sc = (bgam * binv).double().cpu()
+        keep = ((bnx.double().cpu() * sc + (bbeta.double().cpu() - bmean.double().cpu() * sc)) > 0).double()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    v, s1, s2 = _dgrad_reference(dy, w, addend, abits, bnx, keep, bmean, binv, padding=0)
+    assert rel_l2(_nhwc(dx).float().numpy(), v.float().numpy()) < 4e-3
+    got = bpart.double().sum(0).cpu()
+    assert ((got[:, 0] - s1).abs().max() / s1.abs().max()).item() < 5e-3
+    assert ((got[:, 1] - s2).abs().max() / s2.abs().max()).item() < 5e-3
