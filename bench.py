@@ -99,15 +99,15 @@ def cpu_baseline(model_key, dtype_note):
     threads = granted                                    # all host cores this process is granted
     torch.set_num_threads(threads)
     print('bench: CPU baseline on %d threads (nproc %d, cgroup cpu share %s) ...' % (threads, nproc, quota), file=sys.stderr, flush=True)
-    bs = 16
+    bs = 64                                              # bs 256 if it fits, else bs 64 (throughput is flat in batch on CPU)
     torch.manual_seed(21)
     m = tr.MODELS[family](tr.RefSettings(kind, in_size, classes, batch_size=bs, dropout_rate=0.5))
     m.init_optimizer()
     x, y = tr.synthetic_batch(bs, in_size, classes, seed=21)
     tr.ref_training_step(m, x, y)                      # warm-up
     times = []
-    t_end = time.perf_counter() + 25.0
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 6):
+    t_end = time.perf_counter() + 20.0
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 5):
         t0 = time.perf_counter()
         tr.ref_training_step(m, x, y)
         times.append(time.perf_counter() - t0)
@@ -209,7 +209,7 @@ def main():
     graphed = None
     if args.graph == 'on' or (args.graph == 'auto' and not distributed):
         try:
-            graphed = ca.GraphedTrainStep(model, batch)
+            graphed = ca.GraphedTrainStep(model, batch, wgrad_share='auto')
         except Exception as e:                      # capture refused: time the eager step (every rank must agree)
             print('bench: hipGraph capture failed (%s: %s); timing the eager step' % (type(e).__name__, e), file=sys.stderr)
         if distributed:
@@ -217,6 +217,10 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 graphed = None
+    share_ms = graphed.wgrad_share_ms if graphed is not None else None
+    if graphed is None and args.dtype == 'bf16':
+        # eager step (data parallel runs): the same measurement on eager steps, every rank alike
+        share_ms = model.calibrate_wgrad_share(batch) or None
     if graphed is not None:
         # one captured hipGraph launch per step; per-kernel events cannot be read inside a replay, so the
         # dominant kernel's launch durations are measured on eager steps AFTER the timed region
@@ -274,6 +278,17 @@ def main():
                               'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': round((tf_k / peak_tf) if mf else (gb_k / PEAK_HBM_GBPS), 4),
                               'launches_per_step': n_k, 'avg_launch_us': round(ms_k / n_k * 1e3, 2), 'step_ms': round(ms_k, 3),
                               'duration_source': 'HIP events on the launch stream around every launch (cnk_prof_*), serial eager step'})
+        # the same family in the committed rocprofv3 passes (tools/run_profiles.sh -> profiles/pmc_traffic.json): its average
+        # launch duration there (all launches of a profiled run, mostly inside graph replays) next to the live HIP-event one
+        traffic = pmc_traffic(dom_kernel)
+        rocprof_cross = None
+        if traffic and traffic.get('avg_launch_us') and n_l:
+            alg = by_l / n_l if bound == 'hbm' else fl_l / n_l
+            ach = alg / (traffic['avg_launch_us'] * 1e-6) / (1e9 if bound == 'hbm' else 1e12)
+            rocprof_cross = {'avg_launch_us': traffic['avg_launch_us'], 'achieved': round(ach, 2), 'frac': round(ach / peak, 4),
+                             'traffic_over_algorithmic': round(traffic['total'] / (by_l / n_l), 3) if by_l else None,
+                             'note': 'algorithmic bytes (or flops) per launch of THIS run / the family\'s average launch duration in the '
+                                     'committed rocprofv3 --kernel-trace --stats summary; same launch population as `traffic`'}
         conv_classes = {c: {'tflops': round(table[c][2] / table[c][1] / 1e9, 1), 'frac_of_mfma_peak': round(table[c][2] / table[c][1] / 1e9 / peak_tf, 4),
                             'calls_per_step': table[c][0], 'step_ms': round(table[c][1], 3)} for c in CONV_CLASSES if table[c][1] > 0}
         out = {
@@ -288,11 +303,13 @@ def main():
                        'final_loss': round(loss_val, 4)},
             'roofline': {'bound': bound, 'kernel': dom_kernel, 'kernel_runs': KERNEL_NOTE[dom_kernel], 'achieved': round(achieved, 2), 'peak': peak,
                          'unit': unit, 'frac': round(achieved / peak, 4),
-                         'traffic': pmc_traffic(dom_kernel),
+                         'traffic': traffic, 'rocprof': rocprof_cross,
                          'launches': n_l, 'avg_launch_ms': round(ms_l / n_l, 4) if n_l else None,
                          'avg_launch_gflop': round(fl_l / n_l / 1e9, 3) if n_l else None,
                          'avg_launch_alg_mbytes': round(by_l / n_l / 1e6, 2) if n_l else None,
                          'two_stream_backward': bool(_ops.WGRAD_STREAM and args.dtype == 'bf16'),
+                         'wgrad_share': {'chosen': _ops.WGRAD_SHARE[0], 'ms_per_step_by_share': share_ms and {str(k): round(v, 3) for k, v in share_ms.items()},
+                                         'note': 'split-K depth of the side-stream weight gradients, measured at start-up (ops.WGRAD_SHARE)'},
                          'hipgraph_step': graphed is not None,
                          'launch_durations_from': 'eager steps after the timed region' if graphed is not None else 'the timed region',
                          'serial_step_ms_by_kernel': {k: round(ktable[k][1], 3) for k in ktable},

@@ -141,6 +141,40 @@ class MultiClassBaseModel(nn.Module):
         self.flush_bn_counters()
         return loss.detach(), score
 
+    def calibrate_wgrad_share(self, batch, candidates=(1.0, 0.75, 0.5), steps=3):
+        """Measures ops.WGRAD_SHARE for the EAGER step of this model (see convnets_amd/ops.py; GraphedTrainStep does the same
+        for the captured step): a few steps per candidate on a snapshot of the training state, the fastest stays.  Under
+        data parallelism every rank must call it (the steps issue the gradient all-reduces).  Returns {share: ms}."""
+        import time
+        from . import ops
+        from .graph import GraphedTrainStep
+        if self.optimizer is None:
+            self.init_optimizer()
+        if not (ops.WGRAD_STREAM and self.setting.mixed_precision):
+            return {}
+        probe = GraphedTrainStep.__new__(GraphedTrainStep)          # borrow its snapshot / restore of the training state
+        probe.model = self
+        probe._bn_layers = [m for m in self.modules() if hasattr(m, '_stats_epoch')]
+        self.train()
+        snap = probe._snapshot()
+        batch = self.setting.device.move(batch)
+        timings = {}
+        for share in candidates:
+            ops.WGRAD_SHARE[0] = share
+            self.train_batch(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.train_batch(batch)
+            torch.cuda.synchronize()
+            timings[share] = (time.perf_counter() - t0) / steps * 1e3
+            probe._restore(snap)
+        best = min(timings, key=timings.get)
+        if 1.0 in timings and timings[best] > 0.995 * timings[1.0]:
+            best = 1.0
+        ops.WGRAD_SHARE[0] = best
+        return timings
+
     @torch.enable_grad()
     def train_model(self, dataloader):
         """basemodel.py:231-302 with the two per-step host syncs (:121, :287) replaced by

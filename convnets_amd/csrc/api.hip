@@ -115,6 +115,8 @@ static CnkSwitches read_switches() {
     w.rowpatch_stats = env("CNK_ROWPATCH_STATS", 1);
     w.wgrad_big = env("CNK_WGRAD_BIG", 1);
     w.wgrad3 = env("CNK_WGRAD3", 1);
+    w.wgrad_slots_pct = env("CNK_WGRAD_SLOTS_PCT", -1);
+    w.wgrad3_slots_pct = env("CNK_WGRAD3_SLOTS_PCT", -1);
     w.bn_pool_elementwise = getenv("CNK_BN_POOL_ELEMENTWISE") ? 1 : 0;
     w.bn_fused_final = env("CNK_BN_FUSED_FINAL", 1);
     return w;
@@ -408,19 +410,28 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
 int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_wgrad")) return rc;
     CNK_CHECK_ARG(dy && x && dw, "cnk_conv2d_wgrad: null pointer");
-    size_t need = cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD);
-    CNK_CHECK_ARG(workspace && workspace_bytes >= need, "cnk_conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    const size_t need = cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD);
+    const size_t bias_ws = dbias ? colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout) : 0;
+    const bool splitk = wgrad3x3_supported(d) || wgrad_mfma_supported(d);
+    // Split-K kernels take ANY workspace of at least one fp32 slab (+ the bias sum's scratch): less than
+    // cnk_conv2d_workspace_bytes() bounds the number of pixel-range splits (include/cnk.h; why a caller would:
+    // conv_wgrad.hip, wgrad_cap_splits)
+    const size_t slab = (size_t)d->Cout * (conv_groups(d) > 1 ? 64 : d->Cin) * d->kh * d->kw * sizeof(float);
+    const size_t least = splitk ? ((slab + 255) & ~(size_t)255) + bias_ws : need;
+    CNK_CHECK_ARG(workspace && workspace_bytes >= least, "cnk_conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, least);
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 2), S(stream), fl, by);
     int rc;
     size_t a;
-    if (wgrad3x3_supported(d)) {
-        a = wgrad3x3_workspace(d);
-        rc = wgrad3x3(d, dy, x, dw, accumulate, workspace, a, S(stream));
-    } else if (wgrad_mfma_supported(d)) {
-        a = wgrad_mfma_workspace(d);
-        rc = wgrad_mfma(d, dy, x, dw, accumulate, workspace, a, S(stream));
+    if (splitk) {
+        const bool w3 = wgrad3x3_supported(d);
+        const size_t planned = w3 ? wgrad3x3_workspace(d) : wgrad_mfma_workspace(d);
+        size_t avail = (workspace_bytes - bias_ws) & ~(size_t)255;
+        a = avail < planned ? avail : planned;
+        rc = w3 ? wgrad3x3(d, dy, x, dw, accumulate, workspace, a, S(stream)) : wgrad_mfma(d, dy, x, dw, accumulate, workspace, a, S(stream));
     } else if (rowpatch_supported(d)) {
         a = rowpatch_wgrad_workspace(d);
         rc = rowpatch_wgrad(d, dy, x, dw, accumulate, workspace, a, S(stream));
@@ -433,8 +444,6 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
     }
     if (rc) return rc;
     if (dbias) {
-        int Ho, Wo;
-        cnk_conv2d_out_hw(d, &Ho, &Wo);
         a = (a + 255) & ~(size_t)255;
         return colsum(dy, dbias, (int64_t)d->N * Ho * Wo, d->Cout, d->dtype, accumulate, (char*)workspace + a, workspace_bytes - a, S(stream));
     }

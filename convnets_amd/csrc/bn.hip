@@ -212,6 +212,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     float* save_invstd, float* scale, float* shift, float eps, float momentum) {
     __shared__ float sh[3][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
+    // the channel's parameters, requested by the finalising thread together with its partials: fetched at the end they
+    // were four dependent round trips (gamma, beta, running_mean, running_var) of a ~6 us latency-bound launch
+    float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
+    if (tid == 0) {
+        pg = gamma[c]; pb = beta[c];
+        prm = (running_mean ? running_mean : gamma)[c];
+        prv = (running_var ? running_var : gamma)[c];
+    }
     float na = 0.f, ma = 0.f, qa = 0.f;
     int s = tid;
     for (; s + 768 < slices; s += 1024) {       // four independent loads in flight per thread
@@ -247,12 +255,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     save_invstd[c] = invstd;
     if (running_mean) {
         float unb = M > 1 ? qa / (float)(M - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ma;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        running_mean[c] = (1.f - momentum) * prm + momentum * ma;
+        running_var[c] = (1.f - momentum) * prv + momentum * unb;
     }
-    float sc = gamma[c] * invstd;
+    float sc = pg * invstd;
     scale[c] = sc;
-    shift[c] = beta[c] - ma * sc;
+    shift[c] = pb - ma * sc;
 }
 
 // ---- merge + finalisation of a long partial list in ONE launch (round 3) -----------------------------------------------
@@ -389,21 +397,21 @@ __global__ __launch_bounds__(256) void bn_merge_final_kernel(const float* __rest
     __syncthreads();
     if (!is_last) return;
     // the last block of this channel group: merge the shares in share order (wave w: shares w, w+4, ...), sc1 loads only,
-    // all of a wave's <= 16 shares requested at once (one round trip, not shares/16)
+    // all of a wave's <= 32 shares requested at once (one round trip)
     a0 = a1 = a2 = 0.f;
     typename FIN::Pre q = {};
     if (wave == 0 && c < C) q = fin.pre(c);
     if (c < C) {
-        float v[16][NV];
+        float v[32][NV];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 32; ++u) {
             const int ss = wave + 4 * u, sc = ss < shares ? ss : shares - 1;       // unconditional loads (clamped address)
 #pragma unroll
             for (int k = 0; k < NV; ++k)
                 v[u][k] = __hip_atomic_load(out + ((size_t)sc * C + c) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 32; ++u) {
             const bool on = wave + 4 * u < shares;
             if constexpr (NV == 3) chan_merge(a0, a1, a2, on ? v[u][0] : 0.f, v[u][1], v[u][2]);      // n == 0: no-op
             else { a0 += on ? v[u][0] : 0.f; a1 += on ? v[u][1] : 0.f; }
@@ -683,6 +691,8 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(
     // one 256-thread block per channel, fixed summation order (deterministic)
     __shared__ float sh[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.x;
+    float pg = 0.f, pis = 0.f, pdb = 0.f, pdg = 0.f;          // prefetched by the finalising thread (see bn_finalize_kernel)
+    if (tid == 0) { pg = gamma[c]; pis = invstd[c]; pdb = dbeta[c]; pdg = dgamma[c]; }
     float a = 0.f, b = 0.f;
     int s = tid;
     for (; s + 768 < slices; s += 1024) {
@@ -706,9 +716,9 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(
     if (tid != 0) return;
     a = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
     b = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-    dbeta[c] = accumulate ? dbeta[c] + a : a;
-    dgamma[c] = accumulate ? dgamma[c] + b : b;
-    coefA[c] = gamma[c] * invstd[c];
+    dbeta[c] = accumulate ? pdb + a : a;
+    dgamma[c] = accumulate ? pdg + b : b;
+    coefA[c] = pg * pis;
     coefB1[c] = a / (float)M;
     coefB2[c] = b / (float)M;
 }
@@ -1048,7 +1058,7 @@ template <class FIN>
 static int bn_merge_final(const float* partial, int slices, int C, int64_t M, float* scratch, int64_t scratch_floats,
                           const FIN& fin, hipStream_t s) {
     if (!cnk_sw().bn_fused_final || slices < 1024 || ceil_div(C, 64) > BNF_GROUPS) return 0;
-    const int shares = slices >= 2048 ? 64 : 32;          // ~sqrt(slices); <= 64: bn_merge_final_kernel reads 16 shares per wave
+    const int shares = slices >= 2048 ? 128 : 64;         // <= 128: bn_merge_final_kernel reads up to 32 shares per wave, all at once
     if ((int64_t)shares * C * FIN::NV > scratch_floats) return 0;
     const int slot = (int)(g_bnf_slot.fetch_add(1, std::memory_order_relaxed) % BNF_SLOTS);
     hipLaunchKernelGGL((bn_merge_final_kernel<FIN>), dim3(ceil_div(C, 64), shares), dim3(256), 0, s, partial, slices, C, M,

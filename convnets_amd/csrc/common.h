@@ -52,6 +52,8 @@ struct CnkSwitches {
     int rowpatch_stats;        // CNK_ROWPATCH_STATS (1)
     int wgrad_big;             // CNK_WGRAD_BIG (1)
     int wgrad3;                // CNK_WGRAD3 (1)
+    int wgrad3_slots_pct;      // CNK_WGRAD3_SLOTS_PCT (-1: as wgrad_slots_pct): the same for the all-taps 3x3 kernel
+    int wgrad_slots_pct;       // CNK_WGRAD_SLOTS_PCT (-1: all): A/B override of the share of the workgroup slots the weight gradients' split-K fills
     int bn_pool_elementwise;   // CNK_BN_POOL_ELEMENTWISE (0)
     int bn_fused_final;        // CNK_BN_FUSED_FINAL (1): finalisation of the BN partials inside the merge launch
 };

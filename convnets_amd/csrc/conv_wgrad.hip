@@ -385,6 +385,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const float* 
     }
 }
 
+// Share of the chip's workgroup slots the split-K of a weight gradient fills, as the CALLER bounds it: cnk_conv2d_wgrad takes
+// any workspace of at least one slab, and a workspace smaller than cnk_conv2d_workspace_bytes() makes the kernel split the pixel
+// range less deep (max_splits = workspace / slab).  Why a caller would: bf16 weight gradients run on a second HIP stream BESIDE
+// the data gradients and BN backward passes of the training step (convnets_amd/ops.py); they only have to be done when the
+// backward pass ends, and every CU that holds one of their 112-KiB-LDS workgroups admits a single implicit-GEMM workgroup of the
+// main stream instead of four.  Measured (round 3, A/B in one call, hipGraph replays): ResNet-50 bs 256 with all slots
+// 20.54-20.61 ms, 75 % 20.35-20.41, 50 % 20.21-20.22, 35 % 21.3 (the weight gradients become the tail); ResNet-152 bs 128
+// 26.40 -> 25.80 ms at 50 %; but VGG-16 (every layer a heavy 3x3: the weight gradients ARE the critical path) 10.25 -> 11.3 ms
+// and ResNeXt-50 16.99 -> 18.24: the right share is a property of the MODEL, so the host side measures it once
+// (ops.calibrate_wgrad_share).  Fewer splits also mean proportionally less slab traffic and a shorter slab sum.
+// CNK_WGRAD_SLOTS_PCT forces a share inside the library (A/B runs).
+static int wgrad_cap_splits(int splits, int ksteps, size_t slab_bytes, size_t ws_bytes, int* per_split) {
+    const size_t fit = ws_bytes / slab_bytes;
+    if (fit >= (size_t)splits || fit == 0) return splits;       // enough room (or none: the caller's size check reports it)
+    *per_split = ceil_div(ksteps, (int)fit);
+    return ceil_div(ksteps, *per_split);
+}
+
 static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, int* ksteps,
                        int* per_split) {
     int Ho, Wo;
@@ -404,6 +422,8 @@ static void wgrad_plan(const cnk_conv_desc* d, int* bmw, int* bnw, int* splits, 
     }
     int tiles = grouped ? (d->Cout / 64) * d->kh * d->kw
                         : ceil_div(d->Cout, *bmw) * ceil_div(d->Cin, *bnw) * d->kh * d->kw;
+    if (cnk_sw().wgrad_slots_pct > 0) slots = slots * cnk_sw().wgrad_slots_pct / 100;
+    if (slots < 1) slots = 1;
     *ksteps = ceil_div(M, kp);
     // The kernel is resident at 2 workgroups per CU (80 KiB LDS each): 512 slots on 256 CUs.  Fill
     // them exactly once -- tiles*splits just ABOVE a multiple of 512 costs a whole extra round.
@@ -429,8 +449,10 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     int bmw, bnw;
     wgrad_plan(d, &bmw, &bnw, &p.splits, &p.ksteps, &p.ksteps_per_split);
     const bool grouped = conv_groups(d) > 1;
-    size_t need = (size_t)p.splits * d->Cout * (grouped ? 64 : d->Cin) * d->kh * d->kw * sizeof(float);
-    CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    const size_t slab_bytes = (size_t)d->Cout * (grouped ? 64 : d->Cin) * d->kh * d->kw * sizeof(float);
+    p.splits = wgrad_cap_splits(p.splits, p.ksteps, slab_bytes, ws ? ws_bytes : 0, &p.ksteps_per_split);
+    size_t need = (size_t)p.splits * slab_bytes;
+    CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad: workspace too small (%zu < %zu; at least one slab of %zu bytes)", ws_bytes, need, slab_bytes);
     p.dy = dy; p.x = x; p.slab = (float*)ws;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
     p.KH = d->kh; p.KW = d->kw; p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;

@@ -321,7 +321,9 @@ static void w3_plan(const cnk_conv_desc* d, bool* big, int* splits, int* ksteps,
     const int kp = *big ? 64 : 32;
     const int M = d->N * d->H * d->W;
     const int tiles = (d->Cout / (*big ? 128 : 64)) * (d->Cin / 64);
-    const int slots = *big ? 256 : 512;
+    const int pct3 = cnk_sw().wgrad3_slots_pct > 0 ? cnk_sw().wgrad3_slots_pct : (cnk_sw().wgrad_slots_pct > 0 ? cnk_sw().wgrad_slots_pct : 100);
+    int slots = (*big ? 256 : 512) * pct3 / 100;          // A/B switches; the product bounds the splits by the workspace (below)
+    if (slots < 1) slots = 1;
     *ksteps = ceil_div(M, kp);
     int want = tiles >= slots ? 1 : slots / tiles;
     int max_by_k = *ksteps / 4 > 0 ? *ksteps / 4 : 1;
@@ -358,8 +360,14 @@ int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, i
     W3Params p = {};
     bool big;
     w3_plan(d, &big, &p.splits, &p.ksteps, &p.ksteps_per_split);
-    const size_t need = (size_t)p.splits * d->Cout * 9 * d->Cin * sizeof(float);
-    CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    const size_t slab_bytes = (size_t)d->Cout * 9 * d->Cin * sizeof(float);
+    // a workspace below cnk_conv2d_workspace_bytes() bounds the split-K depth (conv_wgrad.hip: wgrad_cap_splits)
+    if (ws && ws_bytes / slab_bytes >= 1 && ws_bytes / slab_bytes < (size_t)p.splits) {
+        p.ksteps_per_split = ceil_div(p.ksteps, (int)(ws_bytes / slab_bytes));
+        p.splits = ceil_div(p.ksteps, p.ksteps_per_split);
+    }
+    const size_t need = (size_t)p.splits * slab_bytes;
+    CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad: workspace too small (%zu < %zu; at least one slab of %zu bytes)", ws_bytes, need, slab_bytes);
     p.dy = dy; p.x = x; p.slab = (float*)ws;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
     p.M = d->N * d->H * d->W;

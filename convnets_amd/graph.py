@@ -22,11 +22,14 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, example_batch, warmup=3):
+    def __init__(self, model, example_batch, warmup=3, wgrad_share=None):
         """model: a MultiClassBaseModel on the GPU with its optimizer initialised; example_batch: (x, y) device
         tensors of the shapes every later batch will have.  The warm-up steps (lazy initialisation: packed
         weight tables, workspaces, allocator pools) run on a snapshot, so constructing the object does NOT
-        advance training."""
+        advance training.
+        wgrad_share: None keeps ops.WGRAD_SHARE; a float sets it; 'auto' MEASURES it (model.calibrate_wgrad_share) -- per
+        candidate share of the weight gradients' split-K depth (ops.WGRAD_SHARE: how hard the side stream competes with
+        the backward pass it runs beside) a few eager steps are timed on a snapshot, the fastest stays."""
         if model.optimizer is None:
             model.init_optimizer()
         x, y = example_batch
@@ -53,6 +56,17 @@ class GraphedTrainStep:
         torch.cuda.current_stream(x.device).wait_stream(self.stream)
         self._bn_layers = [m for m in model.modules() if hasattr(m, '_stats_epoch')]
         self._restore(snap)
+        self.wgrad_share_ms = None
+        if wgrad_share == 'auto':
+            # measured on EAGER steps (same two-stream schedule), on the capture stream, before the one capture: capturing
+            # the step several times in one process is not an option -- every capture after the first replayed 30 % slower
+            # (26.7 vs 20.7 ms, ResNet-50: the runtime's stream-to-hardware-queue mapping)
+            self.stream.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(self.stream):
+                self.wgrad_share_ms = model.calibrate_wgrad_share((self.x, self.y)) or None
+            torch.cuda.current_stream(x.device).wait_stream(self.stream)
+        elif isinstance(wgrad_share, (int, float)):
+            ops.WGRAD_SHARE[0] = float(wgrad_share)
         self._capture()
 
     # ---- state that a throw-away step must not leave behind ----------------------------------------------

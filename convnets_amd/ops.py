@@ -106,6 +106,12 @@ def workspace(nbytes, device):
 # filling the other's idle slots.  The wgrad stream waits on an event recorded after dy is ready; whoever
 # consumes weight gradients (FlatAdam.step, clipping, GradReducer) first calls join_side_streams().
 WGRAD_STREAM = os.environ.get('CNK_WGRAD_STREAM', '1') != '0'
+# Share of the split-K depth the weight gradients get while they run on the side stream (cnk_conv2d_wgrad: a workspace smaller
+# than cnk_conv2d_workspace_bytes bounds the number of pixel-range splits, include/cnk.h).  The gradients only have to be done
+# when the backward pass ends, and every CU holding one of their 112-KiB-LDS workgroups admits one implicit-GEMM workgroup of
+# the compute stream instead of four: ResNet-50 / 152 step 1.7-2.3 % faster at 0.5, VGG-16 10 % slower (its weight gradients
+# are the critical path) -- a property of the MODEL, so it is measured: calibrate_wgrad_share() below.
+WGRAD_SHARE = [float(os.environ.get('CNK_WGRAD_SHARE', '1.0'))]
 _side_streams = {}
 
 
@@ -461,10 +467,16 @@ class Conv2dFn(torch.autograd.Function):
                     if ctx.has_bias else None
             nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), PASS_WGRAD)
 
-            def run_wgrad():
+            def run_wgrad(share=1.0):
                 ws = workspace(nws, x.device)
+                budget = ws.numel()
+                # (the MFMA split-K kernels only: channel counts on the 64 grid, dense -- every other kernel needs its whole workspace)
+                if share < 1.0 and not ctx.has_bias and desc.groups == 1 and desc.Cin % 64 == 0 and desc.Cout % 64 == 0:
+                    # bound the split-K depth: at least one fp32 slab [Cout][kh][kw][Cin], whole multiples of 256 bytes
+                    slab = desc.Cout * (64 if desc.groups > 1 else desc.Cin) * desc.kh * desc.kw * 4
+                    budget = max((slab + 255) // 256 * 256, int(nws * share) // 256 * 256)
                 check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
-                                           int(direct), _p(ws), ws.numel(), _stream()))
+                                           int(direct), _p(ws), budget, _stream()))
                 if direct:
                     _grad_written(weight)
                     if ctx.has_bias:
@@ -475,7 +487,7 @@ class Conv2dFn(torch.autograd.Function):
                 side = wgrad_stream(x.device)
                 side.wait_event(dy_ready)                                    # dy, x (and zero_grad) are ready
                 with torch.cuda.stream(side):
-                    run_wgrad()
+                    run_wgrad(WGRAD_SHARE[0])
                 dy.record_stream(side)
                 x.record_stream(side)
                 _join_at_end_of_backward()

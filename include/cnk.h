@@ -144,7 +144,12 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[Cout][Cin][kh][kw] (fp32) = sum over N,Ho,Wo of dy * x ; dbias[Cout] = sum dy (may be NULL).
- * accumulate != 0 adds into dw/dbias (torch's .grad accumulation), else overwrites. */
+ * accumulate != 0 adds into dw/dbias (torch's .grad accumulation), else overwrites.
+ * workspace: cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD) gives the deepest split of the pixel range (it fills the chip).
+ * The MFMA kernels accept any workspace of at least ONE fp32 slab [Cout][kh][kw][Cin] (rounded up to 256 bytes, plus the
+ * bias sum's scratch when dbias != NULL): a smaller workspace bounds the number of splits -- fewer, longer workgroups, less
+ * slab traffic -- which is what a caller wants when the weight gradient runs on a side stream BESIDE other kernels and only
+ * has to finish with them (convnets_amd/ops.py).  Results differ only in the fp32 summation order of the slabs. */
 int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
                      float* dbias, int accumulate, void* workspace, size_t workspace_bytes,
                      void* stream);

@@ -481,3 +481,69 @@ def test_1x1_data_gradients_with_their_training_step_epilogues(style, N, Cin, Co
     got = bpart.double().sum(0).cpu()
     assert ((got[:, 0] - s1).abs().max() / s1.abs().max()).item() < 5e-3
     assert ((got[:, 1] - s2).abs().max() / s2.abs().max()).item() < 5e-3
+
+
+@pytest.mark.parametrize('Cin,Cout,k,H,N', [(128, 128, 3, 28, 16), (256, 512, 1, 14, 32), (64, 64, 3, 56, 8), (512, 128, 1, 28, 8)])
+def test_weight_gradient_split_depth_follows_the_workspace(Cin, Cout, k, H, N):
+    """cnk_conv2d_wgrad (include/cnk.h): a workspace below cnk_conv2d_workspace_bytes bounds the number of pixel-range splits
+    (round 3: the side-stream weight gradients of the training step run with a share of the full depth, ops.WGRAD_SHARE).
+    Full, half, and one-slab workspaces give the same gradient up to the fp32 order of the slab sum; less than a slab is refused."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    g = torch.Generator().manual_seed(Cin + k)
+    x = torch.randn(N, Cin, H, H, generator=g).bfloat16()
+    dy = torch.randn(N, Cout, H, H, generator=g).bfloat16()
+    xg, dyg = x.cuda().contiguous(memory_format=CL), dy.cuda().contiguous(memory_format=CL)
+    desc = ops.make_desc(xg.shape, (Cout, Cin, k, k), (1, 1), (k // 2, k // 2), _lib.CNK_BF16)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), _lib.PASS_WGRAD)
+    slab = (Cout * Cin * k * k * 4 + 255) // 256 * 256
+    assert nws >= 4 * slab, 'the full plan splits at least four ways at this size'
+    ws = torch.empty(nws, dtype=torch.uint8, device='cuda')
+    out = {}
+    for name, budget in (('full', nws), ('half', nws // 2 // 256 * 256), ('one', slab)):
+        dw = torch.zeros(Cout, Cin, k, k, device='cuda')
+        assert lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dyg), P(xg), P(dw), None, 0, P(ws), budget, st) == 0, lib.cnk_last_error()
+        torch.cuda.synchronize()
+        out[name] = dw
+    assert lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dyg), P(xg), P(out['one']), None, 0, P(ws), slab - 256, st) != 0
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    xr = x.double().requires_grad_(False)
+    wref = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wref, padding=k // 2).backward(dy.double())
+    ref = wref.grad.float().numpy()
+    for name in out:
+        assert rel_l2(host(out[name]), ref) < 2e-5, name
+    assert rel_l2(host(out['half']), host(out['full'])) < 2e-6 and rel_l2(host(out['one']), host(out['full'])) < 2e-6
+
+
+def test_wgrad_share_calibration_leaves_training_state_alone():
+    """ops.WGRAD_SHARE is MEASURED (GraphedTrainStep(wgrad_share='auto'), model.calibrate_wgrad_share): the measurement steps
+    run on a snapshot -- parameters, Adam moments, BN statistics and the step count are what they were."""
+    import convnets_amd as ca
+    from convnets_amd import ops
+    torch.manual_seed(21)
+    s = ca.Settings(kind=26, input_size=(3, 32, 32), num_classes=10, batch_size=32, mixed_precision=True, dropout_rate=0)
+    m = ca.ResNet(s).cuda()
+    m.init_optimizer()
+    m.train()
+    x, y = torch.randn(32, 3, 32, 32, device='cuda'), torch.randint(0, 10, (32,), device='cuda')
+    m.train_batch((x, y))
+    torch.cuda.synchronize()
+    keep = ops.WGRAD_SHARE[0]
+    try:
+        before = (m.optimizer.flat_p.clone(), m.optimizer.exp_avg.clone(), m.optimizer.step_count, [b.clone() for b in m.buffers()])
+        t = m.calibrate_wgrad_share((x, y))
+        assert set(t) == {1.0, 0.75, 0.5} and ops.WGRAD_SHARE[0] in t
+        g = ca.GraphedTrainStep(m, (x, y), wgrad_share='auto')
+        assert g.wgrad_share_ms is not None and ops.WGRAD_SHARE[0] in g.wgrad_share_ms
+        torch.cuda.synchronize()
+        assert torch.equal(before[0], m.optimizer.flat_p) and torch.equal(before[1], m.optimizer.exp_avg)
+        assert before[2] == m.optimizer.step_count
+        for a, b in zip(before[3], m.buffers()):
+            assert torch.equal(a, b)
+        l1, _ = g.replay()
+        l2, _ = g.replay()
+        assert float(l2) < float(l1) * 1.5 and m.optimizer.step_count == before[2] + 2
+    finally:
+        ops.WGRAD_SHARE[0] = keep

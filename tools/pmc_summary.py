@@ -30,6 +30,13 @@ def load_counter(d, cname):
     return agg
 
 
+# bench.py's roofline objects are per libcnk ProfScope family (csrc/common.h CNK_KF_*): the launches of one family are the
+# same population here (traffic and algorithmic bytes must describe the same launches)
+FAMILY = {'gemm1x1_kernel': 'igemm_gather_kernel',                                       # CNK_KF_GATHER
+          'igemm_halo3x3_pf_kernel': 'igemm_halo3x3_kernel', 'pp3x3_kernel': 'igemm_halo3x3_kernel',      # CNK_KF_HALO
+          'wgrad3x3_kernel': 'wgrad_mfma_kernel'}                                        # CNK_KF_WGRAD
+
+
 def main(fetch_dir, write_dir, stats_dir, tag):
     fa, wa = load_counter(fetch_dir, 'FETCH_SIZE'), load_counter(write_dir, 'WRITE_SIZE')
     stats = {}
@@ -44,7 +51,7 @@ def main(fetch_dir, write_dir, stats_dir, tag):
         write = ws * 1024 / max(nw, 1)
         calls, tot, avg = stats.get(k, (0, 0.0, 0.0))
         rows.append((tot, k, nf, fetch, write, avg))
-        f_ = fam[k.split('<')[0].strip()]
+        f_ = fam[FAMILY.get(k.split('<')[0].strip(), k.split('<')[0].strip())]
         f_[0] += nf; f_[1] += fetch * nf; f_[2] += write * nf; f_[3] += avg * nf
         out[k] = {'unit': 'bytes/launch', 'fetch': round(fetch), 'write': round(write), 'total': round(fetch + write),
                   'avg_launch_us': round(avg / 1e3, 2),
@@ -56,7 +63,8 @@ def main(fetch_dir, write_dir, stats_dir, tag):
     txt = '\n'.join(lines)
     print(txt)
     os.makedirs('profiles', exist_ok=True)
-    json.dump({'tag': tag, 'note': 'FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact; KiB->bytes; separate --pmc passes',
+    json.dump({'tag': tag, 'note': 'FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact; KiB->bytes; separate --pmc passes; '
+                                   'families follow libcnk\'s ProfScope families: ' + ', '.join('%s -> %s' % kv for kv in sorted(FAMILY.items())),
                'kernels': out,
                'families': {k: {'unit': 'bytes/launch (launch-weighted mean over template variants)', 'launches_profiled': v[0],
                                 'fetch': round(v[1] / v[0]), 'write': round(v[2] / v[0]), 'total': round((v[1] + v[2]) / v[0]),
