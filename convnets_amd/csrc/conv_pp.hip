@@ -125,7 +125,7 @@ template <class CFG> struct PPState {
     int tile_m, tile_n;
     int pbase_n;                                   // padded index of patch row 0 of the next chunk's tile
     int wuni, wuni_next;                           // weight element offset of (tile_n, chunk) for current / next chunk
-    int post_epi, epi_ops;
+    int post_epi;
 };
 
 __device__ __forceinline__ int pp_index(const PPParams& p, int m) {
@@ -205,10 +205,9 @@ template <class CFG, int T, bool FIRST = false> __device__ __forceinline__ void 
         // retire everything issued before this phase except the patch piece of the previous phase C (the counter
         // retires in order: that piece, which comes from HBM, gets three phases this way)
         constexpr int KEEP = ((PP_ABL & 2) ? 0 : NB) + ((PP_ABL & 1) ? 0 : ((T >= 1 && T <= 7) ? 1 : 0));
-        if (T == 0 && st.post_epi == 1) {
-            if (st.epi_ops == CFG::EPI_STORES + NJ) PP_WAIT_VM(KEEP + CFG::EPI_STORES + NJ);
-            else PP_WAIT_VM(KEEP + CFG::EPI_STORES);
-        } else PP_WAIT_VM(KEEP);
+        // (the first phase L after an epilogue waits for nothing: the epilogue retired every DMA issued before it, this
+        // phase's own weight DMAs are for step 2, and the epilogue's stores are nobody's operand)
+        if (!(T == 0 && st.post_epi != 0)) PP_WAIT_VM(KEEP);
         PP_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -279,7 +278,7 @@ template <class CFG, int T, bool FIRST = false> __device__ __forceinline__ void 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Stores as inline asm: hipcc does not count them, the K loop's vmcnt immediates do (st.epi_ops).  The trailing
+// Stores as inline asm (hipcc tracks no vector-memory operation of this kernel).  The trailing
 // s_nop keeps the data registers intact until the store has read them (cdna_hip_programming.md 5.7 item 1).
 __device__ __forceinline__ void pp_store16(void* g, const bf16x8& v) {
     const u32x4 d = __builtin_bit_cast(u32x4, v);
@@ -312,7 +311,7 @@ enum { PP_EPI_PLAIN = 0, PP_EPI_STATS = 1, PP_EPI_FULL = 2 };
 // Per-wave epilogue of tile (tile_m, tile_n): see the header comment.  MODE: PLAIN = rounded rows only; STATS = + BN
 // statistics partials; FULL = bias / ReLU / gradient addend (+mask) / fused BN backward / statistics, all run-time.
 // The number of vector-memory operations per wave is static: CFG::EPI_STORES row stores, + NJ partial stores in STATS
-// and FULL (when sums are written), so the K loop's counted vmcnt stays exact (st.epi_ops).
+// and FULL (when sums are written).
 // FULL issues the 16 side-operand loads of two row blocks of a column block (4 row passes x {addend, its mask, BN
 // input, its mask}; an absent operand reads the zero block) BEFORE their first store: vmcnt retires in order, so a
 // load waited for behind a store would wait for that store's round trip too.
@@ -328,7 +327,10 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
     const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
     const bool has_add = MODE == PP_EPI_FULL && p.addend != nullptr;
     const bool want_sums = MODE == PP_EPI_STATS || (MODE == PP_EPI_FULL && (p.stats || bnf));
-    const bool full_tile = (st.tile_m + 1) * CFG::BM <= p.M;
+    // Every LDS-DMA of the K loop (the next tile's tap-1 weights, issued one phase ago, are the youngest) is retired HERE,
+    // before the first store of the epilogue: the K loop's counted waits must never have to tell loads from stores, because
+    // vmcnt does not retire them in one order (see the side-operand waits below).
+    PP_WAIT_VM(0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int cb = C0 + j * 32;                                  // first channel of this column block
@@ -414,12 +416,15 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
                     const int m = ms[k];
                     const size_t goff = ((size_t)(m < 0 ? 0 : m) * p.Nout + cb) * 2 + cc * 16;
                     if (MODE == PP_EPI_FULL) {
-                        // retire this pass's four loads: younger are the 4*(3-k) loads of the later passes and the k
-                        // stores of the earlier ones (a partial last tile may have skipped stores: count none there)
+                        // retire this pass's four loads: the count is the 4*(3-k) LOADS of the later passes only.  The k
+                        // stores of the earlier passes are NOT credited: loads retire in order among loads, but a store can
+                        // be acknowledged before an older load has returned (round 3: crediting them -- vmcnt(9 / 6 / 3) --
+                        // let a wait pass with one of its own loads still in flight as soon as the chip was busy enough
+                        // for loads to be slower than store acks; 7 of 196 tiles wrong at batch 128, none at batch 16)
                         if (k == 0) pp_wait_side<12>(av[0], xv[0], am[0], km[0]);
-                        else if (k == 1) { if (full_tile) pp_wait_side<9>(av[1], xv[1], am[1], km[1]); else pp_wait_side<8>(av[1], xv[1], am[1], km[1]); }
-                        else if (k == 2) { if (full_tile) pp_wait_side<6>(av[2], xv[2], am[2], km[2]); else pp_wait_side<4>(av[2], xv[2], am[2], km[2]); }
-                        else { if (full_tile) pp_wait_side<3>(av[3], xv[3], am[3], km[3]); else pp_wait_side<0>(av[3], xv[3], am[3], km[3]); }
+                        else if (k == 1) pp_wait_side<8>(av[1], xv[1], am[1], km[1]);
+                        else if (k == 2) pp_wait_side<4>(av[2], xv[2], am[2], km[2]);
+                        else pp_wait_side<0>(av[3], xv[3], am[3], km[3]);
                     }
                     if (m >= 0) {
                         if (MODE == PP_EPI_FULL) {
@@ -459,7 +464,7 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
                             }
                         }
                         // one store instruction per pass as long as ANY lane has a row (a partial last tile may skip
-                        // whole passes: the caller then stops trusting the static store count, see post_epi)
+                        // whole passes)
                         pp_store16(dst + goff, v);
                     }
                 }
@@ -573,7 +578,6 @@ __global__ __launch_bounds__(512, 2) void pp3x3_kernel(const PPParams p) {
     }
 #endif
     st.k = k0; st.c = 0; st.pb = 0; st.post_epi = 0;
-    st.epi_ops = (MODE == PP_EPI_STATS || (MODE == PP_EPI_FULL && (p.stats || p.bnf_x))) ? CFG::EPI_STORES + NJ : CFG::EPI_STORES;
     const int pbase0 = set_tile(k0);
     st.wuni = st.tile_n * CFG::BN * 9 * p.C;
     set_next();
@@ -604,8 +608,7 @@ __global__ __launch_bounds__(512, 2) void pp3x3_kernel(const PPParams p) {
         pp_tap<CFG, 8>(p, st);
         if (st.c == p.csteps - 1) {
             pp_epilogue<CFG, MODE>(p, st, smem_epi);
-            // a full tile issued exactly epi_ops stores; after a partial one the next wait keeps no allowance
-            st.post_epi = (st.tile_m + 1) * CFG::BM <= p.M ? 1 : 2;
+            st.post_epi = 1;
         }
         if (!st.has_next) break;
         st.k = st.kn; st.c = st.cn; st.pb ^= 1;

@@ -547,3 +547,46 @@ def test_wgrad_share_calibration_leaves_training_state_alone():
         assert float(l2) < float(l1) * 1.5 and m.optimizer.step_count == before[2] + 2
     finally:
         ops.WGRAD_SHARE[0] = keep
+
+
+@pytest.mark.parametrize('N,C,H', [(128, 256, 14), (256, 512, 7), (128, 512, 7)])
+def test_pingpong_full_epilogue_under_load(N, C, H):
+    """Regression (round 3): the fused data gradient on the ping-pong core with EVERY CU busy (196 / 100 single-tile workgroups:
+    the ResNet-152 bs 128 and ResNet-50 bs 256 shapes).  Its hand-counted s_waitcnt vmcnt used to credit the epilogue's own
+    stores as still outstanding; on a busy chip store acknowledgements overtake older loads, a wait then passed with a side
+    operand still in flight, and a few of the 196 tiles came out wrong -- never at the small test sizes.  Five launches each
+    must equal the halo kernel bit for bit (dx) and in the sums."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    g = torch.Generator().manual_seed(N + C)
+    M = N * H * H
+    dy = torch.randn(N, C, H, H, generator=g).bfloat16().cuda().contiguous(memory_format=CL)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.02
+    desc = ops.make_desc(dy.shape, w.shape, (1, 1), (1, 1), _lib.CNK_BF16)
+    _, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bnx = (torch.randn(N, H, H, C, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    addend = torch.randn(N, H, H, C, generator=g).bfloat16().cuda()
+    amask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).cuda()
+    bmean, binv = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    bgam, bbeta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+
+    def run(env, reps):
+        outs = []
+        with _lib.switches(**env):
+            nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+            for r in range(reps):
+                bpart = torch.full((nb, C, 2), float('nan'), device='cuda')
+                fuse = _lib.BnBwdFuse(bnx.data_ptr(), bmean.data_ptr(), binv.data_ptr(), bgam.data_ptr(), bbeta.data_ptr(), None, bpart.data_ptr(), 1)
+                dx = torch.full_like(dy, float('nan'))
+                c0, f0 = cnt(CNT_PP[0]), cnt(CNT_PP_FULL)
+                assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dy), P(wd), P(dx), P(addend), P(amask), ctypes.byref(fuse), None, 0, st) == 0, lib.cnk_last_error()
+                torch.cuda.synchronize()
+                outs.append((dx, bpart.double().sum(0), cnt(CNT_PP_FULL) - f0))
+        return outs
+    ref = run(dict(CNK_PP3X3='0'), 1)[0]
+    assert ref[2] == 0
+    for dx, sums, ran in run(dict(CNK_PP3X3='1', CNK_PP_CFG=None, CNK_PP_FULL=None), 5):
+        assert ran == 1, 'the unforced dispatch must put this shape on the ping-pong core'
+        assert torch.equal(dx, ref[0])
+        assert ((sums - ref[1]).abs().max() / ref[1].abs().max()).item() < 1e-5
