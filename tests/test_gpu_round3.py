@@ -590,3 +590,33 @@ def test_pingpong_full_epilogue_under_load(N, C, H):
         assert ran == 1, 'the unforced dispatch must put this shape on the ping-pong core'
         assert torch.equal(dx, ref[0])
         assert ((sums - ref[1]).abs().max() / ref[1].abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('N,C,H,W', [(4, 64, 32, 32), (3, 64, 15, 18), (2, 128, 9, 7), (2, 24, 12, 12), (1, 8, 2, 2)])
+def test_stem_pool_with_folded_bn_streaming_kernel(N, C, H, W, dtype):
+    """cnk_maxpool2d_fwd_bn (conv -> BN -> ReLU -> MaxPool2d 3x3/2/1, src/resnet.py:66-67): the streaming kernel of round 3
+    (nine unconditional tap loads, coefficients in registers, packed arg-max store) against torch on the CPU -- values bit
+    for bit, and the arg-max bytes must name the element torch's max_pool2d returns (first maximum in scan order)."""
+    _lib, lib, cnt = _lib_and_counter()
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    code = _lib.CNK_BF16 if dtype == 'bf16' else _lib.CNK_F32
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N, H, W, C, generator=g) * 2).to(tdt)
+    x[0, :2, :2] = x[0, 0, 0]                                  # ties inside a window
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    xg = x.cuda()
+    y = torch.empty(N, Ho, Wo, C, dtype=tdt, device='cuda')
+    idx = torch.full((N, Ho, Wo, C), 255, dtype=torch.uint8, device='cuda')
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.cnk_maxpool2d_fwd_bn(P(xg), P(scale.cuda()), P(shift.cuda()), 1, P(y), P(idx), N, H, W, C, 3, 3, 2, 2, 1, 1, code, st) == 0, lib.cnk_last_error()
+    torch.cuda.synchronize()
+    a = torch.relu(x.float() * scale + shift).to(tdt)          # fp32 affine (one fma-free multiply-add), rounded like the BN pass stores it
+    ref, ri = F.max_pool2d(a.float().permute(0, 3, 1, 2), 3, 2, 1, return_indices=True)
+    assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), ref)
+    pos = idx.cpu().permute(0, 3, 1, 2).long()
+    ho = torch.arange(Ho).view(1, 1, Ho, 1)
+    wo = torch.arange(Wo).view(1, 1, 1, Wo)
+    flat = (2 * ho - 1 + pos // 3) * W + (2 * wo - 1 + pos % 3)
+    assert torch.equal(flat, ri)
