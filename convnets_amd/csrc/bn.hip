@@ -1262,24 +1262,32 @@ template <typename T, int VEC> struct CellGather {
         in_h1 = h0 + 1 < p.H;
         in_w1 = w0 + 1 < p.W;
         xoff = ((int64_t)(n * p.H + h0) * p.W + w0) * C + (int64_t)vcol * VEC;
+        // All twelve loads of a cell are UNCONDITIONAL (absent neighbours / windows re-read the cell's first element or
+        // window: addresses always valid, results unused): bounds branches around the loads made them one dependent round
+        // trip each (round 3, from the .s); the caller keeps them together with a sched_barrier.
+        const int64_t dw = in_w1 ? C : 0, dh = in_h1 ? (int64_t)p.W * C : 0;
         xv[0].load(x + xoff);
-        if (in_w1) xv[1].load(x + xoff + C);
-        if (in_h1) xv[2].load(x + xoff + (int64_t)p.W * C);
-        if (in_h1 && in_w1) xv[3].load(x + xoff + (int64_t)p.W * C + C);
+        xv[1].load(x + xoff + dw);
+        xv[2].load(x + xoff + dh);
+        xv[3].load(x + xoff + dh + dw);
+        IB none;
+        if constexpr (VEC == 8) none = IB{0xffffffffu, 0xffffffffu};      // 255 is no window position (kh*kw <= 255)
+        else if constexpr (VEC == 4) none = 0xffffffffu;
+        else none = 0xff;
+        bool okk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int a = k >> 1, c = k & 1;
             const int ho = (int)cj + p.lo_h + a, wo = (int)ci + p.lo_w + c;
-            const bool ok = a < p.nwin_h && c < p.nwin_w && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
-            if constexpr (VEC == 8) b[k] = IB{0xffffffffu, 0xffffffffu};      // 255 is no window position (kh*kw <= 255)
-            else if constexpr (VEC == 4) b[k] = 0xffffffffu;
-            else b[k] = 0xff;
-            if (ok) {
-                const size_t o = ((size_t)(n * p.Ho + ho) * p.Wo + wo) * C + (size_t)vcol * VEC;
-                g[k].load(dy + o);
-                b[k] = *(const IB*)(idx + o);
-            }
+            okk[k] = a < p.nwin_h && c < p.nwin_w && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            const int hoc = okk[k] ? ho : 0, woc = okk[k] ? wo : 0;
+            const size_t o = ((size_t)(n * p.Ho + hoc) * p.Wo + woc) * C + (size_t)vcol * VEC;
+            g[k].load(dy + o);
+            b[k] = *(const IB*)(idx + o);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!okk[k]) b[k] = none;
     }
     // gradient reaching element e = dy*2+dx of the cell, windows summed in (ho, wo) order
     template <int E> __device__ __forceinline__ void sum(const PoolCell& p, float (&d)[VEC]) const {
@@ -1332,6 +1340,7 @@ __global__ __launch_bounds__(256) void bn_cell_bwd_reduce_kernel(
         for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
             CellGather<T, VEC> cg;
             cg.issue(dy, idx, x, pc, (uint32_t)m, vcol, C);
+            __builtin_amdgcn_sched_barrier(0);
             auto element = [&](auto tag) {
                 constexpr int E = decltype(tag)::value;
                 if (!cg.template inside<E>()) return;
@@ -1413,6 +1422,7 @@ __global__ __launch_bounds__(256) void bn_cell_bwd_apply_kernel(
     for (int64_t m = m0 + trow; m < m1; m += g.rpb) {
         CellGather<T, VEC> cg;
         cg.issue(dy, idx, x, pc, (uint32_t)m, vcol, C);
+        __builtin_amdgcn_sched_barrier(0);
         auto element = [&](auto tag) {
             constexpr int E = decltype(tag)::value;
             if (!cg.template inside<E>()) return;

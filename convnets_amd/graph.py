@@ -14,7 +14,9 @@ What makes the step capturable:
   * the weight-gradient side stream forks from and re-joins the capturing stream through events, so it is part of
     the captured graph (two branches that the runtime may run concurrently, as in the eager step); the
     data-parallel reducer's stream and the RCCL all-reduces it issues (convnets_amd/dp.py) join the same way.
-The learning rate is a kernel argument: `replay` re-captures when the scheduler (src/basemodel.py:69-76) changes it.
+The learning rate is a kernel argument of the captured Adam launch; when the scheduler (src/basemodel.py:69-76) changes it the
+replay does NOT re-capture (every capture after a process's first replays ~30 % slower) -- the kernel applies
+lr / bc1 with bc1 read from the device record, so the record carries bc1 * lr_captured / lr_now instead.
 """
 import torch
 
@@ -141,13 +143,17 @@ class GraphedTrainStep:
         """One training step on `batch` (None: the resident batch again).  Returns (loss, correct) as device
         scalars, the tensors of the captured step: read or accumulate them before the next replay."""
         opt = self.model.optimizer
-        if opt.param_groups[0]['lr'] != self.lr:
-            self._capture()
         if batch is not None:
             x, y = batch
             self.x.copy_(x, non_blocking=True)
             self.y.copy_(y, non_blocking=True)
-        self.scalars.push(opt.bias_corrections(opt.step_count + 1), ops._dropout_calls[0])
+        bc = opt.bias_corrections(opt.step_count + 1)
+        lr = opt.param_groups[0]['lr']
+        if lr != self.lr:
+            # adam_kernel steps by (lr_captured / bc1): a changed learning rate rides on the record (equal to the eager
+            # step's lr / bc1 up to one rounding of the quotient)
+            bc = (bc[0] * (self.lr / lr) if lr != 0 else float('inf'), bc[1])
+        self.scalars.push(bc, ops._dropout_calls[0])
         self.graph.replay()
         opt.step_count += 1
         ops._dropout_calls[0] += self.scalars.dropout_calls

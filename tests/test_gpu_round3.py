@@ -620,3 +620,36 @@ def test_stem_pool_with_folded_bn_streaming_kernel(N, C, H, W, dtype):
     wo = torch.arange(Wo).view(1, 1, 1, Wo)
     flat = (2 * ho - 1 + pos // 3) * W + (2 * wo - 1 + pos % 3)
     assert torch.equal(flat, ri)
+
+
+def test_graph_replay_follows_a_learning_rate_change_without_recapture():
+    """GraphedTrainStep: the scheduler's new learning rate (src/basemodel.py:69-76) reaches the captured Adam launch through
+    the device record (bc1 * lr_captured / lr_now), not through a re-capture.  Two replays at lr, two at lr / 10, against the
+    eager steps of an identical model: same parameters to fp32 rounding of one quotient."""
+    import copy
+    import convnets_amd as ca
+    torch.manual_seed(21)
+    s = ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, batch_size=16, mixed_precision=True, dropout_rate=0, learning_rate=1e-3)
+    x, y = torch.randn(16, 3, 32, 32, device='cuda'), torch.randint(0, 10, (16,), device='cuda')
+    models = []
+    for _ in range(2):
+        torch.manual_seed(21)
+        m = ca.ResNet(s).cuda()
+        m.init_optimizer()
+        m.train()
+        models.append(m)
+    a, b = models
+    assert torch.equal(a.optimizer.flat_p, b.optimizer.flat_p)
+    g = ca.GraphedTrainStep(a, (x, y))
+    graph_obj = g.graph
+    for lr in (1e-3, 1e-3, 1e-4, 1e-4):
+        a.optimizer.param_groups[0]['lr'] = lr
+        b.optimizer.param_groups[0]['lr'] = lr
+        g.replay()
+        b.train_batch((x, y))
+    torch.cuda.synchronize()
+    assert g.graph is graph_obj, 'no re-capture'
+    pa, pb = a.optimizer.flat_p, b.optimizer.flat_p
+    assert ((pa - pb).abs().max() / pb.abs().max()).item() < 1e-6
+    step_a = (pa - models[0].optimizer.flat_p).abs().max()
+    assert a.optimizer.step_count == b.optimizer.step_count == 4
