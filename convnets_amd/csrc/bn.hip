@@ -342,11 +342,15 @@ __global__ __launch_bounds__(256) void bn_merge_final_kernel(const float* __rest
     if (c < C) {
         int s = s0 + wave;
         for (; s + 28 < s1; s += 32) {                 // eight independent records in flight per lane
+            // one 8- / 12-byte load per record (records are 4-byte aligned: the vector type says so)
+            typedef float RecA __attribute__((ext_vector_type(NV == 3 ? 3 : 2), aligned(4)));
             float v[8][NV];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; ++u) {
+                const RecA r = *(const RecA*)(partial + ((size_t)(s + 4 * u) * C + c) * NV);
 #pragma unroll
-                for (int k = 0; k < NV; ++k) v[u][k] = partial[((size_t)(s + 4 * u) * C + c) * NV + k];
+                for (int k = 0; k < NV; ++k) v[u][k] = r[k];
+            }
             if constexpr (NV == 3) {
 #pragma unroll
                 for (int u = 0; u < 8; u += 2) chan_merge(v[u][0], v[u][1], v[u][2], v[u + 1][0], v[u + 1][1], v[u + 1][2]);
@@ -390,28 +394,36 @@ __global__ __launch_bounds__(256) void bn_merge_final_kernel(const float* __rest
         is_last = t == (unsigned)shares - 1u;
         if (is_last) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the slot's next launch
+            // (L1 invalidate of this CU; it completes asynchronously -- the loads below bypass L1 anyway (sc1) and the
+            // vmcnt(0) that retires them also covers it: nobody waits for it alone)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!is_last) return;
-    // the last block of this channel group: merge the shares in share order (wave w: shares w, w+4, ...), sc1 loads only,
-    // all of a wave's <= 32 shares requested at once (one round trip)
+    // the last block of this channel group: merge the shares in share order (wave w: shares w, w+4, ...).  One write-through-
+    // coherent (sc1) 8- / 12-byte load per share, all of a wave's <= 16 shares in flight together, retired by one vmcnt(0).
     a0 = a1 = a2 = 0.f;
     typename FIN::Pre q = {};
     if (wave == 0 && c < C) q = fin.pre(c);
-    if (c < C) {
-        float v[32][NV];
+    {
+        typedef __attribute__((ext_vector_type(3))) float f32x3;
+        typedef typename std::conditional<NV == 3, f32x3, f32x2>::type Rec;
+        Rec v[16];
+        const int cc = c < C ? c : C - 1;                                      // lanes past C read a valid record, use none
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int ss = wave + 4 * u, sc = ss < shares ? ss : shares - 1;       // unconditional loads (clamped address)
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-                v[u][k] = __hip_atomic_load(out + ((size_t)sc * C + c) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float* src = out + ((size_t)sc * C + cc) * NV;
+            if constexpr (NV == 3) asm volatile("global_load_dwordx3 %0, %1, off sc1" : "=v"(v[u]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[u]) : "v"(src) : "memory");
         }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                     :: "memory");
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const bool on = wave + 4 * u < shares;
             if constexpr (NV == 3) chan_merge(a0, a1, a2, on ? v[u][0] : 0.f, v[u][1], v[u][2]);      // n == 0: no-op
             else { a0 += on ? v[u][0] : 0.f; a1 += on ? v[u][1] : 0.f; }
@@ -1058,7 +1070,7 @@ template <class FIN>
 static int bn_merge_final(const float* partial, int slices, int C, int64_t M, float* scratch, int64_t scratch_floats,
                           const FIN& fin, hipStream_t s) {
     if (!cnk_sw().bn_fused_final || slices < 1024 || ceil_div(C, 64) > BNF_GROUPS) return 0;
-    const int shares = slices >= 2048 ? 128 : 64;         // <= 128: bn_merge_final_kernel reads up to 32 shares per wave, all at once
+    const int shares = slices >= 2048 ? 64 : 32;          // <= 64: bn_merge_final_kernel reads up to 16 shares per wave, all at once
     if ((int64_t)shares * C * FIN::NV > scratch_floats) return 0;
     const int slot = (int)(g_bnf_slot.fetch_add(1, std::memory_order_relaxed) % BNF_SLOTS);
     hipLaunchKernelGGL((bn_merge_final_kernel<FIN>), dim3(ceil_div(C, 64), shares), dim3(256), 0, s, partial, slices, C, M,
