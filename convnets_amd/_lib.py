@@ -170,7 +170,16 @@ class switches:
         return False
 
 
+_switch_epoch = [0]
+
+
+def switch_epoch():
+    """Moves whenever the library re-resolved its switches: host-side caches of descriptor-derived facts key on it."""
+    return _switch_epoch[0]
+
+
 def reload_switches():
+    _switch_epoch[0] += 1
     lib = load()
     fn = lib.cnk_debug_reload_switches
     fn.restype, fn.argtypes = None, []

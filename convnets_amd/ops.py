@@ -158,6 +158,48 @@ def join_side_streams(device=None):
             cur.wait_stream(st)
 
 
+# Per-shape facts the library derives from a descriptor (output size, partial-slice counts, workspace bytes) are pure
+# functions of the descriptor and of the library's switch table: they are asked for ONCE per (conv, input shape) and kept
+# (round 3: six ctypes round trips and a struct construction less per conv call on the host; a ResNet-152 eager step issues
+# ~1,900 launches from Python).  _lib.reload_switches() (tests, A/B tools) moves the epoch and drops them.
+class ConvPlan:
+    __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'accepts_mask')
+
+
+_conv_plans = {}
+_bn_sizes = {}
+
+
+def conv_plan(x_shape, weight_shape, stride, padding, dtype_code, groups, dilation):
+    key = (tuple(x_shape), tuple(weight_shape), tuple(stride), tuple(padding), dtype_code, groups, dilation, _lib.switch_epoch())
+    pl = _conv_plans.get(key)
+    if pl is None:
+        lib = _lib.load()
+        pl = ConvPlan()
+        pl.desc = d = make_desc(x_shape, weight_shape, stride, padding, dtype_code, groups, dilation)
+        Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
+        lib.cnk_conv2d_out_hw(ctypes.byref(d), ctypes.byref(Ho), ctypes.byref(Wo))
+        pl.Ho, pl.Wo = Ho.value, Wo.value
+        pl.fwd_slices = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d))
+        pl.dgrad_slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(d))
+        pl.wgrad_ws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), PASS_WGRAD)
+        pl.accepts_mask = bool(lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(d)))
+        if len(_conv_plans) > 4096:
+            _conv_plans.clear()
+        _conv_plans[key] = pl
+    return pl
+
+
+def bn_sizes(M, C, dtype_code):
+    """(workspace bytes, mask bytes) of a BN layer over [M][C]."""
+    key = (M, C, dtype_code)
+    v = _bn_sizes.get(key)
+    if v is None:
+        lib = _lib.load()
+        v = _bn_sizes[key] = (lib.cnk_bn_workspace_bytes(M, C), lib.cnk_bn_mask_bytes(M, C, dtype_code))
+    return v
+
+
 def make_desc(x_shape, weight_shape, stride, padding, dtype_code, groups=1, dilation=1):
     N, Cin, H, W = x_shape
     Cout, Cin_w, kh, kw = weight_shape
@@ -379,22 +421,21 @@ class Conv2dFn(torch.autograd.Function):
         x_needs_grad = x.requires_grad        # before any layout copy made here (forward runs under no_grad)
         x = _nhwc(x)
         w = weight if weight.is_contiguous() else weight.contiguous()
-        desc = make_desc(x.shape, w.shape, stride, padding, _dtype_code(x), groups, dilation)
+        plan = conv_plan(x.shape, w.shape, stride, padding, _dtype_code(x), groups, dilation)
+        desc = plan.desc
         need_dgrad = x_needs_grad
         w_fwd, w_dgrad = packed.get(w, desc, need_dgrad)
-        Ho, Wo = ctypes.c_int32(), ctypes.c_int32()
-        lib.cnk_conv2d_out_hw(ctypes.byref(desc), ctypes.byref(Ho), ctypes.byref(Wo))
-        y = torch.empty((desc.N, desc.Cout, Ho.value, Wo.value), dtype=x.dtype, device=x.device,
+        y = torch.empty((desc.N, desc.Cout, plan.Ho, plan.Wo), dtype=x.dtype, device=x.device,
                         memory_format=CL)
         partial = None
         if want_bn_partial:
-            slices = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+            slices = plan.fwd_slices
             if slices > 0:
                 partial = torch.empty((slices, desc.Cout, 3), dtype=torch.float32, device=x.device)
         check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial),
                                  None, 0, _stream()))
         ctx.save_for_backward(x, w)
-        ctx.desc, ctx.w_dgrad, ctx.has_bias = desc, w_dgrad, bias is not None
+        ctx.desc, ctx.w_dgrad, ctx.has_bias, ctx.plan = desc, w_dgrad, bias is not None, plan
         ctx.params = (weight, bias)
         ctx.link = link if x_needs_grad else None
         ctx.bn_rec = bn_rec if (x_needs_grad and BN_BWD_FUSE) else None
@@ -427,7 +468,7 @@ class Conv2dFn(torch.autograd.Function):
                 amask = None
                 if isinstance(addend, tuple):        # (block-output gradient, its packed ReLU mask)
                     addend, amask = addend
-                    if not lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(desc)):
+                    if not ctx.plan.accepts_mask:
                         addend, amask = masked_grad(addend, amask), None
                 if addend is not None:
                     addend = _nhwc(addend)
@@ -438,7 +479,7 @@ class Conv2dFn(torch.autograd.Function):
                 if rec is not None and (ctx.link is None or ctx.link.final) and rec.x is not None \
                         and rec.x.shape == x.shape and rec.x.dtype == x.dtype \
                         and (BN_BWD_FUSE_3X3 or desc.kh != 3 or desc.stride_h != 1):
-                    slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+                    slices = ctx.plan.dgrad_slices
                     if slices > 0:
                         partial = torch.empty((slices, desc.Cin, 2), dtype=torch.float32, device=x.device)
                         fuse = _lib.BnBwdFuse(rec.x.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr(),
@@ -465,7 +506,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw_buf = dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
                 db_buf = db = torch.empty((desc.Cout,), dtype=torch.float32, device=w.device) \
                     if ctx.has_bias else None
-            nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(desc), PASS_WGRAD)
+            nws = ctx.plan.wgrad_ws
 
             def run_wgrad(share=1.0):
                 ws = workspace(nws, x.device)
@@ -517,7 +558,8 @@ class BatchNormActFn(torch.autograd.Function):
         y = torch.empty_like(x, memory_format=CL)
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        ws_bytes, mask_bytes = bn_sizes(M, C, _dtype_code(x))
+        ws = workspace(ws_bytes, x.device)
         if partial is not None and partial.numel() == 0:
             partial = None
         nsl = 0 if partial is None else partial.shape[0]
@@ -525,7 +567,7 @@ class BatchNormActFn(torch.autograd.Function):
         # packed bit mask (1/16 of y's bytes) for the backward instead of re-reading y twice
         mask = None
         if relu and residual is not None and x_needs_grad:
-            mask = torch.empty(lib.cnk_bn_mask_bytes(M, C, _dtype_code(x)), dtype=torch.uint8, device=x.device)
+            mask = torch.empty(mask_bytes, dtype=torch.uint8, device=x.device)
         check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mask),
                                    _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
                                    M, C, eps, momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(),
@@ -586,7 +628,7 @@ class BatchNormActFn(torch.autograd.Function):
         else:
             dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        ws = workspace(bn_sizes(M, C, _dtype_code(x))[0], x.device)
         check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(mask), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
                              _p(dx), _p(dres_out), _p(dg_buf), _p(db_buf), int(direct), None, 0, M, C,
                              int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
@@ -615,7 +657,7 @@ class BatchNormActFn(torch.autograd.Function):
         else:
             dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
+        ws = workspace(bn_sizes(M, C, _dtype_code(x))[0], x.device)
         check(lib.cnk_bn_bwd(_p(dy), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
                              _p(dx), None, _p(dg_buf), _p(db_buf), int(direct), _p(ext_partial),
                              ext_partial.shape[0], M, C, int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(),
