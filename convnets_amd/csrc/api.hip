@@ -109,6 +109,7 @@ static CnkSwitches read_switches() {
     w.pp3x3 = env("CNK_PP3X3", 1);
     w.pp_cfg = env("CNK_PP_CFG", -1);
     w.pp_full = env("CNK_PP_FULL", -1);
+    w.pp_ws = env("CNK_PP_WS", 1);
     w.gemm1x1 = env("CNK_GEMM1X1", 1);
     w.igemm_halo = env("CNK_IGEMM_HALO", 1);
     w.igemm_halo_pf = env("CNK_IGEMM_HALO_PF", -1);

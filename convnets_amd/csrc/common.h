@@ -46,6 +46,7 @@ struct CnkSwitches {
     int pp3x3;                 // CNK_PP3X3 (1): ping-pong 3x3 core on / off
     int pp_cfg;                // CNK_PP_CFG (-1): force configuration 0..3 of conv_pp.hip where it fits
     int pp_full;               // CNK_PP_FULL (-1): 1 / 0 force the fused data gradients onto / off the ping-pong core
+    int pp_ws;                 // CNK_PP_WS (1): the weight-stationary 64 -> 64 channel 3x3 kernel of conv_pp.hip on / off
     int gemm1x1;               // CNK_GEMM1X1 (1): 0 off, 1 by rule, 2 / 4 force that tile
     int igemm_halo;            // CNK_IGEMM_HALO (1)
     int igemm_halo_pf;         // CNK_IGEMM_HALO_PF (-1): 0 / 1 force the plain / weight-prefetching halo kernel
@@ -66,6 +67,7 @@ enum {
     CNK_CNT_HALO = 4, CNK_CNT_HALO_PF = 5, CNK_CNT_GATHER = 6, CNK_CNT_G1_2 = 7, CNK_CNT_G1_4 = 8,
     CNK_CNT_PP_FULL = 9,                                                          // ping-pong launches with the FULL epilogue
     CNK_CNT_BN_FUSED_FINAL = 10, CNK_CNT_BN_FINAL_LAUNCH = 11,
+    CNK_CNT_PP_WS = 12,                                                           // weight-stationary 64 -> 64 launches
     CNK_CNT_MAX = 32
 };
 void cnk_count(int id);

@@ -38,6 +38,12 @@
 
 #include "common.h"
 
+#ifndef WS_SIDE_Q
+#define WS_SIDE_Q 8   // K step of a tile's second job at which the full epilogue's side operands are requested
+#endif
+#ifndef WS_ABL
+#define WS_ABL 0      // debug builds only (ABL_MACRO=WS_ABL tools/ablate_pp.sh): ws3x3_kernel without 1 patch DMA, 4 LDS reads, 8 MFMA, 16 epilogue
+#endif
 #ifndef PP_ABL
 #define PP_ABL 0      // debug builds only (tools/ablate_pp.sh): 1 no patch DMA, 2 no weight DMA, 4 no LDS reads, 8 no MFMA
 #endif
@@ -141,15 +147,15 @@ template <class CFG> __device__ __forceinline__ uint32_t pp_frag_addr(uint32_t b
 
 // Source pointer and LDS destination of one 1-KiB piece of chunk cn of the tile whose patch starts at padded index
 // pbase.  Branch-free 32-bit arithmetic (the tensor is < 2 GiB, checked on the host) so that it can issue between MFMAs.
-template <class CFG> __device__ __forceinline__ void pp_patch_piece_addr(const PPParams& p, const PPState<CFG>& st, int piece, int pbase, int cn, int pbuf, bool live,
+template <class CFG, class ST> __device__ __forceinline__ void pp_patch_piece_addr(const PPParams& p, const ST& st, int piece, int pbase, int cn, int pbuf, bool live,
                                                                         const unsigned char*& g, uint32_t& dst) {
     const int row = piece * CFG::RPP + st.lane / CFG::CPR;
     const uint32_t q = (uint32_t)(pbase + row);
     const uint32_t img = fd_div(q, p.fd_ip), rem = q - img * p.fd_ip.d;
     const uint32_t r = fd_div(rem, p.fd_p), cc = rem - r * p.fd_p.d;
     const int ch = (st.lane % CFG::CPR) ^ ((row >> (4 - CFG::SWS)) & (CFG::CPR - 1));
-    const bool use = live && piece < p.npg;
-    const bool ok = use && r >= 1 && cc >= 1 && img < (uint32_t)p.N;
+    const bool use = live & (piece < p.npg);
+    const bool ok = use & (r >= 1) & (cc >= 1) & (img < (uint32_t)p.N);
     const uint32_t pix = (img * p.H + (r - 1)) * p.W + (cc - 1);
     const uint32_t off = (pix * p.C + cn * CFG::KC + ch * 8) * 2;
     const unsigned char* gz = (const unsigned char*)pp_zero16;
@@ -244,7 +250,7 @@ template <class CFG, int T, bool FIRST = false> __device__ __forceinline__ void 
     uint32_t pdst = 0;
     constexpr bool PATCH = T <= 6 && !(PP_ABL & 1);
     __builtin_amdgcn_s_setprio(1);
-    if (PATCH) pp_patch_piece_addr<CFG>(p, st, T * 8 + st.wave, st.pbase_n, st.cn, st.pb ^ 1, st.has_next != 0, pg, pdst);
+    if (PATCH) pp_patch_piece_addr<CFG, PPState<CFG>>(p, st, T * 8 + st.wave, st.pbase_n, st.cn, st.pb ^ 1, st.has_next != 0, pg, pdst);
     if (T < 8) {
         const uint32_t pbuf = st.lds_patch + st.pb * st.npgb;
 #pragma unroll
@@ -308,6 +314,94 @@ template <int N> __device__ __forceinline__ void pp_wait_side(u32x4& a, u32x4& x
 
 enum { PP_EPI_PLAIN = 0, PP_EPI_STATS = 1, PP_EPI_FULL = 2 };
 
+// Side operands of one 64-row x 32-channel block pair of the full epilogue, and the per-lane BN coefficients of a column block.
+// The ping-pong core fetches them inside the epilogue; the weight-stationary kernel, whose epilogue nothing covers, issues the
+// loads a whole job early (pp_side_issue at the start of the tile's last job) and keeps the coefficients for the launch.
+struct PPSide {
+    u32x4 av[4], xv[4];
+    unsigned am[4], km[4];
+};
+struct PPCoef {
+    float bmu[8], bsc[8], bsf[8], is_fin;
+};
+
+// rows of the four passes of row-block pair ib of this wave (-1: past the end)
+template <class CFG, class ST> __device__ __forceinline__ void pp_side_rows(const PPParams& p, const ST& st, int ib, int (&ms)[4]) {
+    const int crow = st.lane >> 2;
+    const int R0 = st.tile_m * CFG::BM + st.wm * CFG::WROWS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = R0 + (ib * 2 + (k >> 1)) * 32 + (k & 1) * 16 + crow;
+        ms[k] = m < p.M ? m : -1;
+    }
+}
+
+// the 16 side-operand loads of column block j, row-block pair ib (an absent operand reads the zero block)
+template <class CFG, class ST> __device__ __forceinline__ void pp_side_issue(const PPParams& p, const ST& st, int j, int ib, PPSide& sd) {
+    const int cc = st.lane & 3;
+    const int cb = st.tile_n * CFG::BN + st.wn * (CFG::NJ * 32) + j * 32;
+    const bool bnf = p.bnf_x != nullptr, has_add = p.addend != nullptr;
+    int ms[4];
+    pp_side_rows<CFG, ST>(p, st, ib, ms);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t goff = ((size_t)(ms[k] < 0 ? 0 : ms[k]) * p.Nout + cb) * 2 + cc * 16;
+        const unsigned char* z = (const unsigned char*)pp_zero16;
+        const bool on = ms[k] >= 0;
+        pp_load16(sd.av[k], on && has_add ? (const unsigned char*)p.addend + goff : z);
+        pp_load1(sd.am[k], on && has_add && p.addend_mask ? p.addend_mask + (goff >> 4) : z);
+        pp_load16(sd.xv[k], on && bnf ? (const unsigned char*)p.bnf_x + goff : z);
+        pp_load1(sd.km[k], on && bnf && p.bnf_relu && p.bnf_mask ? p.bnf_mask + (goff >> 4) : z);
+    }
+}
+
+// the same coefficients as a per-channel table [mean | scale | shift | invstd][Nout] (thread ch < Nout writes channel ch)
+__device__ __forceinline__ void pp_coef_table(const PPParams& p, int ch, float* tab) {
+    const bool bnf = p.bnf_x != nullptr;
+    const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
+    float mu = 0.f, sc = 0.f, sf = 0.f, is = 0.f;
+    if (bnf) {
+        mu = p.bnf_mean[ch];
+        is = p.bnf_invstd[ch];
+        if (bnf_remask) {
+            sc = p.bnf_gamma[ch] * is;
+            sf = p.bnf_beta[ch] - mu * sc;
+        }
+    }
+    tab[ch] = mu; tab[p.Nout + ch] = sc; tab[2 * p.Nout + ch] = sf; tab[3 * p.Nout + ch] = is;
+}
+
+// BN coefficients of the 8 channels cb + (lane & 3) * 8.. this lane masks / sums, and invstd of the channel it finalises
+__device__ __forceinline__ void pp_coef_load(const PPParams& p, int cb, int lane, PPCoef& cf) {
+    const bool bnf = p.bnf_x != nullptr;
+    const bool bnf_remask = bnf && p.bnf_relu && !p.bnf_mask;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cf.bmu[e] = cf.bsc[e] = cf.bsf[e] = 0.f;
+    cf.is_fin = 0.f;
+    if (bnf) {
+        // unconditional, back-to-back loads (absent gamma / beta read the mean array): per-element "load or zero"
+        // selects made hipcc branch around each load and wait for it alone (see igemm_epilogue)
+        const float* gp = bnf_remask ? p.bnf_gamma : p.bnf_mean;
+        const float* bp = bnf_remask ? p.bnf_beta : p.bnf_mean;
+        const int ch0 = cb + (lane & 3) * 8;
+        float mu[8], gm[8], is[8], bt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = p.bnf_mean[ch0 + e]; gm[e] = gp[ch0 + e]; is[e] = p.bnf_invstd[ch0 + e]; bt[e] = bp[ch0 + e]; }
+        // invstd of the channel this lane finalises: fetched HERE -- a load in front of the partial store would
+        // be waited for with vmcnt(0), i.e. behind every row store of the column block (the counter retires in order)
+        cf.is_fin = p.bnf_invstd[cb + (lane & 31)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = gm[e] * is[e];
+            cf.bmu[e] = mu[e];
+            cf.bsc[e] = bnf_remask ? sc : 0.f;
+            cf.bsf[e] = bnf_remask ? bt[e] - mu[e] * sc : 0.f;
+        }
+    }
+    // the coefficient loads above are hipcc's own (waited for by hipcc, ahead of every asm operation below)
+    asm volatile("" : "+v"(cf.bmu[0]), "+v"(cf.bsc[0]), "+v"(cf.bsf[0]), "+v"(cf.is_fin));
+}
+
 // Per-wave epilogue of tile (tile_m, tile_n): see the header comment.  MODE: PLAIN = rounded rows only; STATS = + BN
 // statistics partials; FULL = bias / ReLU / gradient addend (+mask) / fused BN backward / statistics, all run-time.
 // The number of vector-memory operations per wave is static: CFG::EPI_STORES row stores, + NJ partial stores in STATS
@@ -315,7 +409,9 @@ enum { PP_EPI_PLAIN = 0, PP_EPI_STATS = 1, PP_EPI_FULL = 2 };
 // FULL issues the 16 side-operand loads of two row blocks of a column block (4 row passes x {addend, its mask, BN
 // input, its mask}; an absent operand reads the zero block) BEFORE their first store: vmcnt retires in order, so a
 // load waited for behind a store would wait for that store's round trip too.
-template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const PPParams& p, PPState<CFG>& st, unsigned char* smem_epi) {
+template <class CFG, int MODE, class ST = PPState<CFG>, bool WAIT0 = true, bool PRE = false>
+__device__ __forceinline__ void pp_epilogue(const PPParams& p, ST& st, unsigned char* smem_epi, PPSide* pre_side = nullptr, const float* coef_tab = nullptr) {
+    static_assert(!PRE || (CFG::NJ == 1 && CFG::MI == 2), "preloaded side operands: one column block, one row-block pair");
     constexpr int MI = CFG::MI, NJ = CFG::NJ;
     unsigned char* stg = smem_epi + st.wave * PP_EPI;
     const int lane = st.lane, l31 = st.l31, lh = st.lh;
@@ -329,62 +425,34 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
     const bool want_sums = MODE == PP_EPI_STATS || (MODE == PP_EPI_FULL && (p.stats || bnf));
     // Every LDS-DMA of the K loop (the next tile's tap-1 weights, issued one phase ago, are the youngest) is retired HERE,
     // before the first store of the epilogue: the K loop's counted waits must never have to tell loads from stores, because
-    // vmcnt does not retire them in one order (see the side-operand waits below).
-    PP_WAIT_VM(0);
+    // vmcnt does not retire them in one order (see the side-operand waits below).  (WAIT0 = false: the streaming kernel
+    // below, whose one counted wait per job names loads issued after it only.)
+    if (WAIT0) PP_WAIT_VM(0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int cb = C0 + j * 32;                                  // first channel of this column block
         __builtin_amdgcn_sched_barrier(0);                           // keep the column blocks apart (register pressure)
-        float s8[8], q8[8], bmu[8], bsc[8], bsf[8], is_fin = 0.f;
+        float s8[8], q8[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = bmu[e] = bsc[e] = bsf[e] = 0.f;
-        if (MODE == PP_EPI_FULL) {
-            if (bnf) {
-                // unconditional, back-to-back loads (absent gamma / beta read the mean array): per-element "load or zero"
-                // selects made hipcc branch around each load and wait for it alone (see igemm_epilogue)
-                const float* gp = bnf_remask ? p.bnf_gamma : p.bnf_mean;
-                const float* bp = bnf_remask ? p.bnf_beta : p.bnf_mean;
-                const int ch0 = cb + cc * 8;
-                float mu[8], gm[8], is[8], bt[8];
+        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+        PPCoef cf;
+        if (MODE == PP_EPI_FULL && !PRE) pp_coef_load(p, cb, lane, cf);
+        if (MODE == PP_EPI_FULL && PRE) {
+            // per-channel table in LDS, written once per launch (pp_coef_table): [mean | scale | shift | invstd][Nout]
+            const int ch0 = cb + cc * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { mu[e] = p.bnf_mean[ch0 + e]; gm[e] = gp[ch0 + e]; is[e] = p.bnf_invstd[ch0 + e]; bt[e] = bp[ch0 + e]; }
-                // invstd of the channel this lane finalises below: fetched HERE -- a load in front of the partial store would
-                // be waited for with vmcnt(0), i.e. behind every row store of the column block (the counter retires in order)
-                is_fin = p.bnf_invstd[cb + (lane & 31)];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float sc = gm[e] * is[e];
-                    bmu[e] = mu[e];
-                    bsc[e] = bnf_remask ? sc : 0.f;
-                    bsf[e] = bnf_remask ? bt[e] - mu[e] * sc : 0.f;
-                }
-            }
-            // the coefficient loads above are hipcc's own (waited for by hipcc, ahead of every asm operation below)
-            asm volatile("" : "+v"(bmu[0]), "+v"(bsc[0]), "+v"(bsf[0]), "+v"(is_fin));
+            for (int e = 0; e < 8; ++e) { cf.bmu[e] = coef_tab[ch0 + e]; cf.bsc[e] = coef_tab[p.Nout + ch0 + e]; cf.bsf[e] = coef_tab[2 * p.Nout + ch0 + e]; }
+            cf.is_fin = coef_tab[3 * p.Nout + cb + (lane & 31)];
         }
+        const float is_fin = MODE == PP_EPI_FULL ? cf.is_fin : 0.f;
 #pragma unroll
         for (int ib = 0; ib < MI / 2; ++ib) {
             __builtin_amdgcn_sched_barrier(0);
-            u32x4 av[4], xv[4];
-            unsigned am[4], km[4];
+            PPSide sd_here;
+            PPSide& sd = (MODE == PP_EPI_FULL && PRE) ? *pre_side : sd_here;
             int ms[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int m = R0 + (ib * 2 + (k >> 1)) * 32 + (k & 1) * 16 + crow;
-                ms[k] = m < p.M ? m : -1;
-            }
-            if (MODE == PP_EPI_FULL) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const size_t goff = ((size_t)(ms[k] < 0 ? 0 : ms[k]) * p.Nout + cb) * 2 + cc * 16;
-                    const unsigned char* z = (const unsigned char*)pp_zero16;
-                    const bool on = ms[k] >= 0;
-                    pp_load16(av[k], on && has_add ? (const unsigned char*)p.addend + goff : z);
-                    pp_load1(am[k], on && has_add && p.addend_mask ? p.addend_mask + (goff >> 4) : z);
-                    pp_load16(xv[k], on && bnf ? (const unsigned char*)p.bnf_x + goff : z);
-                    pp_load1(km[k], on && bnf && p.bnf_relu && p.bnf_mask ? p.bnf_mask + (goff >> 4) : z);
-                }
-            }
+            pp_side_rows<CFG, ST>(p, st, ib, ms);
+            if (MODE == PP_EPI_FULL && !PRE) pp_side_issue<CFG, ST>(p, st, j, ib, sd);
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
                 const int i = ib * 2 + i2;
@@ -421,17 +489,17 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
                         // be acknowledged before an older load has returned (round 3: crediting them -- vmcnt(9 / 6 / 3) --
                         // let a wait pass with one of its own loads still in flight as soon as the chip was busy enough
                         // for loads to be slower than store acks; 7 of 196 tiles wrong at batch 128, none at batch 16)
-                        if (k == 0) pp_wait_side<12>(av[0], xv[0], am[0], km[0]);
-                        else if (k == 1) pp_wait_side<8>(av[1], xv[1], am[1], km[1]);
-                        else if (k == 2) pp_wait_side<4>(av[2], xv[2], am[2], km[2]);
-                        else pp_wait_side<0>(av[3], xv[3], am[3], km[3]);
+                        if (k == 0) pp_wait_side<12>(sd.av[0], sd.xv[0], sd.am[0], sd.km[0]);
+                        else if (k == 1) pp_wait_side<8>(sd.av[1], sd.xv[1], sd.am[1], sd.km[1]);
+                        else if (k == 2) pp_wait_side<4>(sd.av[2], sd.xv[2], sd.am[2], sd.km[2]);
+                        else pp_wait_side<0>(sd.av[3], sd.xv[3], sd.am[3], sd.km[3]);
                     }
                     if (m >= 0) {
                         if (MODE == PP_EPI_FULL) {
-                            const bf16x8 a8 = __builtin_bit_cast(bf16x8, av[k]);
-                            const bf16x8 x8 = __builtin_bit_cast(bf16x8, xv[k]);
+                            const bf16x8 a8 = __builtin_bit_cast(bf16x8, sd.av[k]);
+                            const bf16x8 x8 = __builtin_bit_cast(bf16x8, sd.xv[k]);
                             if (has_add) {
-                                const unsigned amk = p.addend_mask ? am[k] : 0xFFu;
+                                const unsigned amk = p.addend_mask ? sd.am[k] : 0xFFu;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (((amk >> e) & 1u) ? (float)a8[e] : 0.f));
                                 if (p.relu) {
@@ -440,18 +508,18 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
                                 }
                             }
                             if (bnf) {
-                                unsigned keep = (p.bnf_relu && p.bnf_mask) ? km[k] : 0xFFu;
+                                unsigned keep = (p.bnf_relu && p.bnf_mask) ? sd.km[k] : 0xFFu;
                                 if (bnf_remask) {
                                     keep = 0;
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) keep |= ((float)x8[e] * bsc[e] + bsf[e] > 0.f ? 1u : 0u) << e;
+                                    for (int e = 0; e < 8; ++e) keep |= ((float)x8[e] * cf.bsc[e] + cf.bsf[e] > 0.f ? 1u : 0u) << e;
                                 }
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
                                     const float dv = ((keep >> e) & 1u) ? (float)v[e] : 0.f;
                                     v[e] = (bf16)dv;
                                     s8[e] += dv;
-                                    q8[e] += dv * ((float)x8[e] - bmu[e]);
+                                    q8[e] += dv * ((float)x8[e] - cf.bmu[e]);
                                 }
                             }
                         }
@@ -475,20 +543,34 @@ template <class CFG, int MODE> __device__ __forceinline__ void pp_epilogue(const
             float* red = (float*)stg;                                   // [16][32]
             float S = 0.f, Q = 0.f;
             const int chn = lane & 31, half = lane >> 5;
+#if !(WS_ABL & 64)
+            // column ^ (row & 7): the 8 rows of a 32-lane half land on 8 different banks per (cc, e) instead of one
+            const int wbase = crow * 32 + ((cc * 8) | (crow & 7));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[crow * 32 + cc * 8 + e] = s8[e];
+            for (int e = 0; e < 8; ++e) red[wbase ^ e] = s8[e];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) S += red[(half * 8 + r) * 32 + chn];
+            for (int r = 0; r < 8; ++r) S += red[(half * 8 + r) * 32 + (chn ^ r)];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[crow * 32 + cc * 8 + e] = q8[e];
+            for (int e = 0; e < 8; ++e) red[wbase ^ e] = q8[e];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) Q += red[(half * 8 + r) * 32 + chn];
+            for (int r = 0; r < 8; ++r) Q += red[(half * 8 + r) * 32 + (chn ^ r)];
             S += __shfl_xor(S, 32, 64);
             Q += __shfl_xor(Q, 32, 64);
+#else
+            (void)red; (void)half;
+#endif
+#if (WS_ABL & 64)
+            S = s8[0] + s8[1] + s8[2] + s8[3] + s8[4] + s8[5] + s8[6] + s8[7];
+            Q = q8[0] + q8[1] + q8[2] + q8[3] + q8[4] + q8[5] + q8[6] + q8[7];
+#endif
             const int ch = cb + chn;
             const int nvalid = min(CFG::WROWS, p.M - R0);
             const int slice = st.tile_m * CFG::GM + st.wm;
+#if (WS_ABL & 32)
+            if (lane < 32 && nvalid > 0 && p.M < 0) {
+#else
             if (lane < 32 && nvalid > 0) {
+#endif
                 if (bnf) {
                     pp_store8(p.bnf_partial + ((size_t)(p.bnf_tile0 + slice) * p.Nout + ch) * 2, S, Q * is_fin);
                 } else {
@@ -585,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void pp3x3_kernel(const PPParams p) {
     for (int piece = st.wave; piece < p.npg; piece += 8) {
         const unsigned char* g;
         uint32_t d;
-        pp_patch_piece_addr<CFG>(p, st, piece, pbase0, 0, 0, true, g, d);
+        pp_patch_piece_addr<CFG, PPState<CFG>>(p, st, piece, pbase0, 0, 0, true, g, d);
         dma16(g, d);
     }
     pp_issue_b<CFG>(p, st, st.wuni, 0, 0, true);
@@ -619,19 +701,268 @@ __global__ __launch_bounds__(512, 2) void pp3x3_kernel(const PPParams p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
+// ---- 64 -> 64 channels: weight-stationary streaming kernel (round 3) -----------------------------------------------------
+// The 3x3 layers of the first ResNet stage (src/resnet.py:171 at 56x56: 64 input and 64 output channels) have K = 576: the whole
+// filter bank is 72 KiB.  ONE 512-thread workgroup per CU (two waves per SIMD, 256 registers each); a wave owns 64 pixels x 32
+// output channels and keeps ITS half of the bank -- 36 fragments, 144 registers -- in registers for the whole launch: no weight
+// traffic through LDS at all (the halo kernel moves 72 KiB of weights through LDS per 128-pixel tile, more than the pixels).
+// The layer is HBM-bound on paper (floor ~41 us forward at 5 TB/s, 24 us of MFMA time at the dense peak).
+// A job = (256-pixel tile, 32-channel chunk): its patch (<= 32 KiB in padded coordinates, as above) sits in one of THREE
+// buffers, filled by LDS-DMA two jobs ahead; a job is 36 MFMAs per wave with no barrier inside, one s_barrier between jobs.
+// Every wave issues exactly PPW patch pieces per job (dummies into the dump block), so the one counted wait -- vmcnt(PPW) at
+// the END of a job's MFMAs, BEFORE any store of an epilogue: it counts loads only, see pp_epilogue -- retires the next job's
+// patch and leaves the one after it in flight.  The source offsets of a tile's pieces are computed once per tile (two
+// fast divisions per piece), between the MFMAs of the previous tile.  Per-wave epilogue shared with the ping-pong core
+// (pp_epilogue: plain / BN statistics / full data-gradient epilogue); the second wave of a SIMD covers it, nothing else does.
+struct WSCfg {
+    static constexpr int MI = 2, NJ = 1, GM = 4, GN = 2, KC = 32;
+    static constexpr int BM = GM * MI * 32, BN = 64;
+    static constexpr int LRB = 6, CPR = 4, RPP = 16, SWS = 2, SWM = (CPR - 1) << 4;      // 64-byte patch rows
+    static constexpr int WROWS = MI * 32;
+    static constexpr int PPW = 4;                          // patch pieces per wave and job (8 waves: <= 32 KiB)
+    static constexpr int NBUF = 3;
+    // of the 18 (chunk, tap) weight groups the LAST WL live in LDS instead of registers: the epilogues need the registers
+    // (the full one ~100 of them; with everything in registers hipcc spilled fragments to scratch and re-read them inside
+    // the loop, behind vmcnt waits that also retired the patch pieces in flight)
+    static constexpr int WL_FULL = 13, WL_STATS = 6, WL_MAX = 13;
+};
+
+struct WSState {
+    f32x16 acc[2][1];
+    int prow[2];
+    const unsigned char* src;
+    uint32_t lds_patch, lds_dump, npgb;
+    int wave, lane, l31, lh, wm, wn;
+    int tile_m, tile_n;
+};
+
+template <int OFF> __device__ __forceinline__ void ws_no_read128(u32x4& d, uint32_t addr) { asm volatile("" : "+v"(d) : "v"(addr)); }
+// s_waitcnt lgkmcnt(n) naming the fragments it retires (n: the reads issued after them; a constant once the K loop is unrolled)
+#define WS_WAIT_CASES(OPS)                                                                                                 \
+    switch (n) {                                                                                                           \
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : OPS : : "memory"); break;                                            \
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : OPS : : "memory"); break;                                            \
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : OPS : : "memory"); break;                                            \
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : OPS : : "memory"); break;                                            \
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" : OPS : : "memory"); break;                                            \
+        default: asm volatile("s_waitcnt lgkmcnt(6)" : OPS : : "memory"); break;                                           \
+    }
+#define WS_OPS2 "+v"(a), "+v"(b)
+#define WS_OPS3 "+v"(a), "+v"(b), "+v"(c)
+__device__ __forceinline__ void ws_wait_frag(int n, u32x4& a, u32x4& b) { WS_WAIT_CASES(WS_OPS2) }
+__device__ __forceinline__ void ws_wait_frag3(int n, u32x4& a, u32x4& b, u32x4& c) { WS_WAIT_CASES(WS_OPS3) }
+#undef WS_OPS2
+#undef WS_OPS3
+#undef WS_WAIT_CASES
+
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ws3x3_kernel(const PPParams p) {
+    typedef WSCfg CFG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* smem = smem_raw;
+    WSState st;
+    const int tid = threadIdx.x;
+    st.lane = tid & 63;
+    st.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    st.l31 = st.lane & 31;
+    st.lh = st.lane >> 5;
+    st.wm = st.wave & 3;
+    st.wn = st.wave >> 2;
+    st.tile_n = 0;
+    st.src = (const unsigned char*)p.src;
+    st.npgb = (uint32_t)p.npg * 1024u;
+    const uint32_t lds_raw = (uint32_t)(uintptr_t)(lds_u8*)smem;
+    st.lds_patch = (lds_raw + 127u) & ~127u;
+    smem += st.lds_patch - lds_raw;
+    const uint32_t lds_epi = st.lds_patch + CFG::NBUF * st.npgb;
+    st.lds_dump = lds_epi + 8 * PP_EPI;
+    unsigned char* smem_epi = smem + CFG::NBUF * st.npgb;
+    // weight groups kept in LDS (fragment-major, lane * 16 B: conflict-free), read beside the pixel fragments of their K steps
+    constexpr int WL = MODE == PP_EPI_FULL ? CFG::WL_FULL : CFG::WL_STATS;
+    constexpr int DEPTH = MODE == PP_EPI_FULL ? 1 : 2;                       // K steps the LDS reads run ahead of the MFMAs
+    const uint32_t lds_wl = st.lds_dump + 2048;                              // 1 KiB dump block, 1 KiB coefficient table
+    float* coef_tab = (float*)(smem_epi + 8 * PP_EPI + 1024);
+    if (MODE == PP_EPI_FULL && tid < 64) pp_coef_table(p, tid, coef_tab);
+
+    int L;
+    {
+        const int q = p.nwg >> 3, r = p.nwg & 7, xcd = blockIdx.x & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int k0 = (int)((long long)L * p.tiles_total / p.nwg), k1 = (int)((long long)(L + 1) * p.tiles_total / p.nwg);
+    if (k0 >= k1) return;
+
+    auto patch_base = [&](int tile) { return pp_index(p, tile * CFG::BM) - p.P - 1; };
+    // Source of this lane's 16 bytes of piece u * 8 + wave of tile `tile` (chunk 0; chunk 1 is 64 bytes further): byte offset
+    // into the tensor (< 2 GiB, checked on the host), or -1 for a padding row / a piece past the patch / a tile past the run
+    int poff[CFG::PPW];
+    auto piece_offset = [&](int tile, int u) {
+        const int piece = u * 8 + st.wave;
+        const int row = piece * CFG::RPP + st.lane / CFG::CPR;
+        const uint32_t q = (uint32_t)(patch_base(tile < k1 ? tile : k0) + row);
+        const uint32_t img = fd_div(q, p.fd_ip), rem = q - img * p.fd_ip.d;
+        const uint32_t r = fd_div(rem, p.fd_p), cc = rem - r * p.fd_p.d;
+        const int ch = (st.lane % CFG::CPR) ^ ((row >> (4 - CFG::SWS)) & (CFG::CPR - 1));
+        const bool ok = (tile < k1) & (piece < p.npg) & (r >= 1) & (cc >= 1) & (img < (uint32_t)p.N);
+        const uint32_t pix = (img * p.H + (r - 1)) * p.W + (cc - 1);
+        return ok ? (int)((pix * p.C + ch * 8) * 2) : -1;
+    };
+    // PPW pieces of chunk c of the tile whose offsets poff[] holds, into patch buffer `buf`
+    auto issue_patch = [&](int c, int buf) {
+#pragma unroll
+        for (int u = 0; u < CFG::PPW; ++u) {
+            const int piece = u * 8 + st.wave;
+            const unsigned char* g = poff[u] >= 0 ? st.src + (uint32_t)(poff[u] + c * (CFG::KC * 2)) : (const unsigned char*)pp_zero16;
+            dma16(g, piece < p.npg ? st.lds_patch + buf * st.npgb + piece * 1024 : st.lds_dump);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < CFG::PPW; ++u) poff[u] = piece_offset(k0, u);
+    issue_patch(0, 0);
+    issue_patch(1, 1);
+#pragma unroll
+    for (int u = 0; u < CFG::PPW; ++u) poff[u] = piece_offset(k0 + 1, u);
+
+    // this wave's half of the filter bank, straight into registers: fragment (chunk c, tap t, k step s) of lane (l31, lh) is the
+    // 8 channels c*32 + s*16 + lh*8.. of tap t of output channel wn*32 + l31 (image: [n][tap][C], as the core above reads it)
+    u32x4 wf[2][9][2];
+    {
+        const bf16* wpk = (const bf16*)p.wpk;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (c * 9 + t >= 18 - WL) {
+                        // fragment (c, t, s) of BOTH channel halves, placed by the eight waves in turn
+                        const int f = (c * 9 + t - (18 - WL)) * 2 + s;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (((f * 2 + h) & 7) == st.wave)
+                                *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(lds_wl + (f * 2 + h) * 1024 + st.lane * 16) =
+                                    *(const u32x4*)(wpk + (size_t)(((h * 32 + st.l31) * 9 + t) * 64 + c * 32 + s * 16 + st.lh * 8));
+                    } else {
+                        wf[c][t][s] = *(const u32x4*)(wpk + (size_t)(((st.wn * 32 + st.l31) * 9 + t) * 64 + c * 32 + s * 16 + st.lh * 8));
+                    }
+                }
+    }
+    __syncthreads();
+
+    auto set_tile = [&](int tile) {
+        st.tile_m = tile;
+        const int m0 = tile * CFG::BM;
+        const int pbase = patch_base(tile);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + st.wm * CFG::WROWS + i * 32 + st.l31;
+            m = m < p.M ? m : p.M - 1;
+            st.prow[i] = pp_index(p, m) - pbase;
+        }
+    };
+
+    // the filter bank is complete HERE: hipcc waits for a load at its first use, which would be inside the loop, where its
+    // count knows nothing of the patch pieces in flight (it would retire them with the weights, every job)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (c * 9 + t < 18 - WL) asm volatile("" : "+v"(wf[c][t][0]), "+v"(wf[c][t][1]));
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = p.toff[t];
+    // full epilogue: the BN coefficients as a table in LDS, written once per launch (above); the side operands of a tile (gradient addend,
+    // BN input, their masks: 16 loads per lane) are issued at the START of the tile's second job, a whole job ahead of the
+    // epilogue that consumes them -- nothing but the other wave of the SIMD would cover their round trip there
+    PPSide side;
+    PP_WAIT_VM(0);                                 // (prologue only) the first tile's two patches
+    int buf = 0;                                   // buffer of job j; job j+2 goes into the one job j-1 read
+    for (int tile = k0; tile < k1; ++tile) {
+        set_tile(tile);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.acc[i][0][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            // every wave has waited for its own pieces of this job's patch and has finished reading the previous job's buffer
+            __builtin_amdgcn_s_barrier();
+            const int nb = buf == 0 ? CFG::NBUF - 1 : buf - 1;
+#if !(WS_ABL & 1)
+            issue_patch(c, nb);                    // chunk c of tile + 1: two jobs ahead
+#else
+            (void)nb;
+#endif
+            const uint32_t pbuf = st.lds_patch + (uint32_t)buf * st.npgb;
+            // 18 K steps (tap t = q / 2, k step s = q & 1); the fragments of step q + DEPTH are read from LDS while step q's
+            // MFMAs run (two steps ahead where the registers allow: 56 vs 59 us for the K loops alone)
+            constexpr int NF = DEPTH + 1;
+            u32x4 fa[NF][2], fw[NF];
+#if (WS_ABL & 4)
+#pragma unroll
+            for (int i = 0; i < NF; ++i) fa[i][0] = fa[i][1] = fw[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, pbuf};
+#define ds_read128 ws_no_read128
+#endif
+            auto in_lds = [&](int q) { return c * 9 + (q >> 1) >= 18 - WL; };          // step q's weights come from LDS
+            auto nreads = [&](int q) { return q < 18 ? (in_lds(q) ? 3 : 2) : 0; };
+            auto read_step = [&](int q, u32x4 (&a)[2], u32x4& w) {
+                const int t1 = q >> 1, s1 = q & 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ds_read128<0>(a[i], pp_frag_addr<CFG>(pbuf, (uint32_t)(st.prow[i] + toff[t1]), st.lh) ^ (uint32_t)(s1 << 5));
+                if (in_lds(q)) ds_read128<0>(w, lds_wl + (uint32_t)((((c * 9 + t1 - (18 - WL)) * 2 + s1) * 2 + st.wn) * 1024 + st.lane * 16));
+            };
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) read_step(q, fa[q], fw[q]);
+#pragma unroll
+            for (int q = 0; q < 18; ++q) {
+                if (q + DEPTH < 18) read_step(q + DEPTH, fa[(q + DEPTH) % NF], fw[(q + DEPTH) % NF]);
+                const int left = nreads(q + 1) + (DEPTH > 1 ? nreads(q + 2) : 0);     // reads issued after step q's
+                if (in_lds(q)) ws_wait_frag3(left, fa[q % NF][0], fa[q % NF][1], fw[q % NF]);
+                else ws_wait_frag(left, fa[q % NF][0], fa[q % NF][1]);
+                if (MODE == PP_EPI_FULL && c == 1 && q == WS_SIDE_Q) pp_side_issue<CFG, WSState>(p, st, 0, 0, side);
+                // next tile's piece offsets, one piece per early K step of the second chunk: VALU work in the MFMAs' shadow
+                if (c == 1 && q >= 1 && q <= CFG::PPW) poff[q - 1] = piece_offset(tile + 2, q - 1);
+#if (WS_ABL & 8)
+                asm volatile("" ::"v"(in_lds(q) ? fw[q % NF] : wf[c][q >> 1][q & 1]), "v"(fa[q % NF][0]), "v"(fa[q % NF][1]));
+#else
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    st.acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, in_lds(q) ? fw[q % NF] : wf[c][q >> 1][q & 1]),
+                                                                            __builtin_bit_cast(bf16x8, fa[q % NF][i]), st.acc[i][0], 0, 0, 0);
+#endif
+            }
+#if (WS_ABL & 4)
+#undef ds_read128
+#endif
+            // the NEXT job's patch (issued a whole job ago) has landed; the one just issued (and the side operands behind it)
+            // stay in flight.  Before any store.
+            if (MODE == PP_EPI_FULL && c == 1) PP_WAIT_VM(CFG::PPW + 16);
+            else PP_WAIT_VM(CFG::PPW);
+            buf = buf == CFG::NBUF - 1 ? 0 : buf + 1;
+        }
+#if !(WS_ABL & 16)
+        pp_epilogue<CFG, MODE, WSState, false, MODE == PP_EPI_FULL>(p, st, smem_epi, &side, coef_tab);
+#else
+        if (st.acc[0][0][0] == 123.456f) pp_epilogue<CFG, PP_EPI_PLAIN, WSState, false>(p, st, smem_epi);
+#endif
+    }
+    PP_WAIT_VM(0);                                 // trailing dummy pieces must not outlive the workgroup's LDS
+}
+
 typedef PPCfg<2, 2, 4, 64> CfgA;      // 256 x 128, wave 64 x 64, 64-channel steps
 typedef PPCfg<2, 1, 4, 64> CfgA1;     // 256 x 64 (64 output channels)
 typedef PPCfg<4, 2, 4, 32> CfgB;      // 512 x 128, wave 128 x 64, 32-channel steps
 typedef PPCfg<4, 2, 2, 32> CfgC;      // 256 x 256, wave 128 x 64, 32-channel steps
 
 struct PPGeom {
-    int cfg;          // 0 A, 1 A1, 2 B, 3 C
+    int cfg;          // 0 A, 1 A1, 2 B, 3 C, 4 weight-stationary 64 -> 64
     int bm, bn, kc, wrows, bstage, rpp;
 };
-const PPGeom PP_GEOM[4] = {{0, CfgA::BM, CfgA::BN, CfgA::KC, CfgA::WROWS, CfgA::BSTAGE, CfgA::RPP},
+const PPGeom PP_GEOM[5] = {{0, CfgA::BM, CfgA::BN, CfgA::KC, CfgA::WROWS, CfgA::BSTAGE, CfgA::RPP},
                            {1, CfgA1::BM, CfgA1::BN, CfgA1::KC, CfgA1::WROWS, CfgA1::BSTAGE, CfgA1::RPP},
                            {2, CfgB::BM, CfgB::BN, CfgB::KC, CfgB::WROWS, CfgB::BSTAGE, CfgB::RPP},
-                           {3, CfgC::BM, CfgC::BN, CfgC::KC, CfgC::WROWS, CfgC::BSTAGE, CfgC::RPP}};
+                           {3, CfgC::BM, CfgC::BN, CfgC::KC, CfgC::WROWS, CfgC::BSTAGE, CfgC::RPP},
+                           {4, WSCfg::BM, WSCfg::BN, WSCfg::KC, WSCfg::WROWS, 0, WSCfg::RPP}};
 
 }  // namespace
 
@@ -647,6 +978,7 @@ static int pp_patch_rows(int H, int W, int bm) {
 static int pp_npg(int H, int W, const PPGeom& g) { return (pp_patch_rows(H, W, g.bm) + g.rpp - 1) / g.rpp; }
 
 static size_t pp_lds_bytes(int H, int W, const PPGeom& g) {
+    if (g.cfg == 4) return (size_t)WSCfg::NBUF * pp_npg(H, W, g) * 1024 + 8 * PP_EPI + 2048 + WSCfg::WL_MAX * 4096 + 128;
     return (size_t)2 * pp_npg(H, W, g) * 1024 + (size_t)3 * g.bstage + 8 * PP_EPI + 1024 + 128;
 }
 
@@ -666,6 +998,9 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
         return (M + g.bm - 1) / g.bm * (Nout / g.bn) >= 8;
     };
     if (forced >= 0 && forced < 4 && fits(forced) && !(dgrad && forced >= 2)) return forced;      // (bench / test runs only)
+    // 64 -> 64 channels: the weight-stationary kernel (filter bank in registers), forward and data gradient alike; its patch
+    // must fit the WSCfg::PPW pieces a wave issues per job
+    if (cnk_sw().pp_ws && forced < 0 && C == 64 && Nout == 64 && pp_npg(H, W, PP_GEOM[4]) <= 8 * WSCfg::PPW && fits(4)) return 4;
     // Rule in work per CU (one persistent workgroup per CU, 256 CUs): the biggest tile -- 256 x 256, then 512 x 128, both
     // with the cheaper 128 x 64 wave tile -- as long as its tiles cover at least 5/8 of the CUs; below that the 256 x 128
     // tile's finer grain fills the chip better (7x7 layers at batch 256: 98 big tiles, 141 vs 75 us).
@@ -740,8 +1075,22 @@ int pp3x3_launch(const PPArgs& a, hipStream_t s) {
     const size_t lds = pp_lds_bytes(a.H, a.W, g);
     const int mode = (a.bias || a.addend || a.bnf_x || a.relu) ? PP_EPI_FULL : (a.stats ? PP_EPI_STATS : PP_EPI_PLAIN);
     ProfScope kscope(CNK_KF_HALO, s, 2.0 * p.M * (double)a.Nout * a.C * 9, a.algo_bytes);
-    cnk_count(CNK_CNT_PP_A + c);
+    if (c < 4) cnk_count(CNK_CNT_PP_A + c);
     if (mode == PP_EPI_FULL) cnk_count(CNK_CNT_PP_FULL);
+    if (c == 4) {
+        cnk_count(CNK_CNT_PP_WS);
+#define WS_LAUNCH(MODEV)                                                                                                   \
+    do {                                                                                                                   \
+        CNK_LDS_OPTIN((ws3x3_kernel<MODEV>), 160 * 1024, "ws3x3");                                                         \
+        hipLaunchKernelGGL((ws3x3_kernel<MODEV>), dim3(p.nwg), dim3(512), lds, s, p);                                      \
+    } while (0)
+        if (mode == PP_EPI_FULL) WS_LAUNCH(PP_EPI_FULL);
+        else if (mode == PP_EPI_STATS) WS_LAUNCH(PP_EPI_STATS);
+        else WS_LAUNCH(PP_EPI_PLAIN);
+#undef WS_LAUNCH
+        CNK_CHECK_LAUNCH("ws3x3");
+        return 0;
+    }
     switch (c) {
         case 0: return pp_launch_cfg<CfgA>(p, mode, lds, s);
         case 1: return pp_launch_cfg<CfgA1>(p, mode, lds, s);

@@ -653,3 +653,99 @@ def test_graph_replay_follows_a_learning_rate_change_without_recapture():
     assert ((pa - pb).abs().max() / pb.abs().max()).item() < 1e-6
     step_a = (pa - models[0].optimizer.flat_p).abs().max()
     assert a.optimizer.step_count == b.optimizer.step_count == 4
+
+
+# ---- weight-stationary 64 -> 64 channel kernel (csrc/conv_pp.hip ws3x3_kernel; reference site src/resnet.py:171 at 56x56) --------
+CNT_PP_WS = 12
+WS_SHAPES = {
+    'n3_56': (3, 64, 56, 56),          # 37 tiles, ragged last one, one tile per workgroup
+    'n64_56': (64, 64, 56, 56),        # 784 tiles: three / four tiles per workgroup, the patch buffers rotate through all phases
+    'n40_28': (40, 64, 28, 28),        # tiles span image boundaries
+    'n50_9x13': (50, 64, 9, 13),       # odd, non-square image
+}
+
+
+@pytest.mark.parametrize('shape', list(WS_SHAPES))
+def test_weight_stationary_64_channel_kernel(shape):
+    """Forward (plain rows / BN statistics partials) and data gradient (plain / gradient addend + packed masks + fused BN
+    backward, mask bits and re-derived mask) of the 64 -> 64 channel 3x3 layers on the weight-stationary kernel, unforced
+    dispatch with a launch counter, against fp64 from the bf16-rounded operands, against the tensor the kernel itself wrote
+    (statistics and BN sums) and against the r01 halo kernel (other K order: two valid bf16 roundings, not the same bits)."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    N, C, H, W = WS_SHAPES[shape]
+    M = N * H * W
+    x, dy, w = _operands(WS_SHAPES[shape], 41)
+    g = torch.Generator().manual_seed(43)
+    xg, dyg = x.cuda().contiguous(memory_format=CL), dy.cuda().contiguous(memory_format=CL)
+    desc = ops.make_desc(xg.shape, w.shape, (1, 1), (1, 1), _lib.CNK_BF16)
+    wf, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bnx = (torch.randn(N, H, W, C, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    addend = torch.randn(N, H, W, C, generator=g).bfloat16().cuda()
+    amask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).cuda()
+    kmask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).cuda()
+    bmean, binv = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    bgam, bbeta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out = {}
+    for name, env in (('ws', dict(CNK_PP3X3=None, CNK_PP_CFG=None, CNK_PP_FULL=None, CNK_PP_WS=None)), ('halo', dict(CNK_PP3X3='0'))):
+        with _lib.switches(**env):
+            nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+            nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+            if name == 'ws':
+                assert nsl == (M + 63) // 64 and nb == (M + 63) // 64, 'the weight-stationary kernel does not take this shape'
+            part = torch.full((nsl, C, 3), float('nan'), device='cuda')
+            y, y2 = torch.empty_like(xg), torch.empty_like(xg)
+            dxp = torch.empty_like(dyg)
+            dxf = {}
+            c0 = cnt(CNT_PP_WS)
+            assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
+            assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(y2), None, None, 0, st) == 0, lib.cnk_last_error()
+            assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dxp), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+            for maskmode in ('bits', 'remask'):
+                bpart = torch.full((nb, C, 2), float('nan'), device='cuda')
+                fuse = _lib.BnBwdFuse(bnx.data_ptr(), bmean.data_ptr(), binv.data_ptr(), bgam.data_ptr(), bbeta.data_ptr(),
+                                      kmask.data_ptr() if maskmode == 'bits' else None, bpart.data_ptr(), 1)
+                d = torch.empty_like(dyg)
+                assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(d), P(addend), P(amask), ctypes.byref(fuse), None, 0, st) == 0, lib.cnk_last_error()
+                torch.cuda.synchronize()
+                assert torch.isfinite(bpart).all()
+                dxf[maskmode] = (d, bpart.double().sum(0).cpu())
+            torch.cuda.synchronize()
+            assert cnt(CNT_PP_WS) - c0 == (5 if name == 'ws' else 0), 'the weight-stationary kernel did not run' if name == 'ws' else 'switch ignored'
+            out[name] = (y, y2, part, dxp, dxf)
+    y, y2, part, dxp, dxf = out['ws']
+    yh, _, _, dxph, dxfh = out['halo']
+    # forward
+    ref = F.conv2d(x.double(), w.bfloat16().double(), padding=1)
+    assert torch.equal(y, y2)
+    assert rel_l2(host(y), ref.float().numpy()) < 4e-3
+    assert rel_l2(host(y), host(yh)) < 3e-3
+    tmean, tvar = _merge_stats(part, M)
+    yd = y.double()
+    assert ((tmean - yd.mean((0, 2, 3))).abs().max() / yd.abs().mean()).item() < 2e-6
+    assert ((tvar - yd.var((0, 2, 3), unbiased=False)).abs() / tvar).max().item() < 2e-5
+    # data gradient
+    shp = (N, H, W, C)
+    vplain, _, _ = _dgrad_reference(dy, w, None, None, None, None, None, None)
+    assert rel_l2(_nhwc(dxp).float().numpy(), vplain.float().numpy()) < 4e-3
+    assert rel_l2(host(dxp), host(dxph)) < 3e-3
+    abits = _unpack_bits(amask, shp)
+    for maskmode in ('bits', 'remask'):
+        if maskmode == 'bits':
+            keep = _unpack_bits(kmask, shp)
+        else:
+            sc = (bgam * binv).double().cpu()
+            sf = bbeta.double().cpu() - bmean.double().cpu() * sc
+            keep = ((bnx.double().cpu() * sc + sf) > 0).double()
+        v, s1, s2 = _dgrad_reference(dy, w, addend, abits, bnx, keep, bmean, binv)
+        d, got = dxf[maskmode]
+        assert rel_l2(_nhwc(d).float().numpy(), v.float().numpy()) < 4e-3
+        assert rel_l2(host(d), host(dxfh[maskmode][0])) < 3e-3
+        assert ((got[:, 0] - s1).abs().max() / s1.abs().max()).item() < 5e-3
+        assert ((got[:, 1] - s2).abs().max() / s2.abs().max()).item() < 5e-3
+        wrote = _nhwc(d)
+        assert ((got[:, 0] - wrote.sum((0, 1, 2))).abs().max() / wrote.abs().sum((0, 1, 2)).max()).item() < 1e-5
+        q = (wrote * (bnx.double().cpu() - bmean.double().cpu())).sum((0, 1, 2)) * binv.double().cpu()
+        assert ((got[:, 1] - q).abs().max() / q.abs().max()).item() < 1e-4

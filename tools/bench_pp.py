@@ -2,6 +2,7 @@
 several kernel variants INTERLEAVED in one process (cdna_hip_programming.md 5.4 rule 24):
     old   the r01 halo kernels (CNK_PP3X3=0)          auto  the ping-pong core, its own configuration choice
     0..3  the ping-pong core forced to configuration 0..3 where it fits (CNK_PP_CFG, conv_pp.hip pp_pick)
+    nows  "auto" with the weight-stationary 64 -> 64 kernel off (CNK_PP_WS=0)
 Prints per variant the median time per launch, TFLOP/s, a SHA-1 of the output bytes and the merged BN statistics.
     PP_VARIANTS=old,auto PP_SHAPES=0,1,2,3 python tools/bench_pp.py [N] [--check]
     (--check: also compare against a torch fp32 conv on the GPU)"""
@@ -30,6 +31,10 @@ def select(v):
     os.environ.pop('CNK_PP_CFG', None)
     os.environ['CNK_PP3X3'] = '0' if v == 'old' else '1'
     os.environ.pop('CNK_PP_FULL', None)
+    os.environ.pop('CNK_PP_WS', None)
+    if v == 'nows':                          # "auto" without the weight-stationary 64 -> 64 kernel
+        os.environ['CNK_PP_WS'] = '0'
+        v = 'auto'
     if v.endswith('f'):                      # "autof" / "0f": fused data gradients forced onto the ping-pong core
         os.environ['CNK_PP_FULL'] = '1'
         v = v[:-1]
