@@ -114,6 +114,7 @@ static CnkSwitches read_switches() {
     w.igemm_halo = env("CNK_IGEMM_HALO", 1);
     w.igemm_halo_pf = env("CNK_IGEMM_HALO_PF", -1);
     w.rowpatch_stats = env("CNK_ROWPATCH_STATS", 1);
+    w.rowpatch_wide = env("CNK_ROWPATCH_WIDE", 1);
     w.wgrad_big = env("CNK_WGRAD_BIG", 1);
     w.wgrad3 = env("CNK_WGRAD3", 1);
     w.wgrad_slots_pct = env("CNK_WGRAD_SLOTS_PCT", -1);

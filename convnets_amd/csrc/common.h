@@ -51,6 +51,7 @@ struct CnkSwitches {
     int igemm_halo;            // CNK_IGEMM_HALO (1)
     int igemm_halo_pf;         // CNK_IGEMM_HALO_PF (-1): 0 / 1 force the plain / weight-prefetching halo kernel
     int rowpatch_stats;        // CNK_ROWPATCH_STATS (1)
+    int rowpatch_wide;         // CNK_ROWPATCH_WIDE (1): first-conv forward items of 32 pixels x 64 channels (0: x 32 channels)
     int wgrad_big;             // CNK_WGRAD_BIG (1)
     int wgrad3;                // CNK_WGRAD3 (1)
     int wgrad3_slots_pct;      // CNK_WGRAD3_SLOTS_PCT (-1: as wgrad_slots_pct): the same for the all-taps 3x3 kernel

@@ -158,11 +158,16 @@ constexpr int RP_FWD_WAVES = 4;
 // scalar instructions (offA / offB below) and a lane spends one select and one add per step; the generic loop (NS == 0)
 // re-derives (kh, chunk) per lane and step -- ~25 vector instructions per MFMA, which made the kernel VALU-bound at a
 // quarter of its store-bandwidth floor.
-template <typename T, bool ALIGN4, bool STATS, int NS>
+// WIDE (round 3; NS > 0, 64 output channels): a work item is a 32-pixel chunk with BOTH channel halves -- every patch fragment
+// read (four ds_read_b32 on 12-byte lane strides, the K loop's cost) feeds two MFMAs instead of one, and a wave writes whole
+// 128-byte pixel rows instead of 64-byte halves.  The wave keeps both halves' weight fragments (2 NS x 4 VGPRs).
+template <typename T, bool ALIGN4, bool STATS, int NS, bool WIDE = false>
 __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const RowPatchParams p) {
     constexpr int CH = RpCfg<T>::CH, ES = (int)sizeof(T), NW = RP_FWD_WAVES;
-    constexpr int SS = 32 * ES + 16;                             // staged pixel row: this wave's 32 channels (+ pad)
-    constexpr int CPRO = 32 * ES / 16;                           // 16-B chunks per staged pixel
+    constexpr int NH = WIDE ? 2 : 1;                             // channel halves per wave
+    constexpr int SS = 32 * NH * ES + 16;                        // staged pixel row: this wave's 32 NH channels (+ pad)
+    constexpr int CPRO = 32 * NH * ES / 16;                      // 16-B chunks per staged pixel
+    static_assert(!WIDE || NS > 0, "the wide item needs the unrolled K loop");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int WS = p.Kp * ES + 16;                               // weight row stride (odd # of 16-B slots)
     const int RING = p.KH + p.s;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
     T* ring = (T*)(Wl + 64 * WS);                                // [RING + 1][PWE], last row all zero
     unsigned char* stage = (unsigned char*)(ring + (size_t)(RING + 1) * p.PWE);   // [NW waves][32][SS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int half = wave & 1;                                   // channels half*32 .. half*32+31
+    const int half = WIDE ? 0 : (wave & 1);                      // channels half*32 .. half*32 + 32 NH - 1
     const T* x = (const T*)p.x;
     const T* wpk = (const T*)p.wpk;
     {
@@ -189,28 +194,33 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
     const int cps = p.Rp / CH;                                   // chunks per kh run
     // NS > 0: this wave's weight fragments (its channel half, all k-steps) stay in registers for the whole workgroup --
     // with them in LDS every MFMA needed 2 KiB of LDS reads and the kernel ran at the LDS port's rate, not the MFMA's
-    u32x4 wreg[NS > 0 ? NS : 1];
+    u32x4 wreg[NH][NS > 0 ? NS : 1];
     if constexpr (NS > 0) {
         __syncthreads();
 #pragma unroll
-        for (int sidx = 0; sidx < NS; ++sidx) wreg[sidx] = *(const u32x4*)(Wl + sidx * 2048 + half * 1024 + lh * 512 + l31 * 16);
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int sidx = 0; sidx < NS; ++sidx) wreg[h][sidx] = *(const u32x4*)(Wl + sidx * 2048 + (half + h) * 1024 + lh * 512 + l31 * 16);
     }
-    // bias of this lane's 16 output channels (4 groups of 4)
-    f32x4 breg[4];
+    // bias of this lane's 16 output channels per half (4 groups of 4)
+    // (the wide item has no registers to spare for them: it fetches the bias in its epilogue, when there is one)
+    f32x4 breg[NH][4];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = half * 32 + 8 * gq + 4 * lh + e;
-            breg[gq][e] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
-        }
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (half + h) * 32 + 8 * gq + 4 * lh + e;
+                breg[h][gq][e] = (!WIDE && p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+            }
     unsigned char* st = stage + wave * 32 * SS;
     const int row0 = blockIdx.x * p.rows_per_wg;
     const int nrows = min(p.rows_per_wg, p.rows_total - row0);
     const int cpr_in = p.PWE / CH, data0 = PATCH_A0 / CH, data1 = data0 + (p.W * p.Cin) / CH;
     const int segs = (cpr_in + 63) / 64;                         // 64-chunk segments per input row
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(rp_lds_u8*)ring;
-    const int nitems = 2 * ((p.Wo + 31) / 32);
+    const int nitems = (WIDE ? 1 : 2) * ((p.Wo + 31) / 32);
     // STATS (Cout == 64): in the copy-out every lane always moves the same 16-byte channel group (lane % CPRO) of pixels
     // lane / CPRO + k * (64 / CPRO): its sums cover CH channels
     float sS[CH], sQ[CH], cnt = 0.f;
@@ -261,13 +271,16 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
             }
         }
         for (int it = wave; it < nitems; it += NW) {
-            const int c0 = (it >> 1) * 32;
+            const int c0 = (WIDE ? it : (it >> 1)) * 32;
             const int ow = c0 + l31;
             const int owc = ow < p.Wo ? ow : p.Wo - 1;           // clamp: reads stay inside the ring row
             const int e0 = PATCH_A0 - p.p * p.Cin - p.lead + owc * p.s * p.Cin;
-            f32x16 acc;
+            f32x16 accs[NH];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[h][r] = 0.f;
+            f32x16& acc = accs[0];
             if constexpr (NS > 0) {
                 const unsigned char* arow = (const unsigned char*)ring;
 #pragma unroll
@@ -275,8 +288,11 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
                     u32x4 fa;
                     if (RP_ABL & 32) fa = u32x4{(unsigned)e0, (unsigned)sidx, 0x3f803f80u, 0x3f803f80u};
                     else fa = read_chunk<T, ALIGN4>((const T*)(arow + (lh ? offB[sidx] : offA[sidx])), e0);
-                    if (RP_ABL & 128) acc[sidx & 15] += __builtin_bit_cast(float, fa[0] ^ fa[1] ^ fa[2] ^ fa[3] ^ wreg[sidx][0]);
-                    else RpMma<T>::run(acc, wreg[sidx], fa);     // transposed: rows = co, cols = pixels
+                    if (RP_ABL & 128) acc[sidx & 15] += __builtin_bit_cast(float, fa[0] ^ fa[1] ^ fa[2] ^ fa[3] ^ wreg[0][sidx][0]);
+                    else {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) RpMma<T>::run(accs[h], wreg[h][sidx], fa);     // transposed: rows = co, cols = pixels
+                    }
                 }
             } else {
             // this lane's k-chunk q = 2*step + lh walks (kh, chunk-in-run); fragments of step+1 are read before the
@@ -314,21 +330,27 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
                 if (t == 12345.678f) ((float*)p.y)[0] = t;
                 continue;
             }
-            // lane (pixel l31, lh) holds channels half*32 + 8g + 4lh + {0..3} in regs 4g..4g+3
+            // lane (pixel l31, lh) holds channels (half + h)*32 + 8g + 4lh + {0..3} in regs 4g..4g+3 of accumulator h
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int col = 8 * gq + 4 * lh;                 // within this wave's half
-                float v[4];
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[4 * gq + e] + breg[gq][e];
-                if constexpr (ES == 2) {
-                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *(bf16x4*)(st + l31 * SS + col * 2) = o;
-                } else {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(st + l31 * SS + col * 4) = o;
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int col = h * 32 + 8 * gq + 4 * lh;    // within this wave's channels
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = accs[h][4 * gq + e] + (WIDE ? 0.f : breg[h][gq][e]);
+                    if (WIDE && p.bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += p.bias[col + e];           // (64 output channels: all live)
+                    }
+                    if constexpr (ES == 2) {
+                        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *(bf16x4*)(st + l31 * SS + col * 2) = o;
+                    } else {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(st + l31 * SS + col * 4) = o;
+                    }
                 }
-            }
             // wave-private staging: no workgroup barrier needed, only this wave's own LDS ordering
             __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
             T* y = (T*)p.y + ((size_t)row * p.Wo + c0) * p.Cout + half * 32;
@@ -398,11 +420,11 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
             nn = nt;
         }
         __syncthreads();                                         // the stage area is free now
-        float* red = (float*)stage;                              // [NW waves][32 ch][3]
+        float* red = (float*)stage;                              // [NW waves][32 NH ch][3]
         if (lane < CPRO) {
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-                float* o = red + ((size_t)wave * 32 + lane * CH + e) * 3;
+                float* o = red + ((size_t)wave * (32 * NH) + lane * CH + e) * 3;
                 o[0] = nn; o[1] = mean[e]; o[2] = m2[e];
             }
         }
@@ -410,8 +432,8 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
         if (tid < 64) {
             float na = 0.f, ma = 0.f, qa = 0.f;
 #pragma unroll
-            for (int w = (tid >> 5); w < NW; w += 2) {           // the waves of channel half tid / 32
-                const float* o = red + ((size_t)w * 32 + (tid & 31)) * 3;
+            for (int w = WIDE ? 0 : (tid >> 5); w < NW; w += WIDE ? 1 : 2) {      // the waves that hold channel tid
+                const float* o = red + ((size_t)w * (32 * NH) + (WIDE ? tid : (tid & 31))) * 3;
                 const float nb = o[0], nt = na + nb, wb = nt > 0.f ? nb / nt : 0.f, d = o[1] - ma;
                 qa = qa + o[2] + d * d * na * wb;
                 ma = ma + d * wb;
@@ -658,8 +680,9 @@ __global__ void rowpatch_pack_kernel(const float* __restrict__ w, T* __restrict_
     }
 }
 
+// the staging area is sized for the wide item (32 pixels x 64 channels per wave)
 size_t rp_fwd_lds(const RowPatchParams& p, int es) {
-    return (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + p.s + 1) * p.PWE * es + (size_t)RP_FWD_WAVES * 32 * (32 * es + 16);
+    return (size_t)64 * (p.Kp * es + 16) + (size_t)(p.KH + p.s + 1) * p.PWE * es + (size_t)RP_FWD_WAVES * 32 * (64 * es + 16);
 }
 
 bool make_rp(const cnk_conv_desc* d, RowPatchParams* out) {
@@ -752,10 +775,16 @@ int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const f
     const int es = d->dtype == CNK_BF16 ? 2 : 4, ch = 16 / es;
     p.ksteps = ceil_div(p.KH * p.Rp, 2 * ch);
     size_t lds = rp_fwd_lds(p, es);
+    const bool wide = cnk_sw().rowpatch_wide && d->Cout == 64 && d->dtype == CNK_BF16;
+#define RP_FWD_NSW(TT, A4, NSV, WD)                                                                                 \
+    do {                                                                                                           \
+        if (stats) hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, true, NSV, WD>), dim3(grid), dim3(64 * RP_FWD_WAVES), lds, s, p); \
+        else hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, false, NSV, WD>), dim3(grid), dim3(64 * RP_FWD_WAVES), lds, s, p);      \
+    } while (0)
 #define RP_FWD_NS(TT, A4, NSV)                                                                                      \
     do {                                                                                                           \
-        if (stats) hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, true, NSV>), dim3(grid), dim3(64 * RP_FWD_WAVES), lds, s, p); \
-        else hipLaunchKernelGGL((rowpatch_fwd_kernel<TT, A4, false, NSV>), dim3(grid), dim3(64 * RP_FWD_WAVES), lds, s, p);      \
+        if (NSV > 0 && wide) RP_FWD_NSW(TT, A4, NSV, (NSV > 0));                                                    \
+        else RP_FWD_NSW(TT, A4, NSV, false);                                                                       \
     } while (0)
 #define RP_FWD(TT, A4)                                                                                             \
     do {                                                                                                           \
@@ -771,6 +800,7 @@ int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const f
         RP_FWD(float, true);
     }
 #undef RP_FWD_NS
+#undef RP_FWD_NSW
 #undef RP_FWD
     CNK_CHECK_LAUNCH("rowpatch_fwd");
     return 0;
