@@ -1000,7 +1000,12 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
     if (forced >= 0 && forced < 4 && fits(forced) && !(dgrad && forced >= 2)) return forced;      // (bench / test runs only)
     // 64 -> 64 channels: the weight-stationary kernel (filter bank in registers), forward and data gradient alike; its patch
     // must fit the WSCfg::PPW pieces a wave issues per job
-    if (cnk_sw().pp_ws && forced < 0 && C == 64 && Nout == 64 && pp_npg(H, W, PP_GEOM[4]) <= 8 * WSCfg::PPW && fits(4)) return 4;
+    // The fused data gradients stay on the halo kernel unless CNK_PP_FULL=1: solo the full-epilogue variant wins (113-120 vs
+    // 126 us), inside the step, beside the weight-gradient stream, it does not (rocprofv3 trace of graph replays: 153 vs 119 us --
+    // one workgroup per CU has nobody to cover its epilogue when the CU's other tenant slows it down).
+    if (cnk_sw().pp_ws && !(dgrad && fused && cnk_sw().pp_full != 1) && forced < 0 && C == 64 && Nout == 64 &&
+        pp_npg(H, W, PP_GEOM[4]) <= 8 * WSCfg::PPW && fits(4))
+        return 4;
     // Rule in work per CU (one persistent workgroup per CU, 256 CUs): the biggest tile -- 256 x 256, then 512 x 128, both
     // with the cheaper 128 x 64 wave tile -- as long as its tiles cover at least 5/8 of the CUs; below that the 256 x 128
     // tile's finer grain fills the chip better (7x7 layers at batch 256: 98 big tiles, 141 vs 75 us).

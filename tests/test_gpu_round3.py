@@ -668,8 +668,8 @@ WS_SHAPES = {
 @pytest.mark.parametrize('shape', list(WS_SHAPES))
 def test_weight_stationary_64_channel_kernel(shape):
     """Forward (plain rows / BN statistics partials) and data gradient (plain / gradient addend + packed masks + fused BN
-    backward, mask bits and re-derived mask) of the 64 -> 64 channel 3x3 layers on the weight-stationary kernel, unforced
-    dispatch with a launch counter, against fp64 from the bf16-rounded operands, against the tensor the kernel itself wrote
+    backward, mask bits and re-derived mask) of the 64 -> 64 channel 3x3 layers on the weight-stationary kernel (unforced
+    dispatch except CNK_PP_FULL=1, which also sends the fused gradients there) with a launch counter, against fp64 from the bf16-rounded operands, against the tensor the kernel itself wrote
     (statistics and BN sums) and against the r01 halo kernel (other K order: two valid bf16 roundings, not the same bits)."""
     _lib, lib, cnt = _lib_and_counter()
     from convnets_amd import ops
@@ -689,7 +689,7 @@ def test_weight_stationary_64_channel_kernel(shape):
     bgam, bbeta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     out = {}
-    for name, env in (('ws', dict(CNK_PP3X3=None, CNK_PP_CFG=None, CNK_PP_FULL=None, CNK_PP_WS=None)), ('halo', dict(CNK_PP3X3='0'))):
+    for name, env in (('ws', dict(CNK_PP3X3=None, CNK_PP_CFG=None, CNK_PP_FULL='1', CNK_PP_WS=None)), ('halo', dict(CNK_PP3X3='0'))):
         with _lib.switches(**env):
             nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
             nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
