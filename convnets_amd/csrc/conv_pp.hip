@@ -1001,8 +1001,9 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
     // 64 -> 64 channels: the weight-stationary kernel (filter bank in registers), forward and data gradient alike; its patch
     // must fit the WSCfg::PPW pieces a wave issues per job
     // The fused data gradients stay on the halo kernel unless CNK_PP_FULL=1: solo the full-epilogue variant wins (113-120 vs
-    // 126 us), inside the step, beside the weight-gradient stream, it does not (rocprofv3 trace of graph replays: 153 vs 119 us --
-    // one workgroup per CU has nobody to cover its epilogue when the CU's other tenant slows it down).
+    // 126 us), inside the step, beside the weight-gradient stream, it does not (rocprofv3 traces of graph replays: 153 vs 147 us
+    // on the same launches, step time equal within noise -- one workgroup per CU has nobody to cover its epilogue when the CU's
+    // other tenant slows it down).
     if (cnk_sw().pp_ws && !(dgrad && fused && cnk_sw().pp_full != 1) && forced < 0 && C == 64 && Nout == 64 &&
         pp_npg(H, W, PP_GEOM[4]) <= 8 * WSCfg::PPW && fits(4))
         return 4;
