@@ -1,0 +1,66 @@
+"""Timeline of one training step from a rocprofv3 --kernel-trace CSV (tools/run_profiles.sh: gpurun_out/<tag>_stats): per
+hardware queue the busy time and the idle gaps between consecutive kernels, the union over queues, and the kernels that sit in
+front of the longest gaps.  A step = from one adam_kernel end to the next.      python tools/trace_gaps.py <kernel_trace.csv>"""
+import collections, csv, re, sys
+
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['Queue_Id']), r['Kernel_Name']))
+rows.sort()
+adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[3]]
+if len(adam) < 3:
+    sys.exit('fewer than three optimizer launches in the trace')
+
+
+def short(n):
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I', n)
+    return (m.group(1) if m else re.sub(r'[<(].*', '', n))[:34]
+
+
+# the LAST complete step of the trace (graph replays when bench.py ran with the graph)
+a, b = adam[-2], adam[-1]
+step = rows[a + 1:b + 1]
+t0, t1 = rows[a][1], rows[b][1]
+print('step wall %.3f ms, %d kernels' % ((t1 - t0) / 1e6, len(step)))
+byq = collections.defaultdict(list)
+for r in step:
+    byq[r[2]].append(r)
+for q, rs in sorted(byq.items()):
+    busy = sum(e - s for s, e, _, _ in rs)
+    gaps = [(rs[i + 1][0] - rs[i][1], rs[i][3], rs[i + 1][3]) for i in range(len(rs) - 1)]
+    pos = [g for g in gaps if g[0] > 0]
+    print('queue %d: %4d kernels, busy %.3f ms, span %.3f ms, gaps>0: %d totalling %.3f ms (median %.2f us), overlapping pairs %d'
+          % (q, len(rs), busy / 1e6, (rs[-1][1] - rs[0][0]) / 1e6, len(pos), sum(g[0] for g in pos) / 1e6,
+             sorted(g[0] for g in pos)[len(pos) // 2] / 1e3 if pos else 0.0, sum(1 for g in gaps if g[0] <= 0)))
+# union over queues
+ev = sorted([(s, 1) for s, e, _, _ in step] + [(e, -1) for s, e, _, _ in step])
+depth, last, idle, busy2 = 0, t0, 0, 0
+for t, d in ev:
+    if depth == 0:
+        idle += t - last
+    elif depth >= 2:
+        busy2 += t - last
+    last = t
+    depth += d
+print('union: idle %.3f ms of the step, two or more kernels in flight %.3f ms' % (idle / 1e6, busy2 / 1e6))
+# idle intervals (nothing running) and what ran before / after them
+ends = sorted(step, key=lambda r: r[1])
+gl = []
+depth, last = 0, t0
+prev = None
+for t, d, r in sorted([(s, 1, (s, e, q, n)) for s, e, q, n in step] + [(e, -1, (s, e, q, n)) for s, e, q, n in step], key=lambda x: (x[0], x[1])):
+    if depth == 0 and d == 1 and prev is not None:
+        gl.append((t - last, prev[3], r[3]))
+    if d == -1:
+        prev = r
+    last = t
+    depth += d
+agg = collections.defaultdict(lambda: [0, 0])
+for g, p, n in gl:
+    k = short(p) + ' -> ' + short(n)
+    agg[k][0] += 1
+    agg[k][1] += g
+print('idle time by (kernel before -> kernel after), top 25:')
+for k, (c, g) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+    print('  %-72s n=%3d  %.1f us total, %.2f us each' % (k, c, g / 1e3, g / 1e3 / c))
