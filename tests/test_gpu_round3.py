@@ -749,3 +749,59 @@ def test_weight_stationary_64_channel_kernel(shape):
         assert ((got[:, 0] - wrote.sum((0, 1, 2))).abs().max() / wrote.abs().sum((0, 1, 2)).max()).item() < 1e-5
         q = (wrote * (bnx.double().cpu() - bmean.double().cpu())).sum((0, 1, 2)) * binv.double().cpu()
         assert ((got[:, 1] - q).abs().max() / q.abs().max()).item() < 1e-4
+
+
+def test_weight_stationary_kernel_random_geometries():
+    """Twelve seeded random (N, H, W) with 64 -> 64 channels wherever the weight-stationary kernel takes the shape: forward
+    (statistics) and both data-gradient modes against the halo kernel (two valid bf16 roundings of one fp32 result:
+    rel-L2 <= 3e-3, BN sums <= 5e-3) -- image sizes down to 5x5 (a tile spans ten images), odd widths, ragged last tiles."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    rng = np.random.default_rng(77)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ran = 0
+    for case in range(12):
+        H, W = int(rng.integers(5, 60)), int(rng.integers(5, 60))
+        N = int(rng.integers(max(1, 2048 // (H * W) + 1), max(2, 40000 // (H * W)) + 2))
+        C = 64
+        M = N * H * W
+        x, dy, w = _operands((N, C, H, W), 500 + case)
+        g = torch.Generator().manual_seed(900 + case)
+        xg, dyg = x.cuda().contiguous(memory_format=CL), dy.cuda().contiguous(memory_format=CL)
+        desc = ops.make_desc(xg.shape, w.shape, (1, 1), (1, 1), _lib.CNK_BF16)
+        wf, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+        bnx = (torch.randn(N, H, W, C, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+        addend = torch.randn(N, H, W, C, generator=g).bfloat16().cuda()
+        amask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).cuda()
+        bmean, binv = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+        bgam, bbeta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+        out = {}
+        took = False
+        for name, env in (('ws', dict(CNK_PP3X3=None, CNK_PP_CFG=None, CNK_PP_FULL='1', CNK_PP_WS=None)), ('halo', dict(CNK_PP3X3='0'))):
+            with _lib.switches(**env):
+                nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+                nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+                part = torch.full((nsl, C, 3), float('nan'), device='cuda')
+                bpart = torch.full((nb, C, 2), float('nan'), device='cuda')
+                fuse = _lib.BnBwdFuse(bnx.data_ptr(), bmean.data_ptr(), binv.data_ptr(), bgam.data_ptr(), bbeta.data_ptr(),
+                                      None, bpart.data_ptr(), 1)
+                y, dxp, dxf = torch.empty_like(xg), torch.empty_like(dyg), torch.empty_like(dyg)
+                c0 = cnt(CNT_PP_WS)
+                assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(xg), P(wf), None, P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
+                assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dxp), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+                assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(dyg), P(wd), P(dxf), P(addend), P(amask), ctypes.byref(fuse), None, 0, st) == 0, lib.cnk_last_error()
+                torch.cuda.synchronize()
+                if name == 'ws':
+                    took = cnt(CNT_PP_WS) - c0 == 3
+                assert torch.isfinite(part).all() and torch.isfinite(bpart).all()
+                out[name] = (y, dxp, dxf, _merge_stats(part, M), bpart.double().sum(0).cpu())
+        if not took:
+            continue                                   # (patch too large for the kernel's buffers, or too few tiles: halo both times)
+        ran += 1
+        a, b = out['ws'], out['halo']
+        for k in range(3):
+            assert rel_l2(host(a[k]), host(b[k])) < 3e-3, (case, N, H, W, k)
+        assert ((a[3][0] - b[3][0]).abs().max() / b[3][0].abs().max().clamp_min(1e-6)).item() < 5e-3
+        assert ((a[3][1] - b[3][1]).abs() / b[3][1]).max().item() < 5e-3
+        assert ((a[4] - b[4]).abs().max(0).values / b[4].abs().max(0).values).max().item() < 5e-3, (case, N, H, W)
+    assert ran >= 8, 'the weight-stationary kernel took only %d of 12 shapes' % ran
