@@ -805,3 +805,63 @@ def test_weight_stationary_kernel_random_geometries():
         assert ((a[3][1] - b[3][1]).abs() / b[3][1]).max().item() < 5e-3
         assert ((a[4] - b[4]).abs().max(0).values / b[4].abs().max(0).values).max().item() < 5e-3, (case, N, H, W)
     assert ran >= 8, 'the weight-stationary kernel took only %d of 12 shapes' % ran
+
+
+def test_weight_stationary_kernel_fullsize_under_load_is_repeatable():
+    """bs 256, 64 -> 64 @56x56 (3136 tiles, twelve or thirteen per workgroup, every CU busy): the weight-stationary kernel's
+    hand-counted vmcnt / lgkmcnt waits and its three-buffer patch ring under the conditions that exposed the ping-pong core's
+    wait bug (see test_pingpong_full_epilogue_under_load).  Five launches per mode while a streaming kernel runs beside them
+    on a second stream: every launch must reproduce the first bit for bit (a wait that passes early shows up as run-to-run
+    differences), and the first must match the halo kernel to two valid bf16 roundings."""
+    _lib, lib, cnt = _lib_and_counter()
+    from convnets_amd import ops
+    N, C, H = 256, 64, 56
+    M = N * H * H
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, H, generator=g).bfloat16().cuda().contiguous(memory_format=CL)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.04
+    desc = ops.make_desc(x.shape, w.shape, (1, 1), (1, 1), _lib.CNK_BF16)
+    wf, wd = ops.PackedWeights().get(w.cuda(), desc, True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bnx = (torch.randn(N, H, H, C, generator=g) * 1.3 + 0.2).bfloat16().cuda()
+    addend = torch.randn(N, H, H, C, generator=g).bfloat16().cuda()
+    amask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).cuda()
+    bmean, binv = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    bgam, bbeta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    noise_a = torch.randn(64 << 20, device='cuda')
+    noise_b = torch.empty_like(noise_a)
+    side = torch.cuda.Stream()
+
+    def run(env, reps, busy):
+        outs = []
+        with _lib.switches(**env):
+            nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(desc))
+            nb = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(desc))
+            for r in range(reps):
+                part = torch.full((nsl, C, 3), float('nan'), device='cuda')
+                bpart = torch.full((nb, C, 2), float('nan'), device='cuda')
+                fuse = _lib.BnBwdFuse(bnx.data_ptr(), bmean.data_ptr(), binv.data_ptr(), bgam.data_ptr(), bbeta.data_ptr(), None, bpart.data_ptr(), 1)
+                y, dxp, dxf = (torch.full_like(x, float('nan')) for _ in range(3))
+                if busy:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        for _ in range(6):
+                            torch.add(noise_a, 1.0, out=noise_b)          # 512 MB of HBM traffic per pass beside the convs
+                c0 = cnt(CNT_PP_WS)
+                assert lib.cnk_conv2d_fwd(ctypes.byref(desc), P(x), P(wf), None, P(y), P(part), None, 0, st) == 0, lib.cnk_last_error()
+                assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(x), P(wd), P(dxp), None, None, None, None, 0, st) == 0, lib.cnk_last_error()
+                assert lib.cnk_conv2d_dgrad(ctypes.byref(desc), P(x), P(wd), P(dxf), P(addend), P(amask), ctypes.byref(fuse), None, 0, st) == 0, lib.cnk_last_error()
+                torch.cuda.synchronize()
+                outs.append((y, dxp, dxf, part, bpart, cnt(CNT_PP_WS) - c0))
+        return outs
+    ref = run(dict(CNK_PP3X3='0'), 1, False)[0]
+    got = run(dict(CNK_PP3X3=None, CNK_PP_CFG=None, CNK_PP_FULL='1', CNK_PP_WS=None), 5, True)
+    first = got[0]
+    assert first[5] == 3, 'all three launches belong on the weight-stationary kernel'
+    for k in range(3):
+        assert torch.isfinite(first[k]).all()
+        assert rel_l2(host(first[k]), host(ref[k])) < 3e-3
+    assert torch.isfinite(first[3]).all() and torch.isfinite(first[4]).all()
+    for o in got[1:]:
+        for k in range(5):
+            assert torch.equal(o[k], first[k]), 'launches of one kernel on the same operands differ (mode %d)' % k
