@@ -139,6 +139,40 @@ __global__ __launch_bounds__(256) void maxpool_k3s2_affine_kernel(const T* __res
                 okm |= (ok ? 1u : 0u) << (r * 3 + q);
             }
         __builtin_amdgcn_sched_barrier(0);                // the nine loads stay in front of the arithmetic
+        if constexpr (sizeof(T) == 2 && VEC == 8) {
+            if (relu) {
+                // bf16 after ReLU is non-negative, so its bit pattern orders like the value: one unsigned max per tap and channel
+                // over the key (bits << 16) | (8 - tap) takes the largest ROUNDED value and, among equal ones, the first tap in
+                // scan order -- the rule of the compare-and-select chain below (no NaN survives the ReLU) at half its VALU work
+                // (the kernel is VALU-bound: 9 taps x 8 channels)
+                unsigned key[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) key[k] = 0u;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const bool on = (okm >> tp) & 1u;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float a = v[tp].get(k) * sc[k] + sf[k];
+                        a = a > 0.f ? a : 0.f;
+                        const T r = from_f32<T>(a);
+                        const unsigned kk = ((unsigned)__builtin_bit_cast(unsigned short, r) << 16) | (unsigned)(8 - tp);
+                        const unsigned cand = on ? kk : 0u;
+                        key[k] = cand > key[k] ? cand : key[k];
+                    }
+                }
+                Raw16<T, VEC> o;
+                u32x2 pk = {0u, 0u};
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    o.v[k] = __builtin_bit_cast(T, (unsigned short)(key[k] >> 16));
+                    pk[k >> 2] |= (8u - (key[k] & 0xFFu)) << (8 * (k & 3));
+                }
+                o.store(y + (size_t)i * VEC);
+                if (idx) *(u32x2*)(idx + (size_t)i * VEC) = pk;
+                continue;
+            }
+        }
         float best[VEC];
         unsigned char bi[VEC];
         bool any = false;
