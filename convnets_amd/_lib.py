@@ -72,6 +72,8 @@ SIGNATURES = {
     'cnk_maxpool2d_bwd': (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_maxpool2d_fwd_bn': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
     'cnk_bn_bwd_maxpool': (ctypes.c_int, [_vp] * 10 + [ctypes.c_int] + [_i32] * 10 + [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    'cnk_maxpool2d_fwd_bn_keep': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp] + [_i32] * 10 + [ctypes.c_int, _vp]),
+    'cnk_bn_bwd_maxpool_kept': (ctypes.c_int, [_vp] * 11 + [ctypes.c_int] + [_i32] * 10 + [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     'cnk_relu_fwd': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp]),
     'cnk_relu_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
     'cnk_add_relu_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),

@@ -90,8 +90,8 @@ size_t bn_mask_bytes(int64_t M, int C, int dtype);
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
 int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, const float* ext_partial, int64_t ext_slices, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
-int bn_bwd_pool(const void* dy, const unsigned char* idx, const void* x, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu, int dtype, float* ws, hipStream_t s);
-int maxpool_affine_dispatch(const void* x, const float* scale, const float* shift, int relu, void* y, unsigned char* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
+int bn_bwd_pool(const void* dy, const unsigned char* idx, const void* x, const void* xmax, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu, int dtype, float* ws, hipStream_t s);
+int maxpool_affine_dispatch(const void* x, const float* scale, const float* shift, int relu, void* y, unsigned char* idx, void* xmax, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 int maxpool_dispatch(bool bwd, const void* a, void* b, void* o, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 template <int OP> int eltwise_dispatch(const void* a, const void* b, void* o, int64_t n, int dtype, hipStream_t s);
 int gap_dispatch(bool bwd, const void* a, void* o, int N, int HW, int C, int dtype, hipStream_t s);
@@ -508,7 +508,7 @@ int cnk_maxpool2d_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N
     return maxpool_dispatch(true, dy, (void*)argmax, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
 }
 
-int cnk_bn_bwd_maxpool(const void* dy_pooled, const uint8_t* argmax, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+static int bn_bwd_maxpool_common(const void* dy_pooled, const uint8_t* argmax, const void* x, const void* x_at_max, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(dy_pooled && argmax && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "cnk_bn_bwd_maxpool: null pointer");
     CNK_CHECK_ARG(!relu || beta, "cnk_bn_bwd_maxpool: relu backward re-derives the mask from x and needs beta");
     CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && kh * kw <= 255, "cnk_bn_bwd_maxpool: bad geometry");
@@ -519,9 +519,19 @@ int cnk_bn_bwd_maxpool(const void* dy_pooled, const uint8_t* argmax, const void*
     CNK_CHECK_ARG(M * C < (1ll << 31), "cnk_bn_bwd_maxpool: tensor too large");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd_maxpool: workspace too small");
     const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
-    // two passes over x, each with a gather of the pooled gradient and its arg-max bytes, one write of dx
-    ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, 3.0 * (double)M * C * esize(dtype) + 2.0 * (double)N * Ho * Wo * C * (esize(dtype) + 1));
-    return bn_bwd_pool(dy_pooled, argmax, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, accumulate, N, H, W, C, kh, kw, sh, sw, ph, pw, relu, dtype, (float*)workspace, S(stream));
+    // two passes over x, each with a gather of the pooled gradient and its arg-max bytes, one write of dx (with x_at_max the
+    // first pass reads the pooled gradient and the kept inputs only)
+    ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, (x_at_max ? 2.0 : 3.0) * (double)M * C * esize(dtype) + 2.0 * (double)N * Ho * Wo * C * (esize(dtype) + 1));
+    return bn_bwd_pool(dy_pooled, argmax, x, x_at_max, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, accumulate, N, H, W, C, kh, kw, sh, sw, ph, pw, relu, dtype, (float*)workspace, S(stream));
+}
+
+int cnk_bn_bwd_maxpool(const void* dy_pooled, const uint8_t* argmax, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_bwd_maxpool_common(dy_pooled, argmax, x, nullptr, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, accumulate, N, H, W, C, kh, kw, sh, sw, ph, pw, relu, dtype, workspace, workspace_bytes, stream);
+}
+
+int cnk_bn_bwd_maxpool_kept(const void* dy_pooled, const uint8_t* argmax, const void* x, const void* x_at_max, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(x_at_max, "cnk_bn_bwd_maxpool_kept: null pointer");
+    return bn_bwd_maxpool_common(dy_pooled, argmax, x, x_at_max, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, accumulate, N, H, W, C, kh, kw, sh, sw, ph, pw, relu, dtype, workspace, workspace_bytes, stream);
 }
 
 int cnk_maxpool2d_fwd_bn(const void* x, const float* scale, const float* shift, int relu, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
@@ -529,7 +539,15 @@ int cnk_maxpool2d_fwd_bn(const void* x, const float* scale, const float* shift, 
     CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && kh * kw <= 255, "cnk_maxpool2d_fwd_bn: bad geometry");
     CNK_CHECK_ARG(H + 2 * ph >= kh && W + 2 * pw >= kw && 2 * ph <= kh && 2 * pw <= kw, "cnk_maxpool2d_fwd_bn: bad padding");
     CNK_CHECK_ARG(dtype == CNK_F32 || dtype == CNK_BF16, "cnk_maxpool2d_fwd_bn: bad dtype %d", dtype);
-    return maxpool_affine_dispatch(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+    return maxpool_affine_dispatch(x, scale, shift, relu, y, idx, nullptr, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
+}
+
+int cnk_maxpool2d_fwd_bn_keep(const void* x, const float* scale, const float* shift, int relu, void* y, uint8_t* idx, void* x_at_max, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream) {
+    CNK_CHECK_ARG(x && scale && shift && y && idx && x_at_max, "cnk_maxpool2d_fwd_bn_keep: null pointer");
+    CNK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0 && kh * kw <= 255, "cnk_maxpool2d_fwd_bn_keep: bad geometry");
+    CNK_CHECK_ARG(H + 2 * ph >= kh && W + 2 * pw >= kw && 2 * ph <= kh && 2 * pw <= kw, "cnk_maxpool2d_fwd_bn_keep: bad padding");
+    CNK_CHECK_ARG(dtype == CNK_F32 || dtype == CNK_BF16, "cnk_maxpool2d_fwd_bn_keep: bad dtype %d", dtype);
+    return maxpool_affine_dispatch(x, scale, shift, relu, y, idx, x_at_max, N, H, W, C, kh, kw, sh, sw, ph, pw, dtype, S(stream));
 }
 
 int cnk_relu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {

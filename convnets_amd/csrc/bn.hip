@@ -1483,10 +1483,10 @@ static bool make_pool_cell(PoolCell& pc, int H, int W, int kh, int kw, int sh, i
 }  // namespace
 
 template <typename T, int VEC>
-static int bn_bwd_pool_t(const void* dy, const unsigned char* idx, const void* x, const float* gamma, const float* beta,
-                         const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int N,
-                         int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu, float* ws,
-                         hipStream_t s) {
+static int bn_bwd_pool_t(const void* dy, const unsigned char* idx, const void* x, const void* xmax, const float* gamma,
+                         const float* beta, const float* sm, const float* si, void* dx, float* dgamma, float* dbeta,
+                         int accumulate, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu,
+                         float* ws, hipStream_t s) {
     const int64_t M = (int64_t)N * H * W;
     SliceGeom g = make_geom(M, C, VEC);
     PoolGeom pg;
@@ -1504,14 +1504,33 @@ static int bn_bwd_pool_t(const void* dy, const unsigned char* idx, const void* x
         const int64_t cells = (int64_t)N * pc.cells_h * pc.cells_w;
         SliceGeom gc = make_geom(cells, C, VEC);
         const dim3 cgrid(gc.slices, gc.colgroups);
-        if (relu)
-            hipLaunchKernelGGL((bn_cell_bwd_reduce_kernel<T, VEC, true>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
-                               (const T*)x, gamma, beta, sm, si, partial, cells, C, gc, pc);
-        else
-            hipLaunchKernelGGL((bn_cell_bwd_reduce_kernel<T, VEC, false>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
-                               (const T*)x, gamma, beta, sm, si, partial, cells, C, gc, pc);
-        CNK_CHECK_LAUNCH("bn_cell_bwd_reduce");
-        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, gc.slices, C, M, gamma, si, dgamma,
+        int red_slices = gc.slices;
+        if (xmax) {
+            // The pooled gradient only reaches arg-max elements, and the forward kept their INPUT values (x_at_max): both sums
+            // run over the POOLED tensors -- sum d' and sum d' (x - mean) over windows equal the sums over elements, an element
+            // that wins two windows contributes twice -- i.e. the regular reduce pass on [N Ho Wo][C] rows, a quarter of the
+            // bytes of the gather over x (ResNet-50 stem: 206 MB instead of 565).
+            const int64_t Mp = (int64_t)N * pc.Ho * pc.Wo;
+            SliceGeom gp = make_geom(Mp, C, VEC);
+            red_slices = gp.slices;
+            const dim3 pgrid(gp.slices, gp.colgroups);
+            if (relu)
+                hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, ACT_REMASK>), pgrid, dim3(256), 0, s, (const T*)dy, (const T*)xmax,
+                                   (const T*)nullptr, (const unsigned char*)nullptr, gamma, beta, sm, si, partial, Mp, C, gp);
+            else
+                hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, ACT_NONE>), pgrid, dim3(256), 0, s, (const T*)dy, (const T*)xmax,
+                                   (const T*)nullptr, (const unsigned char*)nullptr, gamma, beta, sm, si, partial, Mp, C, gp);
+            CNK_CHECK_LAUNCH("bn_bwd_reduce(pooled)");
+        } else {
+            if (relu)
+                hipLaunchKernelGGL((bn_cell_bwd_reduce_kernel<T, VEC, true>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
+                                   (const T*)x, gamma, beta, sm, si, partial, cells, C, gc, pc);
+            else
+                hipLaunchKernelGGL((bn_cell_bwd_reduce_kernel<T, VEC, false>), cgrid, dim3(256), 0, s, (const T*)dy, idx,
+                                   (const T*)x, gamma, beta, sm, si, partial, cells, C, gc, pc);
+            CNK_CHECK_LAUNCH("bn_cell_bwd_reduce");
+        }
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, red_slices, C, M, gamma, si, dgamma,
                            dbeta, coefA, coefB1, coefB2, accumulate);
         CNK_CHECK_LAUNCH("bn_bwd_final");
         const double pooled = (double)N * pc.Ho * pc.Wo * C * (sizeof(T) + 1);
@@ -1548,11 +1567,11 @@ static int bn_bwd_pool_t(const void* dy, const unsigned char* idx, const void* x
     return 0;
 }
 
-int bn_bwd_pool(const void* dy, const unsigned char* idx, const void* x, const float* gamma, const float* beta,
+int bn_bwd_pool(const void* dy, const unsigned char* idx, const void* x, const void* xmax, const float* gamma, const float* beta,
                 const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int N, int H,
                 int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu, int dtype, float* ws,
                 hipStream_t s) {
-#define CNK_BN_POOL(T, V) bn_bwd_pool_t<T, V>(dy, idx, x, gamma, beta, sm, si, dx, dgamma, dbeta, accumulate, N, H, W, C, kh, kw, sh, sw, ph, pw, relu, ws, s)
+#define CNK_BN_POOL(T, V) bn_bwd_pool_t<T, V>(dy, idx, x, xmax, gamma, beta, sm, si, dx, dgamma, dbeta, accumulate, N, H, W, C, kh, kw, sh, sw, ph, pw, relu, ws, s)
     if (dtype == CNK_BF16) return C % 8 == 0 ? CNK_BN_POOL(bf16, 8) : CNK_BN_POOL(bf16, 1);
     return C % 4 == 0 ? CNK_BN_POOL(float, 4) : CNK_BN_POOL(float, 1);
 #undef CNK_BN_POOL

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                                                           unsigned char* __restrict__ idx,
                                                           PoolParams p, int64_t total,
                                                           const float* __restrict__ scale = nullptr,
-                                                          const float* __restrict__ shift = nullptr, int relu = 0) {
+                                                          const float* __restrict__ shift = nullptr, int relu = 0,
+                                                          T* __restrict__ xmax = nullptr) {
     const int cols = p.C / VEC;
     // blocks are dealt to the 8 XCDs round-robin: walk the tensor so that each XCD gets a CONTIGUOUS run of every grid
     // sweep -- neighbouring output rows share input rows, which then hit in that XCD's L2 (r02c FETCH_SIZE: 626 MB per
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         uint32_t pix = fd_div((uint32_t)i, p.fd_cols), vc = (uint32_t)i - pix * cols;
         uint32_t t = fd_div(pix, p.fd_wo), wo = pix - t * p.Wo;
         uint32_t n = fd_div(t, p.fd_ho), ho = t - n * p.Ho;
-        float best[VEC];
+        float best[VEC], bx[VEC];
         unsigned char bi[VEC];
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+        for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = 0; bx[k] = 0.f; }
         for (int r = 0; r < p.kh; ++r) {
             int h = (int)ho * p.sh - p.ph + r;
             if ((unsigned)h >= (unsigned)p.H) continue;
@@ -75,6 +76,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 if ((unsigned)w >= (unsigned)p.W) continue;
                 VL<T, VEC> v;
                 v.load(x + ((size_t)(n * p.H + h) * p.W + w) * p.C + vc * VEC);
+                float raw[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) raw[k] = v.f[k];
                 if constexpr (AFFINE) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 unsigned char pos = (unsigned char)(r * p.kw + q);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    if (!any || v.f[k] > best[k] || v.f[k] != v.f[k]) { best[k] = v.f[k]; bi[k] = pos; }
+                    if (!any || v.f[k] > best[k] || v.f[k] != v.f[k]) { best[k] = v.f[k]; bi[k] = pos; bx[k] = raw[k]; }
                 any = true;
             }
         }
@@ -97,6 +101,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         if (idx) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) idx[(size_t)i * VEC + k] = bi[k];
+        }
+        if constexpr (AFFINE) {
+            if (xmax) {                                  // the INPUT value at the arg-max (cnk_maxpool2d_fwd_bn_keep)
+                VL<T, VEC> ox;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) ox.f[k] = bx[k];
+                ox.store(xmax + (size_t)i * VEC);
+            }
         }
     }
 }
@@ -111,7 +123,7 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_k3s2_affine_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                   unsigned char* __restrict__ idx, PoolParams p, int64_t total,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                  int relu) {
+                                                                  int relu, T* __restrict__ xmax) {
     const int cols = p.C / VEC;
     const int g8 = gridDim.x & ~7;
     const int lb = (int)blockIdx.x < g8 ? ((int)blockIdx.x & 7) * (g8 >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
@@ -170,23 +182,37 @@ __global__ __launch_bounds__(256) void maxpool_k3s2_affine_kernel(const T* __res
                 }
                 o.store(y + (size_t)i * VEC);
                 if (idx) *(u32x2*)(idx + (size_t)i * VEC) = pk;
+                if (xmax) {
+                    // the INPUT value at the arg-max (cnk_maxpool2d_fwd_bn_keep): one select per tap and channel by the winner's tap
+                    Raw16<T, VEC> ox;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const unsigned win = 8u - (key[k] & 0xFFu);
+                        T xr = v[0].v[k];
+#pragma unroll
+                        for (int tp = 1; tp < 9; ++tp) xr = win == (unsigned)tp ? v[tp].v[k] : xr;
+                        ox.v[k] = xr;
+                    }
+                    ox.store(xmax + (size_t)i * VEC);
+                }
                 continue;
             }
         }
-        float best[VEC];
+        float best[VEC], bx[VEC];
         unsigned char bi[VEC];
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+        for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; bi[k] = 0; bx[k] = 0.f; }
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             if (!((okm >> tp) & 1u)) continue;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float a = v[tp].get(k) * sc[k] + sf[k];
+                const float raw = v[tp].get(k);
+                float a = raw * sc[k] + sf[k];
                 if (relu) a = a > 0.f ? a : 0.f;
                 const float f = to_f32(from_f32<T>(a));
-                if (!any || f > best[k] || f != f) { best[k] = f; bi[k] = (unsigned char)tp; }
+                if (!any || f > best[k] || f != f) { best[k] = f; bi[k] = (unsigned char)tp; bx[k] = raw; }
             }
             any = true;
         }
@@ -194,6 +220,12 @@ __global__ __launch_bounds__(256) void maxpool_k3s2_affine_kernel(const T* __res
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o.set(k, best[k]);
         o.store(y + (size_t)i * VEC);
+        if (xmax) {
+            Raw16<T, VEC> ox;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) ox.set(k, bx[k]);
+            ox.store(xmax + (size_t)i * VEC);
+        }
         if (idx) {
             if constexpr (VEC == 8) {
                 u32x2 pk;
@@ -598,7 +630,7 @@ static int maxpool_t(bool bwd, const void* a, void* b, void* o, int N, int H, in
 
 template <typename T, int VEC>
 static int maxpool_affine_t(const void* x, const float* scale, const float* shift, int relu, void* y, unsigned char* idx,
-                            int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t s) {
+                            void* xmax, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, hipStream_t s) {
     PoolParams p = make_pool(N, H, W, C, kh, kw, sh, sw, ph, pw, VEC);
     int64_t total = (int64_t)N * p.Ho * p.Wo * (C / VEC);
     CNK_CHECK_ARG(total < (1ll << 31), "maxpool: tensor too large");
@@ -609,26 +641,26 @@ static int maxpool_affine_t(const void* x, const float* scale, const float* shif
         // (grid * 256) is a multiple of the vector columns
         if (kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 && H >= 2 && W >= 2 && ((int64_t)grid * 256) % cols == 0) {
             hipLaunchKernelGGL((maxpool_k3s2_affine_kernel<T, VEC>), dim3(grid), dim3(256), 0, s, (const T*)x, (T*)y, idx, p,
-                               total, scale, shift, relu);
+                               total, scale, shift, relu, (T*)xmax);
             CNK_CHECK_LAUNCH("maxpool_k3s2_affine");
             return 0;
         }
     }
     hipLaunchKernelGGL((maxpool_fwd_kernel<T, VEC, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (T*)y, idx, p,
-                       total, scale, shift, relu);
+                       total, scale, shift, relu, (T*)xmax);
     CNK_CHECK_LAUNCH("maxpool_affine");
     return 0;
 }
 
 int maxpool_affine_dispatch(const void* x, const float* scale, const float* shift, int relu, void* y, unsigned char* idx,
-                            int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
+                            void* xmax, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
                             hipStream_t s) {
     if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return maxpool_affine_t<bf16, 8>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
-        return maxpool_affine_t<bf16, 1>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+        if (C % 8 == 0) return maxpool_affine_t<bf16, 8>(x, scale, shift, relu, y, idx, xmax, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+        return maxpool_affine_t<bf16, 1>(x, scale, shift, relu, y, idx, xmax, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
     }
-    if (C % 4 == 0) return maxpool_affine_t<float, 4>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
-    return maxpool_affine_t<float, 1>(x, scale, shift, relu, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    if (C % 4 == 0) return maxpool_affine_t<float, 4>(x, scale, shift, relu, y, idx, xmax, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
+    return maxpool_affine_t<float, 1>(x, scale, shift, relu, y, idx, xmax, N, H, W, C, kh, kw, sh, sw, ph, pw, s);
 }
 
 template <typename T, int VEC>

@@ -691,6 +691,9 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=Non
     return y
 
 
+POOL_KEEP = os.environ.get('CNK_POOL_KEEP', '1') != '0'      # (A/B switch for the kept arg-max inputs below)
+
+
 class BatchNormActMaxPoolFn(torch.autograd.Function):
     """BatchNorm2d (training) -> [ReLU] -> MaxPool2d as ONE autograd node (the stems: resnet.py:88-89; VGG's stage
     ends).  Forward: the BN statistics, then a pooling pass that normalises the conv output on the fly
@@ -719,16 +722,25 @@ class BatchNormActMaxPoolFn(torch.autograd.Function):
         y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=CL)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
         scale, shift = ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(ws.data_ptr() + 4 * C)   # left there by the BN call
-        check(lib.cnk_maxpool2d_fwd_bn(_p(x), scale, shift, int(relu), _p(y), _p(idx), N, H, W, C, ksize[0], ksize[1],
-                                       stride[0], stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
-        ctx.save_for_backward(x, idx, gamma, beta, save_mean, save_invstd)
+        # stride-2 pools whose backward gathers through <= 2 x 2 windows: the pooling pass also keeps the INPUT value at every
+        # arg-max (a quarter of x), and the backward's reduction pass then reads that and the pooled gradient instead of
+        # gathering over all of x (cnk_bn_bwd_maxpool_kept)
+        keep = POOL_KEEP and x.requires_grad and tuple(stride) == (2, 2) and ksize[0] <= 4 and ksize[1] <= 4
+        xmax = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device) if keep else None
+        if keep:
+            check(lib.cnk_maxpool2d_fwd_bn_keep(_p(x), scale, shift, int(relu), _p(y), _p(idx), _p(xmax), N, H, W, C, ksize[0],
+                                                ksize[1], stride[0], stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
+        else:
+            check(lib.cnk_maxpool2d_fwd_bn(_p(x), scale, shift, int(relu), _p(y), _p(idx), N, H, W, C, ksize[0], ksize[1],
+                                           stride[0], stride[1], padding[0], padding[1], _dtype_code(x), _stream()))
+        ctx.save_for_backward(x, idx, gamma, beta, save_mean, save_invstd, xmax)
         ctx.relu, ctx.geom, ctx.params = bool(relu), (ksize, stride, padding), (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, idx, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        x, idx, gamma, beta, save_mean, save_invstd, xmax = ctx.saved_tensors
         ksize, stride, padding = ctx.geom
         dy = _nhwc(dy)
         N, C, H, W = x.shape
@@ -745,10 +757,16 @@ class BatchNormActMaxPoolFn(torch.autograd.Function):
         ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
         if ksize[0] <= 2 * stride[0] and ksize[1] <= 2 * stride[1] and os.environ.get('CNK_BN_POOL_BWD', '1') != '0':
             # both BN passes gather the pooled gradient themselves: no full-size intermediate
-            check(lib.cnk_bn_bwd_maxpool(_p(dy), _p(idx), _p(x), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
-                                         _p(dx), _p(dg_buf), _p(db_buf), int(direct), N, H, W, C, ksize[0], ksize[1],
-                                         stride[0], stride[1], padding[0], padding[1], int(ctx.relu), _dtype_code(x),
-                                         _p(ws), ws.numel(), _stream()))
+            if xmax is not None:
+                check(lib.cnk_bn_bwd_maxpool_kept(_p(dy), _p(idx), _p(x), _p(xmax), _p(gamma), _p(beta), _p(save_mean),
+                                                  _p(save_invstd), _p(dx), _p(dg_buf), _p(db_buf), int(direct), N, H, W, C,
+                                                  ksize[0], ksize[1], stride[0], stride[1], padding[0], padding[1],
+                                                  int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
+            else:
+                check(lib.cnk_bn_bwd_maxpool(_p(dy), _p(idx), _p(x), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                             _p(dx), _p(dg_buf), _p(db_buf), int(direct), N, H, W, C, ksize[0], ksize[1],
+                                             stride[0], stride[1], padding[0], padding[1], int(ctx.relu), _dtype_code(x),
+                                             _p(ws), ws.numel(), _stream()))
         else:
             da = torch.empty_like(x, memory_format=CL)
             check(lib.cnk_maxpool2d_bwd(_p(dy), _p(idx), _p(da), N, H, W, C, ksize[0], ksize[1], stride[0], stride[1],

@@ -220,6 +220,11 @@ int cnk_maxpool2d_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N
 int cnk_maxpool2d_fwd_bn(const void* x, const float* scale, const float* shift, int relu, void* y, uint8_t* idx,
                          int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
                          int32_t ph, int32_t pw, int dtype, void* stream);
+/* The same pass, also keeping x_at_max [N][Ho][Wo][C] (dtype): the INPUT value x at each window's arg-max, for
+ * cnk_bn_bwd_maxpool_kept. */
+int cnk_maxpool2d_fwd_bn_keep(const void* x, const float* scale, const float* shift, int relu, void* y, uint8_t* idx,
+                              void* x_at_max, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw,
+                              int32_t sh, int32_t sw, int32_t ph, int32_t pw, int dtype, void* stream);
 
 /* Backward of that pair in one call, for pools where at most 2 x 2 windows cover an element (kh <= 2*sh, kw <= 2*sw:
  * the 3x3/2 stem pool, VGG's 2x2/2): cnk_bn_bwd whose incoming gradient is max-pool-backward(dy_pooled, argmax), gathered
@@ -233,6 +238,15 @@ int cnk_bn_bwd_maxpool(const void* dy_pooled, const uint8_t* argmax, const void*
                        float* dbeta, int accumulate, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw,
                        int32_t sh, int32_t sw, int32_t ph, int32_t pw, int relu, int dtype, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The same backward with the inputs kept by cnk_maxpool2d_fwd_bn_keep: the pooled gradient only reaches arg-max elements,
+ * so the reduction pass (dgamma, dbeta and the coefficients of dx) runs over dy_pooled and x_at_max -- a quarter of the
+ * bytes of the gather over x for a stride-2 pool (stride-2 pools with <= 2 x 2 covering windows; other geometries ignore
+ * x_at_max); the sums equal cnk_bn_bwd_maxpool's up to fp32 summation order.  dx as before. */
+int cnk_bn_bwd_maxpool_kept(const void* dy_pooled, const uint8_t* argmax, const void* x, const void* x_at_max,
+                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                            void* dx, float* dgamma, float* dbeta, int accumulate, int32_t N, int32_t H, int32_t W,
+                            int32_t C, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw, int relu,
+                            int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.ReLU (basemodel.py:1012,1065) and the block-level  output += identity; F.relu(output)
  * (resnet.py:151-154,191-194) as stand-alone ops for unfused use. */

@@ -865,3 +865,70 @@ def test_weight_stationary_kernel_fullsize_under_load_is_repeatable():
     for o in got[1:]:
         for k in range(5):
             assert torch.equal(o[k], first[k]), 'launches of one kernel on the same operands differ (mode %d)' % k
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('N,C,H,W,k,p,relu', [
+    (4, 64, 32, 32, 3, 1, 1),          # the ResNet stem pool
+    (3, 64, 15, 18, 3, 1, 1),          # odd sizes: cells without a second row / column
+    (2, 24, 12, 12, 3, 1, 0),          # no ReLU, scalar-free channel count off the 64 grid
+    (4, 128, 16, 16, 2, 0, 1),         # VGG's 2x2 / 2
+    (64, 64, 112, 112, 3, 1, 1),       # the stem at batch 64: many slices
+])
+def test_bn_backward_through_maxpool_with_kept_inputs(N, C, H, W, k, p, relu, dtype):
+    """cnk_maxpool2d_fwd_bn_keep + cnk_bn_bwd_maxpool_kept (round 3): the pooling pass also writes the INPUT value at every
+    window's arg-max, and the backward's reduction pass then runs over the pooled gradient and those values instead of
+    gathering over the whole input.  x_at_max must be exactly x at the position the arg-max byte names; y and idx must
+    equal cnk_maxpool2d_fwd_bn's bit for bit; dgamma / dbeta must equal cnk_bn_bwd_maxpool's up to the fp32 summation
+    order, dx up to the coefficients that follow from them."""
+    _lib, lib, cnt = _lib_and_counter()
+    code = _lib.CNK_F32 if dtype == 'f32' else _lib.CNK_BF16
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    s = 2
+    g = torch.Generator().manual_seed(31 + C + H)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).to(tdt).cuda()
+    dyp = torch.randn(N, Ho, Wo, C, generator=g).to(tdt).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C, generator=g) * 0.2).cuda()
+    M = N * H * W
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nws = lib.cnk_bn_workspace_bytes(M, C)
+    ws = torch.empty(nws // 4 + 4, dtype=torch.float32, device='cuda')
+    sm, si = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    assert lib.cnk_bn_fwd_train(P(x), P(gamma), P(beta), None, None, None, None, None, P(sm), P(si), None, 0, M, C, 1e-5, 0.1,
+                                relu, code, P(ws), nws, st) == 0, lib.cnk_last_error()
+    scale, shift = ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(ws.data_ptr() + 4 * C)
+    y0, y1 = (torch.empty(N, Ho, Wo, C, dtype=tdt, device='cuda') for _ in range(2))
+    i0, i1 = (torch.full((N, Ho, Wo, C), 255, dtype=torch.uint8, device='cuda') for _ in range(2))
+    xm = torch.full((N, Ho, Wo, C), float('nan'), dtype=tdt, device='cuda')
+    assert lib.cnk_maxpool2d_fwd_bn(P(x), scale, shift, relu, P(y0), P(i0), N, H, W, C, k, k, s, s, p, p, code, st) == 0, lib.cnk_last_error()
+    assert lib.cnk_maxpool2d_fwd_bn_keep(P(x), scale, shift, relu, P(y1), P(i1), P(xm), N, H, W, C, k, k, s, s, p, p, code, st) == 0, lib.cnk_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(i0, i1)
+    # x at the arg-max: window (ho, wo), tap byte t -> (ho*s - p + t // k, wo*s - p + t % k)
+    t = i1.long()
+    hh = (torch.arange(Ho, device='cuda') * s - p).view(1, Ho, 1, 1) + t // k
+    wwi = (torch.arange(Wo, device='cuda') * s - p).view(1, 1, Wo, 1) + t % k
+    assert (hh >= 0).all() and (hh < H).all() and (wwi >= 0).all() and (wwi < W).all()
+    nn_ = torch.arange(N, device='cuda').view(N, 1, 1, 1).expand_as(t)
+    cc_ = torch.arange(C, device='cuda').view(1, 1, 1, C).expand_as(t)
+    assert torch.equal(xm, x[nn_, hh, wwi, cc_])
+    outs = {}
+    for name in ('gather', 'kept', 'kept2'):
+        dx, dg, db = torch.full_like(x, 3.0), torch.full((C,), 5.0, device='cuda'), torch.full((C,), 5.0, device='cuda')
+        if name == 'gather':
+            rc = lib.cnk_bn_bwd_maxpool(P(dyp), P(i1), P(x), P(gamma), P(beta), P(sm), P(si), P(dx), P(dg), P(db), 0, N, H, W, C,
+                                        k, k, s, s, p, p, relu, code, P(ws), nws, st)
+        else:
+            rc = lib.cnk_bn_bwd_maxpool_kept(P(dyp), P(i1), P(x), P(xm), P(gamma), P(beta), P(sm), P(si), P(dx), P(dg), P(db), 0,
+                                             N, H, W, C, k, k, s, s, p, p, relu, code, P(ws), nws, st)
+        assert rc == 0, lib.cnk_last_error()
+        torch.cuda.synchronize()
+        outs[name] = (dx, dg, db)
+    for a, b in zip(outs['kept'], outs['kept2']):
+        assert torch.equal(a, b)                                              # deterministic
+    (dx0, dg0, db0), (dx1, dg1, db1) = outs['gather'], outs['kept']
+    assert ((dg1 - dg0).abs().max() / dg0.abs().max()).item() < (2e-5 if dtype == 'f32' else 2e-5)
+    assert ((db1 - db0).abs().max() / db0.abs().max()).item() < 2e-5
+    assert rel_l2(host(dx1), host(dx0)) < (1e-5 if dtype == 'f32' else 2e-3)
