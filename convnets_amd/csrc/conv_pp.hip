@@ -543,7 +543,6 @@ __device__ __forceinline__ void pp_epilogue(const PPParams& p, ST& st, unsigned 
             float* red = (float*)stg;                                   // [16][32]
             float S = 0.f, Q = 0.f;
             const int chn = lane & 31, half = lane >> 5;
-#if !(WS_ABL & 64)
             // column ^ (row & 7): the 8 rows of a 32-lane half land on 8 different banks per (cc, e) instead of one
             const int wbase = crow * 32 + ((cc * 8) | (crow & 7));
 #pragma unroll
@@ -556,21 +555,10 @@ __device__ __forceinline__ void pp_epilogue(const PPParams& p, ST& st, unsigned 
             for (int r = 0; r < 8; ++r) Q += red[(half * 8 + r) * 32 + (chn ^ r)];
             S += __shfl_xor(S, 32, 64);
             Q += __shfl_xor(Q, 32, 64);
-#else
-            (void)red; (void)half;
-#endif
-#if (WS_ABL & 64)
-            S = s8[0] + s8[1] + s8[2] + s8[3] + s8[4] + s8[5] + s8[6] + s8[7];
-            Q = q8[0] + q8[1] + q8[2] + q8[3] + q8[4] + q8[5] + q8[6] + q8[7];
-#endif
             const int ch = cb + chn;
             const int nvalid = min(CFG::WROWS, p.M - R0);
             const int slice = st.tile_m * CFG::GM + st.wm;
-#if (WS_ABL & 32)
-            if (lane < 32 && nvalid > 0 && p.M < 0) {
-#else
             if (lane < 32 && nvalid > 0) {
-#endif
                 if (bnf) {
                     pp_store8(p.bnf_partial + ((size_t)(p.bnf_tile0 + slice) * p.Nout + ch) * 2, S, Q * is_fin);
                 } else {
