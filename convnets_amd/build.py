@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libcnk.so')
-SOURCES = ['api.hip', 'conv_igemm.hip', 'conv_pp.hip', 'conv_gemm1x1.hip', 'conv_wgrad.hip', 'conv_wgrad3.hip', 'conv_direct.hip', 'conv_smallc.hip', 'conv_rowpatch.hip', 'bn.hip', 'misc.hip', 'head.hip', 'dwconv.hip', 'sk.hip']
+SOURCES = ['api.hip', 'conv_igemm.hip', 'conv_pp.hip', 'conv_gemm1x1.hip', 'bnfold.hip', 'conv_wgrad.hip', 'conv_wgrad3.hip', 'conv_direct.hip', 'conv_smallc.hip', 'conv_rowpatch.hip', 'bn.hip', 'misc.hip', 'head.hip', 'dwconv.hip', 'sk.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-ffp-contract=off']
 

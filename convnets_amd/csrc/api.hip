@@ -17,6 +17,11 @@ size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
+int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, hipStream_t s);
+bool bnfold_supported(const cnk_conv_desc* d);
+size_t bnfold_image_bytes(const cnk_conv_desc* d);
+int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s);
+int bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, float* ws, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
 bool dwconv_supported(const cnk_conv_desc* d);
 int dwconv_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y, hipStream_t s);
@@ -57,7 +62,7 @@ bool wgrad3x3_supported(const cnk_conv_desc* d);
 size_t wgrad3x3_workspace(const cnk_conv_desc* d);
 int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
-int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s, const WgradFold* fold = nullptr);
 int direct_fwd(const cnk_conv_desc* d, const void* x, const void* w_t, const float* bias, void* y, hipStream_t s);
 int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend, hipStream_t s);
 size_t direct_wgrad_workspace(const cnk_conv_desc* d);
@@ -450,6 +455,62 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
         return colsum(dy, dbias, (int64_t)d->N * Ho * Wo, d->Cout, d->dtype, accumulate, (char*)workspace + a, workspace_bytes - a, S(stream));
     }
     return 0;
+}
+
+int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d) {
+    return check_desc(d, "cnk_conv2d_bnfold_supported") == 0 && bnfold_supported(d) && igemm_supported(d, CNK_PASS_DGRAD) &&
+           wgrad_mfma_supported(d);
+}
+
+size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d) { return bnfold_image_bytes(d); }
+
+int cnk_bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* save_invstd, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int32_t C, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(ext_partial && ext_slices > 0 && gamma && save_invstd && dgamma && dbeta && coef, "cnk_bn_bwd_coef: null pointer");
+    CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd_coef: empty tensor");
+    CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd_coef: workspace too small");
+    return bn_bwd_coef(ext_partial, ext_slices, gamma, save_invstd, dgamma, dbeta, accumulate, coef, M, C, (float*)workspace, S(stream));
+}
+
+int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean, const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_bnfold_prepare")) return rc;
+    CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_bnfold_prepare: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
+    CNK_CHECK_ARG(w && w_dgrad && save_mean && save_invstd && coef && w_fold && bias_fold, "cnk_conv2d_bnfold_prepare: null pointer");
+    return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef, w_fold, bias_fold, S(stream));
+}
+
+int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_dgrad_bnfold")) return rc;
+    CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_dgrad_bnfold: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
+    CNK_CHECK_ARG(g && x && w_fold && bias_fold && dx, "cnk_conv2d_dgrad_bnfold: null pointer");
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    const double px = (double)d->N * d->H * d->W;
+    fl += 2.0 * px * d->Cin * d->Cin;                                   // the second K segment
+    by += px * d->Cin * esize(d->dtype);                                // ... reads the conv input
+    if (bn) {
+        by += px * d->Cin * esize(d->dtype);
+        CNK_CHECK_ARG(cnk_conv2d_dgrad_bn_slices(d) > 0, "cnk_conv2d_dgrad_bnfold: this conv shape cannot fuse the BN backward (cnk_conv2d_dgrad_bn_slices == 0)");
+        CNK_CHECK_ARG(bn->x && bn->mean && bn->invstd && bn->partial, "cnk_conv2d_dgrad_bnfold: bn fuse: null pointer");
+        CNK_CHECK_ARG(!bn->relu || bn->relu_mask || (bn->gamma && bn->beta), "cnk_conv2d_dgrad_bnfold: bn fuse: ReLU without a mask needs gamma and beta");
+    }
+    ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
+    return igemm_dgrad_bnfold(d, g, x, w_fold, bias_fold, dx, bn, S(stream));
+}
+
+int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_wgrad_bnfold")) return rc;
+    CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_wgrad_bnfold: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
+    CNK_CHECK_ARG(g && y && x && save_mean && save_invstd && coef && dw, "cnk_conv2d_wgrad_bnfold: null pointer");
+    const size_t slab = ((size_t)d->Cout * d->Cin * sizeof(float) + 255) & ~(size_t)255;
+    CNK_CHECK_ARG(workspace && workspace_bytes >= slab, "cnk_conv2d_wgrad_bnfold: workspace too small (%zu < %zu)", workspace_bytes, slab);
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    by += (double)d->N * d->H * d->W * d->Cout * esize(d->dtype);       // the BN input is read beside the gradient
+    ProfScope ps(conv_cls(d, 2), S(stream), fl, by);
+    const size_t planned = wgrad_mfma_workspace(d);
+    const size_t avail = workspace_bytes & ~(size_t)255;
+    const WgradFold fold = {y, coef, save_mean, save_invstd};
+    return wgrad_mfma(d, g, x, dw, accumulate, workspace, avail < planned ? avail : planned, S(stream), &fold);
 }
 
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(M, C); }

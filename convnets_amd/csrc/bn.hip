@@ -1245,6 +1245,32 @@ int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* ma
     return bn_bwd_t<float, 1>(dy, x, y, mask, gamma, beta, sm, si, dx, dres, dgamma, dbeta, accumulate, ep, es, M, C, relu, ws, s);
 }
 
+// The finalisation half of the backward alone (cnk_bn_bwd_coef): dgamma / dbeta and the three coefficient vectors of
+//   dx = A * (dy' - B1 - xhat * B2),  A = gamma * invstd, B1 = mean(dy'), B2 = mean(dy' * xhat)
+// from the partial sums a consumer conv's data-gradient epilogue left (cnk_bn_bwd_fuse).  The apply pass is not run: the
+// caller folds it into the backward of the 1x1 conv in front of this layer (cnk_conv2d_dgrad_bnfold / _wgrad_bnfold).
+int bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* si, float* dgamma, float* dbeta,
+                int accumulate, float* coef, int64_t M, int C, float* ws, hipStream_t s) {
+    const SliceGeom g = make_geom(M, C, C % 8 == 0 ? 8 : 1);          // (scratch capacity only, as bn_bwd_t<bf16, 8>)
+    float* coefA = coef;
+    float* coefB1 = coef + C;
+    float* coefB2 = coef + 2 * (size_t)C;
+    float* scratch = ws + ws_partials_off(C);
+    const float* ep = ext_partial;
+    int nslices = (int)ext_slices;
+    const BnFinalBwd fin = {gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate};
+    const int fused_final = bn_merge_final(ep, nslices, C, M, scratch, (int64_t)g.slices * C * 3, fin, s);
+    if (fused_final < 0) return -fused_final;
+    if (!fused_final) {
+        if (int rc = bn_premerge<2>(ep, nslices, C, scratch, (int64_t)g.slices * C * 3, s)) return rc;
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, ep, nslices, C, M, gamma, si, dgamma, dbeta, coefA,
+                           coefB1, coefB2, accumulate);
+        CNK_CHECK_LAUNCH("bn_bwd_final");
+        cnk_count(CNK_CNT_BN_FINAL_LAUNCH);
+    }
+    return 0;
+}
+
 namespace {
 
 // Stride-2 pools (every pool of the reference's models): one thread owns a 2 x 2 cell of input elements.  The <= 2 x 2

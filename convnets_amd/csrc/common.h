@@ -206,7 +206,8 @@ int pp3x3_launch(const PPArgs& a, hipStream_t s);
 int gemm1x1_pick(int64_t M, int K, int Nout, int full);          // 0: no; 2 / 4: column blocks per wave
 int64_t gemm1x1_slices(int64_t M);
 struct G1Args {
-    const void* a; const void* b; void* c;            // [M][K], [Nout][K], [M][Nout]  (bf16)
+    const void* a; const void* b; void* c;            // [M][K], [Nout][K + K2], [M][Nout]  (bf16)
+    const void* a2; int K2;                           // optional second K segment [M][K2] (nullptr / 0: none)
     const float* bias; float* stats;
     const void* addend; const unsigned char* addend_mask;
     const void* bnf_x; const float* bnf_mean; const float* bnf_invstd; const float* bnf_gamma; const float* bnf_beta;
@@ -215,6 +216,14 @@ struct G1Args {
     double algo_flops, algo_bytes;
 };
 int gemm1x1_launch(int nj, const G1Args& a, hipStream_t s);
+
+// cnk_conv2d_wgrad_bnfold: the BN layer behind the conv whose backward apply pass runs inside the weight-gradient kernel's staging
+struct WgradFold {
+    const void* y;            // conv output = BN input [M][Cout]
+    const float* coef;        // [3][Cout] (cnk_bn_bwd_coef)
+    const float* mean;
+    const float* invstd;
+};
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int conv_groups(const cnk_conv_desc* d) { return d->groups > 1 ? d->groups : 1; }

@@ -53,7 +53,8 @@ typedef __attribute__((address_space(3))) unsigned char g1_lds_u8;
 
 struct G1Params {
     const bf16* a;          // [M][K]
-    const bf16* b;          // [Nout][K]
+    const bf16* a2;         // optional second K segment [M][K2] (the loop then walks K + K2; nullptr: none)
+    const bf16* b;          // [Nout][K + K2]
     bf16* c;                // [M][Nout]
     const float* bias;      // [Nout] or nullptr
     float* stats;           // [tiles_m][Nout][3] or nullptr
@@ -69,7 +70,7 @@ struct G1Params {
     const unsigned char* bnf_mask;
     float* bnf_partial;     // [bnf_tile0 + tiles_m][Nout][2]
     int bnf_relu, bnf_tile0;
-    int M, K, Nout, tiles_m, tiles_n, nk;
+    int M, K, K2, Nout, tiles_m, tiles_n, nk;
 };
 
 __device__ __forceinline__ void g1_dma16(const void* g, uint32_t lds_addr) {        // M0 saved / restored inside
@@ -114,19 +115,30 @@ __global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_ke
         alive[h] = m0 + row < p.M;
         asrc[h] = alive[h] ? (const unsigned char*)(p.a + (size_t)(m0 + row) * p.K + logical * 8) : (const unsigned char*)g1_zero16;
     }
+    // second K segment (p.a2): the A rows continue in another matrix after nk1 steps; the B rows are K + K2 long
+    const int nk1 = p.K / G1_KC;
+    const unsigned char* asrc2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (wave + 8 * h) * 16 + prow;
+        const int logical = pslot ^ ((row >> 2) & 3);
+        asrc2[h] = (alive[h] && p.a2) ? (const unsigned char*)(p.a2 + (size_t)(m0 + row) * p.K2 + logical * 8) - (size_t)nk1 * (G1_KC * 2)
+                                      : (const unsigned char*)g1_zero16;
+    }
     const unsigned char* bsrc[BPW];
 #pragma unroll
     for (int h = 0; h < BPW; ++h) {
         const int row = (wave + 8 * h) * 16 + prow;
         const int logical = pslot ^ ((row >> 2) & 3);
-        bsrc[h] = (const unsigned char*)(p.b + (size_t)(n0 + row) * p.K + logical * 8);
+        bsrc[h] = (const unsigned char*)(p.b + (size_t)(n0 + row) * (p.K + p.K2) + logical * 8);
     }
     auto issue = [&](int k) {
         const uint32_t sb = lds0 + (uint32_t)(k % NST) * STAGE;
         const size_t ko = (size_t)k * (G1_KC * 2);
         if (G1_ABL & 2) return;
-        g1_dma16(alive[0] ? asrc[0] + ko : asrc[0], sb + (uint32_t)wave * 1024);
-        g1_dma16(alive[1] ? asrc[1] + ko : asrc[1], sb + (uint32_t)(wave + 8) * 1024);
+        const bool seg2 = k >= nk1;                              // (uniform)
+        g1_dma16(alive[0] ? (seg2 ? asrc2[0] : asrc[0]) + ko : asrc[0], sb + (uint32_t)wave * 1024);
+        g1_dma16(alive[1] ? (seg2 ? asrc2[1] : asrc[1]) + ko : asrc[1], sb + (uint32_t)(wave + 8) * 1024);
 #pragma unroll
         for (int h = 0; h < BPW; ++h) g1_dma16(bsrc[h] + ko, sb + G1_ASTAGE + (uint32_t)(wave + 8 * h) * 1024);
     };
@@ -154,6 +166,19 @@ __global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_ke
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // launches with a second K segment (the folded BN backward) take their bias as the accumulators' start value: the loads are
+    // issued here, under the ring fill, not as dependent round trips in the epilogue
+    const bool bias_first = p.a2 != nullptr && p.bias != nullptr;
+    if (bias_first) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 b4 = *(const f32x4*)(p.bias + n0 + wn * (32 * NJ) + j * 32 + 8 * gq + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][j][4 * gq + e] = acc[1][j][4 * gq + e] = b4[e];
+            }
+    }
 
     // ---- main loop: one barrier per step.  (A ping-pong variant -- two wave groups half a step apart, two barriers per step,
     // fragments read in one phase and multiplied in the other, as conv_pp.hip does for the 3x3 -- measured 5-10 % slower
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_ke
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
-                if (p.bias) {
+                if (p.bias && !bias_first) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += p.bias[n0 + wn * (32 * NJ) + col + e];
                 }
@@ -410,12 +435,13 @@ static int gemm1x1_launch_t(const G1Params& p0, double algo_flops, double algo_b
 
 int gemm1x1_launch(int nj, const G1Args& a, hipStream_t s) {
     G1Params p = {};
-    p.a = (const bf16*)a.a; p.b = (const bf16*)a.b; p.c = (bf16*)a.c; p.bias = a.bias; p.stats = a.stats;
+    p.a = (const bf16*)a.a; p.a2 = (const bf16*)a.a2; p.b = (const bf16*)a.b; p.c = (bf16*)a.c; p.bias = a.bias; p.stats = a.stats;
     p.addend = (const bf16*)a.addend; p.addend_mask = a.addend_mask;
     p.bnf_x = (const bf16*)a.bnf_x; p.bnf_mean = a.bnf_mean; p.bnf_invstd = a.bnf_invstd; p.bnf_gamma = a.bnf_gamma;
     p.bnf_beta = a.bnf_beta; p.bnf_mask = a.bnf_mask; p.bnf_partial = a.bnf_partial; p.bnf_relu = a.bnf_relu; p.bnf_tile0 = a.bnf_tile0;
-    p.M = (int)a.M; p.K = a.K; p.Nout = a.Nout;
-    p.tiles_m = (int)((a.M + G1_BM - 1) / G1_BM); p.tiles_n = 0; p.nk = a.K / G1_KC;
+    p.M = (int)a.M; p.K = a.K; p.K2 = a.a2 ? a.K2 : 0; p.Nout = a.Nout;
+    CNK_CHECK_ARG(p.K2 % G1_KC == 0, "gemm1x1: second K segment off the 32-channel grid");
+    p.tiles_m = (int)((a.M + G1_BM - 1) / G1_BM); p.tiles_n = 0; p.nk = (p.K + p.K2) / G1_KC;
     CNK_CHECK_ARG(!(p.stats && (p.addend || p.bnf_x)), "gemm1x1: statistics partials and data-gradient side operands are exclusive");
     return nj == 4 ? gemm1x1_launch_t<4>(p, a.algo_flops, a.algo_bytes, s) : gemm1x1_launch_t<2>(p, a.algo_flops, a.algo_bytes, s);
 }

@@ -36,6 +36,11 @@ struct GatherParams {
     const void* wpk;
     void* dst;
     const float* bias;
+    // optional second K segment of a dense 1x1 launch (CAT kernels): C2 more channels per pixel read from src2 [M][C2]; the
+    // weight image rows are then [ntaps * Cpad + C2] long.  Used by the data gradient that carries the backward of the BN
+    // layer behind the conv (cnk_conv2d_dgrad_bnfold): K = [dy' | conv input].
+    const void* src2;
+    int C2;
     const void* addend;      // optional tensor shaped like dst: dst = conv + addend (fused grad sum)
     const unsigned char* addend_mask;   // optional packed ReLU mask (1 byte per 16-B vector) gating addend
     float* stats;            // optional [tiles_m][Nout][3] BN partials (n, mean, M2) of the OUTPUT
@@ -91,7 +96,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // Shared epilogue of the implicit-GEMM kernels (see the comment inside): bias, LDS-staged
 // coalesced row stores, optional gradient addend (+ReLU mask), optional BN statistics partials.
 // EDGE: Nout is any multiple of one 16-byte vector (not of BN): the last n-tile has ncols < BN valid columns.
-template <typename T, int BN, bool EDGE = false>
+template <typename T, int BN, bool EDGE = false, bool BIAS_DONE = false>
 __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned char* smem,
                                                const int* row_dst, f32x16 (&acc)[2][BN / 64],
                                                int tile_m, int tile_n, int tid, int wm, int wn,
@@ -128,7 +133,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
-                if (p.bias && (!EDGE || col < ncols)) {          // (Nout % 4 == 0: a group of four is all in or all out)
+                if (!BIAS_DONE && p.bias && (!EDGE || col < ncols)) {          // (Nout % 4 == 0: a group of four is all in or all out)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += p.bias[tile_n * BN + col + e];
                 }
@@ -305,7 +310,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
 
 // EDGE: channel counts that are multiples of one 16-byte vector but not of the K step / BN: chunks past C fetch
 // zeros, the weight image is zero-padded to [tiles_n*BN][taps][Cpad], the epilogue skips the missing columns.
-template <typename T, int BN, bool EDGE = false>
+template <typename T, int BN, bool EDGE = false, bool CAT = false>
 __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
     constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
@@ -369,8 +374,9 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     // grouped conv (block-diagonal image): this 64-wide n-tile only sees its own 64 input channels
     const int csteps = p.chunked ? 64 / KSTEP : p.Cpad / KSTEP;
     const int cs0 = p.chunked ? tile_n * (64 / KSTEP) : 0;
-    const int nk = p.ntaps * csteps;
-    const size_t wrow = (size_t)p.ntaps * p.Cpad;
+    const int nk1 = p.ntaps * csteps;
+    const int nk = CAT ? nk1 + p.C2 / KSTEP : nk1;
+    const size_t wrow = (size_t)p.ntaps * p.Cpad + (CAT ? p.C2 : 0);
 
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -380,6 +386,18 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int l31 = lane & 31, lh = lane >> 5;
+    if constexpr (CAT) {
+        // the bias goes in as the accumulators' start value: its loads are issued here, under the first K step's DMAs, instead of
+        // as dependent round trips inside the epilogue (where they cost the 56x56 launches +60 %); CAT launches always carry one
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 b4 = *(const f32x4*)(p.bias + tile_n * BN + wn * (BN / 2) + j * 32 + 8 * gq + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][j][4 * gq + e] = acc[1][j][4 * gq + e] = b4[e];
+            }
+    }
     auto compute = [&]() {
         const unsigned char* Ab = As;
         const unsigned char* Bb = Bs;
@@ -411,12 +429,19 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     // loop that beat every double-buffered / register-staged variant tried (2 or 3 workgroups/CU).
     lds_u8* As3 = (lds_u8*)As;
     lds_u8* Bs3 = (lds_u8*)Bs;
-    int ld_t = 0, ld_cs = 0;
+    int ld_t = 0, ld_cs = 0, ld_k = 0;
     auto issue = [&]() {
-        const int t = ld_t, cb = (cs0 + ld_cs) * KSTEP;
-        if (++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
-        const int tp = tap_tab[t];                   // LDS (uniform address: broadcast), lgkmcnt only
+        // (CAT: after the nk1 steps of the first segment the same pixel rows are read from src2 -- dense 1x1, no taps, no
+        // padding -- and the weight rows continue behind the first segment; everything that differs is wave-uniform)
+        const bool seg2 = CAT && ld_k >= nk1;
+        const int t = ld_t, cb = seg2 ? (ld_k - nk1) * KSTEP : (cs0 + ld_cs) * KSTEP;
+        if constexpr (CAT) ++ld_k;
+        if (!seg2 && ++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
+        const int tp = seg2 ? 0 : tap_tab[t];        // LDS (uniform address: broadcast), lgkmcnt only
         const int dh = tp >> 16, dw = (int)(short)(tp & 0xffff);
+        const T* sp = seg2 ? (const T*)p.src2 : src;
+        const int sC = seg2 ? p.C2 : p.C;
+        const size_t wo = seg2 ? (size_t)p.ntaps * p.Cpad + cb : (size_t)t * p.Cpad + cb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = lrow + 32 * i;
@@ -424,7 +449,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
             const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
             const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW &&
                             (!EDGE || cb + c * PER16 < p.C);
-            const T* gp = ok ? src + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + cb + c * PER16
+            const T* gp = ok ? sp + ((size_t)(a_base[i] + ih) * p.IW + iw) * sC + cb + c * PER16
                              : (const T*)cnk_zero16;
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
         }
@@ -432,7 +457,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
         for (int i = 0; i < B_LOADS; ++i) {
             const int r = lrow + 32 * i;
             const int c = chunk ^ ((r >> 1) & 7);
-            const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + (size_t)t * p.Cpad + cb + c * PER16;
+            const T* gp = wpk + (size_t)(tile_n * BN + r) * wrow + wo + c * PER16;
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(Bs3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
         }
     };
@@ -449,7 +474,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     }
     if (nk == 0) __syncthreads();
 
-    igemm_epilogue<T, BN, EDGE>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
+    igemm_epilogue<T, BN, EDGE, CAT>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
 
 // 3x3 / stride 1 / "same" convolutions (forward, and the data gradient of such a conv): halo reuse.
@@ -745,16 +770,17 @@ __global__ __launch_bounds__(256, 2) void igemm_halo3x3_pf_kernel(const GatherPa
 
 // algorithmic cost of ONE launch: the source tensor and the weight image read once, the output written once,
 // plus the fused side operands (gradient addend, the BN layer's input for its backward reduction)
-static double gather_flops(const GatherParams& p) { return 2.0 * p.M * p.Nout * (double)p.C * p.ntaps; }
+static double gather_flops(const GatherParams& p) { return 2.0 * p.M * p.Nout * ((double)p.C * p.ntaps + (p.src2 ? p.C2 : 0)); }
 static double gather_bytes(const GatherParams& p, size_t esz) {
     double out = (double)p.M * p.Nout;
     double e = (double)p.N * p.IH * p.IW * p.C + out + (double)p.Nout * p.ntaps * p.C;
+    if (p.src2) e += (double)p.M * p.C2 + (double)p.Nout * p.C2;
     if (p.addend) e += out;
     if (p.bnf_x) e += out;
     return e * esz;
 }
 
-template <typename T, int BN, bool EDGE = false> int launch_gather(const GatherParams& p, hipStream_t s) {
+template <typename T, int BN, bool EDGE = false, bool CAT = false> int launch_gather(const GatherParams& p, hipStream_t s) {
     size_t pipe = BM * 128 + BN * 128;
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
     size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);     // aliases the staged tile
@@ -762,7 +788,7 @@ template <typename T, int BN, bool EDGE = false> int launch_gather(const GatherP
     size_t lds = IG_HDR + (pipe > epi ? pipe : epi);
     ProfScope kscope(CNK_KF_GATHER, s, gather_flops(p), gather_bytes(p, sizeof(T)));
     cnk_count(CNK_CNT_GATHER);
-    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE, CAT>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
 }
@@ -845,10 +871,13 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         a.algo_bytes = gather_bytes(p, sizeof(T));
         return pp3x3_launch(a, s);
     }
+    if (p.src2) CNK_CHECK_ARG(sizeof(T) == 2 && !p.chunked && dense_1x1(p) && p.C2 % KS == 0 && !p.relu && !p.stats && p.bias,
+                              "igemm: a second K segment needs a dense bf16 1x1 launch with C2 on the K-step grid");
     if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.relu && !(p.stats && (p.addend || p.bnf_x)))
-        if (const int nj = gemm1x1_pick(p.M, p.C, p.Nout, p.addend || p.bnf_x)) {
+        if (const int nj = gemm1x1_pick(p.M, p.C + (p.src2 ? p.C2 : 0), p.Nout, p.addend || p.bnf_x)) {
             G1Args a = {};
             a.a = p.src; a.b = p.wpk; a.c = p.dst; a.bias = p.bias; a.stats = p.stats;
+            a.a2 = p.src2; a.K2 = p.src2 ? p.C2 : 0;
             a.addend = p.addend; a.addend_mask = p.addend_mask;
             a.bnf_x = p.bnf_x; a.bnf_mean = p.bnf_mean; a.bnf_invstd = p.bnf_invstd; a.bnf_gamma = p.bnf_gamma; a.bnf_beta = p.bnf_beta;
             a.bnf_mask = p.bnf_mask; a.bnf_partial = p.bnf_partial; a.bnf_relu = p.bnf_relu; a.bnf_tile0 = p.bnf_tile0;
@@ -866,6 +895,8 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         size_t lds = use128 ? halo_lds<T, 128>(p) : halo_lds<T, 64>(p);
         if (lds <= (size_t)(igemm_halo_pf(p.tiles_total, bn) ? 80 : 53) * 1024) return use128 ? launch_halo<T, 128>(p, s) : launch_halo<T, 64>(p, s);
     }
+    if constexpr (sizeof(T) == 2)
+        if (p.src2) return use128 ? launch_gather<T, 128, false, true>(p, s) : launch_gather<T, 64, false, true>(p, s);
     return use128 ? launch_gather<T, 128>(p, s) : launch_gather<T, 64>(p, s);
 }
 
@@ -996,6 +1027,28 @@ int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     int64_t n = 0;
     for (int c = 0; c < nc; ++c) n += ceil_div64((int64_t)d->N * cls[c].OH * cls[c].OW, BM);
     return n;
+}
+
+// Data gradient of a dense 1x1 / stride-1 conv with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
+// K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c.
+int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
+                       void* dx, const cnk_bn_bwd_fuse* bn, hipStream_t s) {
+    GatherParams p = {};
+    p.src = g; p.src2 = x; p.C2 = d->Cin; p.wpk = w_fold; p.dst = dx; p.bias = bias_fold; p.is_dgrad = 1;
+    p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cout;
+    p.OH = d->H; p.OW = d->W; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
+    p.sm_h = 1; p.sm_w = 1; p.dm_h = 1; p.dm_w = 1; p.d_h0 = 0; p.d_w0 = 0;
+    p.ntaps = 1; p.dh[0] = 0; p.dw[0] = 0;
+    p.M = d->N * d->H * d->W;
+    if (p.M == 0) return 0;
+    if (bn) {
+        p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;
+        p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
+        p.bnf_relu = bn->relu; p.bnf_tile0 = 0;
+    }
+    p.fd_ohw = make_fastdiv(d->H * d->W);
+    p.fd_ow = make_fastdiv(d->W);
+    return launch_gather_bn<bf16>(p, s);
 }
 
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,

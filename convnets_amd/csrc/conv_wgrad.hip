@@ -26,6 +26,13 @@ struct WgradParams {
     int tiles_co, tiles_ci, ntaps;
     int diag;               // grouped conv: only the diagonal 64x64 (co chunk, same ci chunk) tiles exist
     FastDiv fd_howo, fd_wo;
+    // FOLD kernels (cnk_conv2d_wgrad_bnfold): `dy` is the gradient w.r.t. the OUTPUT of the BN layer behind this conv (already
+    // ReLU-masked) and the gradient w.r.t. the conv output is formed while the tile is staged, exactly as bn_bwd_apply_kernel
+    // would have written it: dy_conv = A * (dy - B1 - (y - mean) * (invstd * B2)), rounded to bf16.
+    const void* fy;         // the conv output / BN input [M][Cout]
+    const float* fcoef;     // [3][Cout]: A = gamma * invstd, B1 = mean(dy), B2 = mean(dy * xhat)  (cnk_bn_bwd_coef)
+    const float* fmean;
+    const float* finvstd;
 };
 
 template <typename T> struct WgCfg;
@@ -41,7 +48,7 @@ template <> struct WgCfg<float> {
 // WM x WN waves (2 x 2: 256 threads, two workgroups per CU; 4 x 2 / 2 x 4: 512 threads, ONE 256x128 / 128x256 tile per
 // CU -- the kernel is bound by the global -> LDS path (rocprofv3 MFMA-busy 21 % with 64 B/clk/CU demanded at full MFMA
 // rate for 128x128 against ~28 B/clk delivered), and a 256x128 tile moves 25 % fewer bytes per flop).
-template <typename T, int BMW, int BNW, int NBUF, int WM = 2, int WN = 2>
+template <typename T, int BMW, int BNW, int NBUF, int WM = 2, int WN = 2, bool FOLD = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NBUF != 2) ? 3 : 2) void wgrad_mfma_kernel(const WgradParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int PER16 = ElemTraits<T>::PER16;
@@ -83,16 +90,45 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NBUF != 2) ? 3 : 2) 
     const int ks1 = min(p.ksteps, ks0 + p.ksteps_per_split);
 
     u32x4 ra[PASSA], rb[PASSB];
+    // FOLD: this thread always stages the same 16-byte channel group of the dy tile (NT is a multiple of CPRA): its BN-backward
+    // coefficients stay in registers
+    static_assert(!FOLD || (NT % CPRA == 0 && sizeof(T) == 2), "FOLD: bf16, fixed channel group per thread");
+    u32x4 ry[FOLD ? PASSA : 1];
+    unsigned fok = 0;
+    float ka[FOLD ? PER16 : 1], kb1[FOLD ? PER16 : 1], kmu[FOLD ? PER16 : 1], kis[FOLD ? PER16 : 1];
+    if constexpr (FOLD) {
+        const int c0 = tile_co * BMW + (tid % CPRA) * PER16;
+        if (c0 < p.Cout) {
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) {
+                ka[e] = p.fcoef[c0 + e];
+                kb1[e] = p.fcoef[p.Cout + c0 + e];
+                kmu[e] = p.fmean[c0 + e];
+                kis[e] = p.finvstd[c0 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) kis[e] *= p.fcoef[2 * p.Cout + c0 + e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) ka[e] = kb1[e] = kmu[e] = kis[e] = 0.f;
+        }
+    }
     auto load_step = [&](int ks) {
         const int m0 = ks * KP;
+        if constexpr (FOLD) fok = 0;
 #pragma unroll
         for (int i = 0; i < PASSA; ++i) {
             int idx = tid + NT * i, r = idx / CPRA, c = idx - r * CPRA;
             int m = m0 + r;
             u32x4 v = {0, 0, 0, 0};
             // (channel bound: Cout / Cin may be any multiple of one vector; columns past them are zeros)
-            if (m < p.M && tile_co * BMW + c * PER16 < p.Cout)
+            if (m < p.M && tile_co * BMW + c * PER16 < p.Cout) {
                 v = *(const u32x4*)(dy + (size_t)m * p.Cout + tile_co * BMW + c * PER16);
+                if constexpr (FOLD) {
+                    ry[i] = *(const u32x4*)((const T*)p.fy + (size_t)m * p.Cout + tile_co * BMW + c * PER16);
+                    fok |= 1u << i;
+                }
+            }
             ra[i] = v;
         }
 #pragma unroll
@@ -117,6 +153,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NBUF != 2) ? 3 : 2) 
 #pragma unroll
         for (int i = 0; i < PASSA; ++i) {
             int idx = tid + NT * i, r = idx / CPRA, c = idx - r * CPRA;
+            if constexpr (FOLD) {
+                if ((fok >> i) & 1u) {
+                    // same expression, same rounding as bn_bwd_row (bn.hip): the staged tile IS the tensor that kernel would write
+                    const bf16x8 dv = __builtin_bit_cast(bf16x8, ra[i]), yv = __builtin_bit_cast(bf16x8, ry[i]);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e)
+                        o[e] = (bf16)(ka[e] * ((float)dv[e] - kb1[e] - ((float)yv[e] - kmu[e]) * kis[e]));
+                    ra[i] = __builtin_bit_cast(u32x4, o);
+                }
+            }
             *(u32x4*)(As + buf * (KP * ROWA) + r * ROWA + c * 16) = ra[i];
         }
 #pragma unroll
@@ -311,17 +358,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
     }
 }
 
-template <typename T, int BMW, int BNW, int WM = 2, int WN = 2> int launch_wgrad(const WgradParams& p, hipStream_t s) {
+template <typename T, int BMW, int BNW, int WM = 2, int WN = 2, bool FOLD = false> int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int KP = WgCfg<T>::KP;
     size_t lds = 2 * (KP * (BMW * sizeof(T) + WgCfg<T>::PAD) + KP * (BNW * sizeof(T) + WgCfg<T>::PAD));   // double-buffered
     int grid = p.splits * p.tiles_co * p.ntaps * p.tiles_ci;
     // algorithmic bytes: dy and x read once, dw written once (the split-K slabs are implementation traffic: the PMC
     // passes show them, the roofline does not credit them -- ADVICE r02)
     ProfScope kscope(CNK_KF_WGRAD, s, 2.0 * p.M * p.Cout * (double)(p.diag ? BNW : p.Cin) * p.ntaps,
-                     ((double)p.M * p.Cout + (double)p.N * p.H * p.W * p.Cin) * sizeof(T) +
+                     ((double)p.M * p.Cout * (FOLD ? 2 : 1) + (double)p.N * p.H * p.W * p.Cin) * sizeof(T) +
                          (double)p.Cout * p.ntaps * (p.diag ? BNW : p.Cin) * sizeof(float));
-    if (lds > 64 * 1024) CNK_LDS_OPTIN((wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN>), 160 * 1024, "wgrad_mfma");
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN>), dim3(grid), dim3(64 * WM * WN), lds, s, p);
+    if (lds > 64 * 1024) CNK_LDS_OPTIN((wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN, FOLD>), 160 * 1024, "wgrad_mfma");
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, BMW, BNW, 2, WM, WN, FOLD>), dim3(grid), dim3(64 * WM * WN), lds, s, p);
     CNK_CHECK_LAUNCH("wgrad_mfma");
     return 0;
 }
@@ -442,7 +489,7 @@ size_t wgrad_mfma_workspace(const cnk_conv_desc* d) {
 }
 
 int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate,
-               void* ws, size_t ws_bytes, hipStream_t s) {
+               void* ws, size_t ws_bytes, hipStream_t s, const WgradFold* fold) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     WgradParams p = {};
@@ -464,6 +511,16 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     p.fd_wo = make_fastdiv(Wo);
     int rc;
     bool b = d->dtype == CNK_BF16;
+    if (fold) {
+        CNK_CHECK_ARG(b && !grouped && d->Cout % 64 == 0 && d->Cin % 64 == 0, "wgrad_mfma: the folded BN backward needs a dense bf16 conv on the 64-channel grid");
+        p.fy = fold->y; p.fcoef = fold->coef; p.fmean = fold->mean; p.finvstd = fold->invstd;
+        if (bmw == 256) rc = launch_wgrad<bf16, 256, 128, 4, 2, true>(p, s);
+        else if (bnw == 256) rc = launch_wgrad<bf16, 128, 256, 2, 4, true>(p, s);
+        else if (bmw == 128 && bnw == 128) rc = launch_wgrad<bf16, 128, 128, 2, 2, true>(p, s);
+        else if (bmw == 128) rc = launch_wgrad<bf16, 128, 64, 2, 2, true>(p, s);
+        else if (bnw == 128) rc = launch_wgrad<bf16, 64, 128, 2, 2, true>(p, s);
+        else rc = launch_wgrad<bf16, 64, 64, 2, 2, true>(p, s);
+    } else
     if (bmw == 256) rc = launch_wgrad<bf16, 256, 128, 4, 2>(p, s);
     else if (bnw == 256) rc = launch_wgrad<bf16, 128, 256, 2, 4>(p, s);
     else if (bmw == 128 && bnw == 128) rc = b ? launch_wgrad<bf16, 128, 128>(p, s) : launch_wgrad<float, 128, 128>(p, s);

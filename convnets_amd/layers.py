@@ -59,7 +59,7 @@ class Conv2d(nn.Conv2d):
             new.__dict__[k] = ops.PackedWeights() if k == '_packed' else copy.deepcopy(v, memo)
         return new
 
-    def forward(self, x, want_bn_partial=False, link=None):
+    def forward(self, x, want_bn_partial=False, link=None, fold=None):
         if self._depthwise:                      # conv2d_depthwise (basemodel.py:981-997)
             y = ops.DepthwiseConv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
             return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
@@ -76,7 +76,7 @@ class Conv2d(nn.Conv2d):
                                       self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), 1)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
                                   self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups,
-                                  self._dil)
+                                  self._dil, fold)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -87,7 +87,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     # model then bumps every layer's num_batches_tracked with ONE kernel per step, not one per layer
     _deferred_counter = None
 
-    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None):
+    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None, fold=None):
         """pool: the MaxPool2d module that consumes this layer's output (ConvBlock passes it for the stems, training
         mode only): BN, ReLU and the pooling then run as one autograd node and the POOLED tensor is returned."""
         if not (self.affine and self.track_running_stats):
@@ -105,7 +105,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                 rec = ops.BnRecord() if (torch.is_grad_enabled() and x.requires_grad) else None
                 y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
                                              self.running_var, float(self.eps), float(self.momentum),
-                                             bool(relu), partial, link, rec)
+                                             bool(relu), partial, link, rec, fold)
                 if rec is not None and rec.x is not None:
                     y._cnk_bn = rec
             self._stats_epoch = getattr(self, '_stats_epoch', 0) + 1     # running statistics changed
@@ -280,13 +280,16 @@ class ConvBlock(nn.Sequential):
         act = isinstance(mods[-1], ReLU)
         if bn is not None:
             if bn.training:      # the conv epilogue also emits the BN statistics partials
-                y, partial = conv(x, want_bn_partial=True, link=in_link)
+                # (fold: the BN backward's apply pass runs inside this conv's backward where the shape allows, ops.FoldRecord)
+                fold = ops.FoldRecord() if (ops.BN_FOLD and in_link is None and torch.is_grad_enabled()
+                                            and isinstance(conv, Conv2d) and conv.kernel_size == (1, 1)) else None
+                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold)
                 pool = self._linked_pool()
                 if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
                     return bn(y, relu=act, partial=partial, pool=pool)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
-                          link=res_link)
+                          link=res_link, fold=fold if (fold is not None and fold.ok) else None)
             if not torch.is_grad_enabled():
                 # inference: BN folded into the conv, ReLU / residual add in its epilogue (one kernel)
                 fold = self.__dict__.setdefault('_fold', ops.FoldedConv())

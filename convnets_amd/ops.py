@@ -163,7 +163,7 @@ def join_side_streams(device=None):
 # (round 3: six ctypes round trips and a struct construction less per conv call on the host; a ResNet-152 eager step issues
 # ~1,900 launches from Python).  _lib.reload_switches() (tests, A/B tools) moves the epoch and drops them.
 class ConvPlan:
-    __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'accepts_mask')
+    __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'accepts_mask', 'bnfold', 'fold_bytes')
 
 
 _conv_plans = {}
@@ -184,6 +184,8 @@ def conv_plan(x_shape, weight_shape, stride, padding, dtype_code, groups, dilati
         pl.dgrad_slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(d))
         pl.wgrad_ws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), PASS_WGRAD)
         pl.accepts_mask = bool(lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(d)))
+        pl.bnfold = bool(lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)))
+        pl.fold_bytes = lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)) if pl.bnfold else 0
         if len(_conv_plans) > 4096:
             _conv_plans.clear()
         _conv_plans[key] = pl
@@ -232,6 +234,22 @@ class BnRecord:
         self.relu = False
 
 
+class FoldRecord:
+    """Shared by the Conv2dFn and the BatchNormActFn of one conv -> BN pair (layers.ConvBlock.forward; the conv output is a
+    local of that forward, so the BN layer is its only consumer).  For a dense 1x1 / stride-1 bf16 conv the BN backward's apply
+    pass is folded into the conv's own backward (csrc/bnfold.hip): BatchNormActFn.backward then only finalises the partial sums
+    (dgamma, dbeta, the three coefficient vectors), parks them here together with the gradient w.r.t. the BN OUTPUT, and hands
+    that very tensor to autograd as the "gradient" of the conv output; Conv2dFn.backward recognises it (same storage) and runs
+    cnk_conv2d_dgrad_bnfold / cnk_conv2d_wgrad_bnfold.  The [M][Cout] gradient w.r.t. the conv output is never written."""
+    __slots__ = ('ok', 'g', 'y', 'mean', 'invstd', 'coef')
+
+    def __init__(self):
+        self.ok = False                   # set by Conv2dFn.forward when the conv shape can fold
+        self.g = self.y = self.mean = self.invstd = self.coef = None
+
+
+BN_FOLD = os.environ.get('CNK_BN_FOLD', '1') != '0'
+FOLD_COUNTS = {'folded': 0}               # folded conv backward passes (tests read this)
 BN_BWD_FUSE = os.environ.get('CNK_BN_BWD_FUSE', '1') != '0'
 # the same fusion for the stride-1 3x3 convs only (A/B switch, DESIGN.md: break-even per layer, see there)
 BN_BWD_FUSE_3X3 = os.environ.get('CNK_BN_BWD_FUSE_3X3', '1') != '0'
@@ -411,7 +429,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None,
-                bn_rec=None, groups=1, dilation=1):
+                bn_rec=None, groups=1, dilation=1, fold=None):
         """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
         of y emitted by the conv epilogue (None when this conv shape cannot produce them).
         link: optional GradLink shared with the other consumer of x (residual blocks)."""
@@ -439,6 +457,13 @@ class Conv2dFn(torch.autograd.Function):
         ctx.params = (weight, bias)
         ctx.link = link if x_needs_grad else None
         ctx.bn_rec = bn_rec if (x_needs_grad and BN_BWD_FUSE) else None
+        # conv -> BN with the BN backward folded into this conv's backward (FoldRecord): dense 1x1 bf16, no bias, and no
+        # gradient hand-over at the input (the folded data gradient takes no addend)
+        ctx.fold = None
+        if fold is not None and BN_FOLD and plan.bnfold and bias is None and ctx.link is None and w.dtype == torch.float32 \
+                and x_needs_grad and w_dgrad is not None:
+            fold.ok = True
+            ctx.fold = fold
         if want_bn_partial:
             if partial is None:
                 partial = torch.empty(0, device=x.device)         # placeholder: "not available"
@@ -450,11 +475,24 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
         if dy is None:                        # y took no part in the loss
-            return (None,) * 11
+            return (None,) * 12
         x, w = ctx.saved_tensors
         desc = ctx.desc
+        # folded BN backward: dy is the gradient w.r.t. the BN OUTPUT, parked by BatchNormActFn.backward
+        fold, ctx.fold = ctx.fold, None
+        if fold is not None:
+            fold.ok = False
+            if fold.g is None or fold.g.data_ptr() != dy.data_ptr() or fold.g.shape != dy.shape:
+                fold = None
         dy = _nhwc(dy)
         dx = dw = db = None
+        w_fold = bias_fold = None
+        if fold is not None:
+            FOLD_COUNTS['folded'] += 1
+            w_fold = torch.empty(ctx.plan.fold_bytes, dtype=torch.uint8, device=x.device)
+            bias_fold = torch.empty(desc.Cin, dtype=torch.float32, device=x.device)
+            check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(desc), _p(w), _p(ctx.w_dgrad), _p(fold.mean), _p(fold.invstd),
+                                                _p(fold.coef), _p(w_fold), _p(bias_fold), _stream()))
         # dy is complete on the compute stream HERE: the weight gradient (issued below on the second
         # stream) waits for this point only, so it also overlaps this conv's own data gradient
         dy_ready = None
@@ -486,9 +524,13 @@ class Conv2dFn(torch.autograd.Function):
                                               rec.gamma.data_ptr(), rec.beta.data_ptr(),
                                               rec.mask.data_ptr() if rec.mask is not None else None,
                                               partial.data_ptr(), int(rec.relu))
-                check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(out),
-                                           _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None,
-                                           None, 0, _stream()))
+                if fold is not None:           # (ctx.link is None: no addend)
+                    check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(desc), _p(dy), _p(x), _p(w_fold), _p(bias_fold), _p(out),
+                                                      ctypes.byref(fuse) if fuse else None, _stream()))
+                else:
+                    check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(out),
+                                               _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None,
+                                               None, 0, _stream()))
                 if fuse is not None:
                     rec.fused = (out, partial)
                 return out
@@ -516,8 +558,13 @@ class Conv2dFn(torch.autograd.Function):
                     # bound the split-K depth: at least one fp32 slab [Cout][kh][kw][Cin], whole multiples of 256 bytes
                     slab = desc.Cout * (64 if desc.groups > 1 else desc.Cin) * desc.kh * desc.kw * 4
                     budget = max((slab + 255) // 256 * 256, int(nws * share) // 256 * 256)
-                check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
-                                           int(direct), _p(ws), budget, _stream()))
+                if fold is not None:
+                    check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fold.y), _p(x), _p(fold.mean),
+                                                      _p(fold.invstd), _p(fold.coef), _p(dw_buf), int(direct), _p(ws),
+                                                      budget, _stream()))
+                else:
+                    check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
+                                               int(direct), _p(ws), budget, _stream()))
                 if direct:
                     _grad_written(weight)
                     if ctx.has_bias:
@@ -531,10 +578,15 @@ class Conv2dFn(torch.autograd.Function):
                     run_wgrad(WGRAD_SHARE[0])
                 dy.record_stream(side)
                 x.record_stream(side)
+                if fold is not None:
+                    for t in (fold.y, fold.mean, fold.invstd, fold.coef):
+                        t.record_stream(side)
                 _join_at_end_of_backward()
             else:
                 run_wgrad()
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        if fold is not None:
+            fold.g = fold.y = fold.mean = fold.invstd = fold.coef = None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -543,7 +595,7 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu,
-                partial=None, link=None, rec=None):
+                partial=None, link=None, rec=None, fold=None):
         _require_gpu(x)
         lib = _lib.load()
         x_needs_grad = x.requires_grad
@@ -579,6 +631,7 @@ class BatchNormActFn(torch.autograd.Function):
         ctx.params = (gamma, beta)
         ctx.link = link if res_needs_grad else None
         ctx.rec = None
+        ctx.fold = fold if (fold is not None and fold.ok and x_needs_grad and x.dtype == torch.bfloat16) else None
         if rec is not None and x_needs_grad and (mask is not None or residual is None):
             # what a consumer conv needs to run this layer's backward reduction in its dgrad epilogue
             rec.x, rec.mean, rec.invstd, rec.gamma, rec.beta = x, save_mean, save_invstd, gamma.detach(), beta.detach()
@@ -642,7 +695,7 @@ class BatchNormActFn(torch.autograd.Function):
             # identity shortcut: park the residual gradient for the block's first conv, whose
             # dgrad epilogue adds it (falls back to a plain add if this backward is the last one)
             dres = ctx.link.contribute(lambda parked: dres if parked is None else dres + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx, want_res, ext_partial, M, C):
@@ -658,10 +711,20 @@ class BatchNormActFn(torch.autograd.Function):
             dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(bn_sizes(M, C, _dtype_code(x))[0], x.device)
-        check(lib.cnk_bn_bwd(_p(dy), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
-                             _p(dx), None, _p(dg_buf), _p(db_buf), int(direct), _p(ext_partial),
-                             ext_partial.shape[0], M, C, int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(),
-                             _stream()))
+        fold = ctx.fold
+        if fold is not None and fold.ok:
+            # the apply pass is folded into the backward of the 1x1 conv that produced x (FoldRecord): finalise only, and
+            # hand dy itself on as that conv's incoming "gradient"
+            coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+            check(lib.cnk_bn_bwd_coef(_p(ext_partial), ext_partial.shape[0], _p(gamma), _p(save_invstd), _p(dg_buf),
+                                      _p(db_buf), int(direct), _p(coef), M, C, _p(ws), ws.numel(), _stream()))
+            fold.g, fold.y, fold.mean, fold.invstd, fold.coef = dy, x, save_mean, save_invstd, coef
+            dx = dy
+        else:
+            check(lib.cnk_bn_bwd(_p(dy), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                 _p(dx), None, _p(dg_buf), _p(db_buf), int(direct), _p(ext_partial),
+                                 ext_partial.shape[0], M, C, int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(),
+                                 _stream()))
         if direct:
             _grad_written(pg)
             _grad_written(pb)
@@ -670,7 +733,7 @@ class BatchNormActFn(torch.autograd.Function):
             dres = dy
             if ctx.link is not None:
                 dres = ctx.link.contribute(lambda parked: dy if parked is None else dy + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):

@@ -192,6 +192,34 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
                int64_t ext_slices, int64_t M, int32_t C, int relu,
                int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of conv(1x1, stride 1, no bias) -> BatchNorm2d with the BN layer's apply pass FOLDED into the conv's own backward
+ * (conv2d_block, basemodel.py:999-1015, as the bottleneck's last block uses it, resnet.py:172-176; autograd runs the two
+ * backward passes at basemodel.py:278).  The BN backward dy_conv = A (g - B1 - xhat B2) is linear in g (the masked gradient
+ * w.r.t. the BN output) and, because y = W a, in the conv input a, so
+ *     da = [g | a] x [A W ; -W^T diag(A invstd B2) W]  +  c
+ * is ONE GEMM over K = Cout + Cin and the [M][Cout] tensor dy_conv is never written (csrc/bnfold.hip).  Sequence:
+ *   1. a consumer's cnk_conv2d_dgrad with a cnk_bn_bwd_fuse record leaves g (masked) and the partial sums;
+ *   2. cnk_bn_bwd_coef: dgamma / dbeta and coef[3][C] = A | B1 | B2 (fp32) from those partials (no apply pass);
+ *      workspace: cnk_bn_workspace_bytes(M, C);
+ *   3. cnk_conv2d_bnfold_prepare: the per-step weight image w_fold (cnk_conv2d_bnfold_image_bytes) and bias_fold[Cin] from
+ *      the fp32 master weights w [Cout][Cin], the packed data-gradient image w_dgrad and coef;
+ *   4. cnk_conv2d_dgrad_bnfold(g, x = the conv input, ...) -> dx, with the same optional fused BN backward of the layer that
+ *      produced x as cnk_conv2d_dgrad;  cnk_conv2d_wgrad_bnfold(g, y = the conv output, x, ...) -> dw, which forms dy_conv
+ *      while staging its tiles, bit for bit the tensor cnk_bn_bwd would have written (workspace as cnk_conv2d_wgrad).
+ * cnk_conv2d_bnfold_supported: bf16, 1x1, stride 1, no padding, dense, both channel counts multiples of 64. */
+int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d);
+size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d);
+int cnk_bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* save_invstd,
+                    float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int32_t C, void* workspace,
+                    size_t workspace_bytes, void* stream);
+int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean,
+                              const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream);
+int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
+                            void* dx, const cnk_bn_bwd_fuse* bn, void* stream);
+int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean,
+                            const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* nn.AvgPool2d (avgpool2d, basemodel.py:1026-1033; DenseNet's transition block, densenet.py:129): floor mode,
  * count_include_pad=True (every window divides by kh*kw), zero padding.  SURVEY.md 8f n4. */
 int cnk_avgpool2d_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh,
