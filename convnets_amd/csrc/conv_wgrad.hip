@@ -122,12 +122,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NBUF != 2) ? 3 : 2) 
             int m = m0 + r;
             u32x4 v = {0, 0, 0, 0};
             // (channel bound: Cout / Cin may be any multiple of one vector; columns past them are zeros)
-            if (m < p.M && tile_co * BMW + c * PER16 < p.Cout) {
+            if constexpr (FOLD) {
+                // unconditional loads from a clamped address, the zero selected when the tile is staged: with the two loads and
+                // the flag update inside the bounds branch hipcc waited vmcnt(0) in front of every pair -- four dependent round
+                // trips per K step (cdna_hip_programming.md 5, trap (c)), which doubled this kernel's time
+                const bool ok = m < p.M && tile_co * BMW + c * PER16 < p.Cout;
+                const size_t off = ok ? (size_t)m * p.Cout + tile_co * BMW + c * PER16 : 0;
+                v = *(const u32x4*)(dy + off);
+                ry[i] = *(const u32x4*)((const T*)p.fy + off);
+                fok |= (ok ? 1u : 0u) << i;
+            } else if (m < p.M && tile_co * BMW + c * PER16 < p.Cout) {
                 v = *(const u32x4*)(dy + (size_t)m * p.Cout + tile_co * BMW + c * PER16);
-                if constexpr (FOLD) {
-                    ry[i] = *(const u32x4*)((const T*)p.fy + (size_t)m * p.Cout + tile_co * BMW + c * PER16);
-                    fok |= 1u << i;
-                }
             }
             ra[i] = v;
         }
@@ -154,15 +159,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NBUF != 2) ? 3 : 2) 
         for (int i = 0; i < PASSA; ++i) {
             int idx = tid + NT * i, r = idx / CPRA, c = idx - r * CPRA;
             if constexpr (FOLD) {
-                if ((fok >> i) & 1u) {
-                    // same expression, same rounding as bn_bwd_row (bn.hip): the staged tile IS the tensor that kernel would write
-                    const bf16x8 dv = __builtin_bit_cast(bf16x8, ra[i]), yv = __builtin_bit_cast(bf16x8, ry[i]);
-                    bf16x8 o;
+                // same expression, same rounding as bn_bwd_row (bn.hip): the staged tile IS the tensor that kernel would write
+                const bf16x8 dv = __builtin_bit_cast(bf16x8, ra[i]), yv = __builtin_bit_cast(bf16x8, ry[i]);
+                bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < PER16; ++e)
-                        o[e] = (bf16)(ka[e] * ((float)dv[e] - kb1[e] - ((float)yv[e] - kmu[e]) * kis[e]));
-                    ra[i] = __builtin_bit_cast(u32x4, o);
-                }
+                for (int e = 0; e < PER16; ++e)
+                    o[e] = (bf16)(ka[e] * ((float)dv[e] - kb1[e] - ((float)yv[e] - kmu[e]) * kis[e]));
+                const u32x4 ov = __builtin_bit_cast(u32x4, o);
+                const bool ok = (fok >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[i][e] = ok ? ov[e] : 0u;
             }
             *(u32x4*)(As + buf * (KP * ROWA) + r * ROWA + c * 16) = ra[i];
         }
