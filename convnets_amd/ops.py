@@ -249,6 +249,11 @@ class FoldRecord:
 
 
 BN_FOLD = os.environ.get('CNK_BN_FOLD', '1') != '0'
+# The fold pays where the apply pass it removes (3 * M * Cout elements of HBM traffic) outweighs what it adds to the critical
+# path (the finalise + image launches, ~20-30 us, and K + Cin/Cout in the data gradient) and to the weight-gradient stream (the
+# BN input read beside the gradient): measured per ResNet-50 stage at batch 256 (tools/bench_fold.py) 366 -> 163 / 203 -> 110 /
+# 119 -> 83 / 87 -> 91 us on the compute stream, i.e. not at 7x7; the rule below is M * Cout elements of the BN tensor.
+BN_FOLD_MIN_ELEMS = float(os.environ.get('CNK_BN_FOLD_MIN', '4e7'))
 FOLD_COUNTS = {'folded': 0}               # folded conv backward passes (tests read this)
 BN_BWD_FUSE = os.environ.get('CNK_BN_BWD_FUSE', '1') != '0'
 # the same fusion for the stride-1 3x3 convs only (A/B switch, DESIGN.md: break-even per layer, see there)
@@ -461,7 +466,7 @@ class Conv2dFn(torch.autograd.Function):
         # gradient hand-over at the input (the folded data gradient takes no addend)
         ctx.fold = None
         if fold is not None and BN_FOLD and plan.bnfold and bias is None and ctx.link is None and w.dtype == torch.float32 \
-                and x_needs_grad and w_dgrad is not None:
+                and x_needs_grad and w_dgrad is not None and desc.N * plan.Ho * plan.Wo * desc.Cout >= BN_FOLD_MIN_ELEMS:
             fold.ok = True
             ctx.fold = fold
         if want_bn_partial:

@@ -255,7 +255,8 @@ def test_bottleneck_resnet_step_with_and_without_the_fold():
     (DESIGN.md section 4).  Residual branches damped (x 0.1) as in the well-conditioned fixture, so the bound means something."""
     from convnets_amd import ops
     from oracle import torch_ref as tr
-    prev = ops.BN_FOLD
+    prev, prev_min = ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS
+    ops.BN_FOLD_MIN_ELEMS = 0              # (the size rule would leave this small net unfolded)
     try:
         res = {}
         for fold in (True, False):
@@ -277,7 +278,7 @@ def test_bottleneck_resnet_step_with_and_without_the_fold():
             grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
             res[fold] = (float(loss), grads, ops.FOLD_COUNTS['folded'])
     finally:
-        ops.BN_FOLD = prev
+        ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS = prev, prev_min
     (l1, g1, n1), (l0, g0, n0) = res[True], res[False]
     assert n0 == 0 and n1 >= 7, 'the fold ran %d times (ResNet-26 has 8 bottlenecks; the last one has no fused reduction)' % n1
     assert l1 == l0                                  # the forward pass does not change
