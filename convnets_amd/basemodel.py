@@ -159,16 +159,31 @@ class MultiClassBaseModel(nn.Module):
         snap = probe._snapshot()
         batch = self.setting.device.move(batch)
         timings = {}
-        for share in candidates:
-            ops.WGRAD_SHARE[0] = share
-            self.train_batch(batch)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
+        previous = ops.WGRAD_SHARE[0]
+        try:
+            for share in candidates:
+                ops.WGRAD_SHARE[0] = share
                 self.train_batch(batch)
-            torch.cuda.synchronize()
-            timings[share] = (time.perf_counter() - t0) / steps * 1e3
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.train_batch(batch)
+                torch.cuda.synchronize()
+                timings[share] = (time.perf_counter() - t0) / steps * 1e3
+                probe._restore(snap)
+        except BaseException:
+            # a failed probe step must leave neither a candidate share nor a half-trained state behind
+            ops.WGRAD_SHARE[0] = previous
             probe._restore(snap)
+            raise
+        red = getattr(self, 'grad_reducer', None)
+        if red is not None and getattr(red, 'world', 1) > 1:
+            # every rank must take the SAME share: the split-K depth is the fp32 summation order of the weight gradients, and
+            # replicas that sum in different orders drift apart bit by bit.  Slowest rank per candidate decides.
+            import torch.distributed as dist
+            t = torch.tensor([timings[c] for c in candidates], dtype=torch.float64, device=self.setting.device.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=getattr(red, 'group', None))
+            timings = {c: float(v) for c, v in zip(candidates, t.tolist())}
         best = min(timings, key=timings.get)
         if 1.0 in timings and timings[best] > 0.995 * timings[1.0]:
             best = 1.0

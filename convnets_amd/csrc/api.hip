@@ -414,19 +414,27 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
     return direct_dgrad(d, dy, w_dgrad, dx, addend, S(stream));
 }
 
+// The smallest workspace cnk_conv2d_wgrad accepts: split-K kernels take ANY workspace of at least one fp32 slab (+ the bias
+// sum's scratch) -- less than cnk_conv2d_workspace_bytes() bounds the number of pixel-range splits (include/cnk.h; why a caller
+// would: conv_wgrad.hip, wgrad_cap_splits); every other kernel needs its whole workspace.
+size_t cnk_conv2d_wgrad_min_workspace_bytes(const cnk_conv_desc* d, int has_bias) {
+    if (check_desc(d, "cnk_conv2d_wgrad_min_workspace_bytes")) return 0;
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    const size_t bias_ws = has_bias ? colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout) : 0;
+    if (!(wgrad3x3_supported(d) || wgrad_mfma_supported(d))) return cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD);
+    const size_t slab = (size_t)d->Cout * (conv_groups(d) > 1 ? 64 : d->Cin) * d->kh * d->kw * sizeof(float);
+    return ((slab + 255) & ~(size_t)255) + bias_ws;
+}
+
 int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_wgrad")) return rc;
     CNK_CHECK_ARG(dy && x && dw, "cnk_conv2d_wgrad: null pointer");
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
-    const size_t need = cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD);
     const size_t bias_ws = dbias ? colsum_workspace((int64_t)d->N * Ho * Wo, d->Cout) : 0;
     const bool splitk = wgrad3x3_supported(d) || wgrad_mfma_supported(d);
-    // Split-K kernels take ANY workspace of at least one fp32 slab (+ the bias sum's scratch): less than
-    // cnk_conv2d_workspace_bytes() bounds the number of pixel-range splits (include/cnk.h; why a caller would:
-    // conv_wgrad.hip, wgrad_cap_splits)
-    const size_t slab = (size_t)d->Cout * (conv_groups(d) > 1 ? 64 : d->Cin) * d->kh * d->kw * sizeof(float);
-    const size_t least = splitk ? ((slab + 255) & ~(size_t)255) + bias_ws : need;
+    const size_t least = cnk_conv2d_wgrad_min_workspace_bytes(d, dbias != nullptr);
     CNK_CHECK_ARG(workspace && workspace_bytes >= least, "cnk_conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, least);
     double fl, by;
     conv_cost(d, &fl, &by);

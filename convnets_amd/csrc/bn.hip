@@ -11,6 +11,7 @@
 // Algorithmic bytes: forward 3*E*s (x twice, y once), backward reads dy,x(,y) twice + writes dx.
 #include "common.h"
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -271,9 +272,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 // No release fence anywhere (MI355X_MICROARCH.md: an agent-scope release is an L2 write-back -- round 2's attempt with
 // __threadfence() in every block of the STREAMING pass lost 1.4 ms per step); the last block of a group runs one acquire
 // (L1 invalidate of its own CU) and reads the shares with sc1 loads.  cdna_hip_programming.md 5, "Projection GEMM" item 2.
-// Tickets live in a __device__ array (zero at module load), 64 slots handed out round-robin by the host so that launches in
-// flight on different streams never share a counter; the last block resets its counter for the slot's next user.
-constexpr int BNF_SLOTS = 64, BNF_GROUPS = 64;
+// Tickets live in a __device__ array (zero at module load; the last block resets its counter for the slot's next user).  The
+// 64 slots are 16 BANKS of 4: a bank belongs to ONE stream (host table, first come first served), so two launches that can be
+// in flight together -- different streams -- never share a counter, and launches of one stream, which execute in order, walk
+// their bank round-robin.  A 17th stream takes the two-kernel path.  (the slots used to be handed out from one
+// process-wide counter, so launches 64 issues apart on two streams could have met on one counter.)  What is NOT covered: two
+// captured graphs holding launches of the same bank replayed CONCURRENTLY on two streams -- include/cnk.h says so.
+constexpr int BNF_BANKS = 16, BNF_PER_BANK = 4, BNF_SLOTS = BNF_BANKS * BNF_PER_BANK, BNF_GROUPS = 64;
 __device__ unsigned int bn_tickets[BNF_SLOTS * BNF_GROUPS];
 
 struct BnFinalFwd {
@@ -1065,14 +1070,30 @@ static int bn_premerge(const float*& partial, int& slices, int C, float* scratch
 
 // One launch for merge + finalisation (bn_merge_final_kernel) when the list is long enough to need two levels.
 // Returns 1 when taken (done), 0 when the caller should run the two-kernel path, < 0 on error.
-static std::atomic<unsigned> g_bnf_slot{0};
+static std::mutex g_bnf_mu;
+static hipStream_t g_bnf_stream[BNF_BANKS];
+static unsigned g_bnf_next[BNF_BANKS];
+static int g_bnf_banks = 0;
+static int bnf_slot_for(hipStream_t s) {               // -1: no bank left for this stream
+    std::lock_guard<std::mutex> lk(g_bnf_mu);
+    int b = 0;
+    while (b < g_bnf_banks && g_bnf_stream[b] != s) ++b;
+    if (b == g_bnf_banks) {
+        if (g_bnf_banks == BNF_BANKS) return -1;
+        g_bnf_stream[b] = s;
+        g_bnf_next[b] = 0;
+        ++g_bnf_banks;
+    }
+    return b * BNF_PER_BANK + (int)(g_bnf_next[b]++ % BNF_PER_BANK);
+}
 template <class FIN>
 static int bn_merge_final(const float* partial, int slices, int C, int64_t M, float* scratch, int64_t scratch_floats,
                           const FIN& fin, hipStream_t s) {
     if (!cnk_sw().bn_fused_final || slices < 1024 || ceil_div(C, 64) > BNF_GROUPS) return 0;
     const int shares = slices >= 2048 ? 64 : 32;          // <= 64: bn_merge_final_kernel reads up to 16 shares per wave, all at once
     if ((int64_t)shares * C * FIN::NV > scratch_floats) return 0;
-    const int slot = (int)(g_bnf_slot.fetch_add(1, std::memory_order_relaxed) % BNF_SLOTS);
+    const int slot = bnf_slot_for(s);
+    if (slot < 0) return 0;
     hipLaunchKernelGGL((bn_merge_final_kernel<FIN>), dim3(ceil_div(C, 64), shares), dim3(256), 0, s, partial, slices, C, M,
                        scratch, slot, fin);
     hipError_t e = hipGetLastError();

@@ -96,7 +96,24 @@ class GraphedTrainStep:
 
     def _capture(self):
         opt = self.model.optimizer
-        self.lr = opt.param_groups[0]['lr']
+        if len(opt.param_groups) != 1:
+            raise NotImplementedError('GraphedTrainStep: one parameter group (the reference builds one, src/basemodel.py:64-67)')
+        group = opt.param_groups[0]
+        # The captured Adam launch steps by lr_captured / bc1 with bc1 read from the device record, which is how a later
+        # learning-rate change reaches it (replay()).  A step captured at lr == 0 (warm-up schedules) would freeze that
+        # quotient at 0 and turn it into 0 / 0 once the rate moves: capture such a step with a nominal rate of 1 instead;
+        # replays at lr == 0 then carry bc1 = inf, i.e. a step of exactly zero, like the eager kernel.
+        lr_now = group['lr']
+        self.lr = lr_now if lr_now != 0 else 1.0
+        # every other hyper-parameter is a kernel argument frozen into the graph: replay() refuses a change
+        self._frozen = (tuple(group['betas']), group['eps'], group['weight_decay'])
+        group['lr'] = self.lr
+        try:
+            self._capture_step(opt)
+        finally:
+            group['lr'] = lr_now
+
+    def _capture_step(self, opt):
         step0, drop0 = opt.step_count, ops._dropout_calls[0]
         self.scalars.dropout_calls = 0
         self.graph = torch.cuda.CUDAGraph()
@@ -148,7 +165,11 @@ class GraphedTrainStep:
             self.x.copy_(x, non_blocking=True)
             self.y.copy_(y, non_blocking=True)
         bc = opt.bias_corrections(opt.step_count + 1)
-        lr = opt.param_groups[0]['lr']
+        group = opt.param_groups[0]
+        if len(opt.param_groups) != 1 or (tuple(group['betas']), group['eps'], group['weight_decay']) != self._frozen:
+            raise RuntimeError('GraphedTrainStep: betas / eps / weight_decay / the parameter groups changed after the capture; '
+                               'they are arguments of the captured Adam launch -- build a new GraphedTrainStep')
+        lr = group['lr']
         if lr != self.lr:
             # adam_kernel steps by (lr_captured / bc1): a changed learning rate rides on the record (equal to the eager
             # step's lr / bc1 up to one rounding of the quotient)

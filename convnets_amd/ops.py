@@ -163,7 +163,8 @@ def join_side_streams(device=None):
 # (round 3: six ctypes round trips and a struct construction less per conv call on the host; a ResNet-152 eager step issues
 # ~1,900 launches from Python).  _lib.reload_switches() (tests, A/B tools) moves the epoch and drops them.
 class ConvPlan:
-    __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'accepts_mask', 'bnfold', 'fold_bytes')
+    __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'wgrad_min_ws', 'wgrad_min_ws_bias', 'accepts_mask',
+                 'bnfold', 'fold_bytes')
 
 
 _conv_plans = {}
@@ -183,6 +184,8 @@ def conv_plan(x_shape, weight_shape, stride, padding, dtype_code, groups, dilati
         pl.fwd_slices = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d))
         pl.dgrad_slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(d))
         pl.wgrad_ws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), PASS_WGRAD)
+        pl.wgrad_min_ws = lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(d), 0)
+        pl.wgrad_min_ws_bias = lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(d), 1)
         pl.accepts_mask = bool(lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(d)))
         pl.bnfold = bool(lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)))
         pl.fold_bytes = lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)) if pl.bnfold else 0
@@ -554,15 +557,15 @@ class Conv2dFn(torch.autograd.Function):
                 db_buf = db = torch.empty((desc.Cout,), dtype=torch.float32, device=w.device) \
                     if ctx.has_bias else None
             nws = ctx.plan.wgrad_ws
+            min_ws = ctx.plan.wgrad_min_ws_bias if ctx.has_bias else ctx.plan.wgrad_min_ws
 
             def run_wgrad(share=1.0):
                 ws = workspace(nws, x.device)
                 budget = ws.numel()
-                # (the MFMA split-K kernels only: channel counts on the 64 grid, dense -- every other kernel needs its whole workspace)
-                if share < 1.0 and not ctx.has_bias and desc.groups == 1 and desc.Cin % 64 == 0 and desc.Cout % 64 == 0:
-                    # bound the split-K depth: at least one fp32 slab [Cout][kh][kw][Cin], whole multiples of 256 bytes
-                    slab = desc.Cout * (64 if desc.groups > 1 else desc.Cin) * desc.kh * desc.kw * 4
-                    budget = max((slab + 255) // 256 * 256, int(nws * share) // 256 * 256)
+                # a share of the split-K depth: never below what the library says it needs (the whole workspace for every
+                # kernel that does not split; cnk_conv2d_wgrad_min_workspace_bytes)
+                if share < 1.0:
+                    budget = min(budget, max(min_ws, int(nws * share) // 256 * 256))
                 if fold is not None:
                     check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fold.y), _p(x), _p(fold.mean),
                                                       _p(fold.invstd), _p(fold.coef), _p(dw_buf), int(direct), _p(ws),
@@ -773,6 +776,9 @@ class BatchNormActMaxPoolFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, partial, ksize, stride, padding):
         _require_gpu(x)
         lib = _lib.load()
+        # (read before any layout copy made here: a copy made under no_grad drops the flag; the kept reduction also serves
+        # dgamma / dbeta when x itself needs no gradient)
+        needs_bwd = x.requires_grad or gamma.requires_grad or beta.requires_grad
         x = _nhwc(x)
         N, C, H, W = x.shape
         M = N * H * W
@@ -793,7 +799,7 @@ class BatchNormActMaxPoolFn(torch.autograd.Function):
         # stride-2 pools whose backward gathers through <= 2 x 2 windows: the pooling pass also keeps the INPUT value at every
         # arg-max (a quarter of x), and the backward's reduction pass then reads that and the pooled gradient instead of
         # gathering over all of x (cnk_bn_bwd_maxpool_kept)
-        keep = POOL_KEEP and x.requires_grad and tuple(stride) == (2, 2) and ksize[0] <= 4 and ksize[1] <= 4
+        keep = POOL_KEEP and needs_bwd and tuple(stride) == (2, 2) and ksize[0] <= 4 and ksize[1] <= 4
         xmax = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device) if keep else None
         if keep:
             check(lib.cnk_maxpool2d_fwd_bn_keep(_p(x), scale, shift, int(relu), _p(y), _p(idx), _p(xmax), N, H, W, C, ksize[0],

@@ -153,6 +153,9 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
 int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
                      float* dbias, int accumulate, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* The smallest workspace cnk_conv2d_wgrad accepts for this shape (has_bias: dbias != NULL): one slab (+ the bias sum's
+ * scratch) for the split-K kernels, cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD) for every other kernel. */
+size_t cnk_conv2d_wgrad_min_workspace_bytes(const cnk_conv_desc* d, int has_bias);
 
 /* nn.BatchNorm2d in training mode (basemodel.py:1008,1061), optionally fused with the ReLU that
  * follows it in conv2d_block (:1012) and with the residual add + F.relu of the ResNet blocks
@@ -164,6 +167,10 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
  * relu_mask (may be NULL; cnk_bn_mask_bytes(M, C, dtype) bytes): packed ReLU mask of the output,
  * one bit per element; handing it to cnk_bn_bwd replaces two full reads of y by 1/16 of the bytes.
  * workspace: cnk_bn_workspace_bytes(M, C). */
+/* Concurrency: calls on ONE stream may follow each other freely (stream order is all the BN entry points rely on); calls on
+ * different streams may run concurrently.  The merge + finalise launch behind long partial lists keeps last-block tickets in
+ * device memory owned by the library, banked per stream (csrc/bn.hip); the one unsupported pattern is replaying two CAPTURED
+ * graphs that contain BN calls of the same original stream concurrently on two streams. */
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C);
 size_t cnk_bn_mask_bytes(int64_t M, int32_t C, int dtype);
 int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual,

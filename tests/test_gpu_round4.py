@@ -291,3 +291,45 @@ def test_bottleneck_resnet_step_with_and_without_the_fold():
                 if float((g0[k] ** 2).sum()) > 1e-12)
     print('worst tensor', worst)
     assert worst[0] < 1.5e-1
+
+
+def test_graphed_step_captured_at_zero_learning_rate():
+    """a step captured while a warm-up schedule holds lr == 0 used to freeze lr_captured / bc1 at 0 and turn it
+    into 0 / 0 (NaN for every parameter) once the rate moved.  Two replays (lr 0, then 0.01) against two eager steps of a
+    twin model; a changed weight decay is refused."""
+    import convnets_amd as ca
+    from convnets_amd.graph import GraphedTrainStep
+    from oracle import torch_ref as tr
+
+    def build():
+        torch.manual_seed(21)
+        s = ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, batch_size=16, dropout_rate=0, mixed_precision=True,
+                        device='cuda:0')
+        m = ca.ResNet(s).cuda()
+        m.init_optimizer()
+        m.train()
+        return m
+    x, y = tr.synthetic_batch(16, (3, 32, 32), 10, seed=21)
+    x, y = x.cuda(), y.cuda()
+    eager, graphed = build(), build()
+    for m in (eager, graphed):
+        m.optimizer.param_groups[0]['lr'] = 0.0
+    step = GraphedTrainStep(graphed, (x, y))
+    assert graphed.optimizer.param_groups[0]['lr'] == 0.0           # the nominal capture rate does not leak out
+    p0 = graphed.optimizer.flat_p.clone()
+    step.replay()
+    eager.train_batch((x, y))
+    torch.cuda.synchronize()
+    assert torch.equal(graphed.optimizer.flat_p, p0), 'a step at lr == 0 moved the parameters'
+    for m in (eager, graphed):
+        m.optimizer.param_groups[0]['lr'] = 0.01
+    step.replay()
+    eager.train_batch((x, y))
+    torch.cuda.synchronize()
+    pg, pe = graphed.optimizer.flat_p, eager.optimizer.flat_p
+    assert torch.isfinite(pg).all() and not torch.equal(pg, p0)
+    assert torch.allclose(pg, pe, rtol=2e-6, atol=1e-8), float((pg - pe).abs().max())
+    assert torch.equal(graphed.optimizer.exp_avg, eager.optimizer.exp_avg)
+    graphed.optimizer.param_groups[0]['weight_decay'] = 0.5
+    with pytest.raises(RuntimeError):
+        step.replay()
