@@ -69,6 +69,8 @@ SIGNATURES = {
     'cnk_bn_mask_bytes': (_sz, [_i64, _i32, ctypes.c_int]),
     'cnk_bn_fwd_train': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
                                         _f32, _f32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
+    'cnk_bn_fwd_train_res_affine': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
+                                                   _f32, _f32, ctypes.c_int, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_bn_fwd_eval': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32,
                                        ctypes.c_int, ctypes.c_int, _vp]),
     'cnk_bn_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,

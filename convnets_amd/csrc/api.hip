@@ -92,7 +92,7 @@ int pack_batch(const cnk_pack_job* jobs_dev, const void* block_map_dev, int nblo
 int pack_job_blocks(const cnk_pack_job& j);
 size_t bn_workspace_bytes(int64_t M, int C);
 size_t bn_mask_bytes(int64_t M, int C, int dtype);
-int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s);
+int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* partial, int64_t partial_slices, int64_t M, int C, float eps, float mom, int relu, int dtype, float* ws, hipStream_t s, const float* raff = nullptr);
 int bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* rm, const float* rv, const void* res, void* y, int64_t M, int C, float eps, int relu, int dtype, hipStream_t s);
 int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate, const float* ext_partial, int64_t ext_slices, int64_t M, int C, int relu, int dtype, float* ws, hipStream_t s);
 int bn_bwd_pool(const void* dy, const unsigned char* idx, const void* x, const void* xmax, const float* gamma, const float* beta, const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw, int relu, int dtype, float* ws, hipStream_t s);
@@ -535,6 +535,17 @@ int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const
     ProfScope ps(CNK_CLS_BN_FWD, S(stream), 0.0, (partial ? 2.0 : 3.0) * (double)M * C * esize(dtype));
     CNK_CHECK_ARG(!relu_mask || relu, "cnk_bn_fwd_train: relu_mask without relu");
     return bn_fwd_train(x, gamma, beta, residual, y, relu_mask, running_mean, running_var, save_mean, save_invstd, partial, partial_slices, M, C, eps, momentum, relu, dtype, (float*)workspace, S(stream));
+}
+
+int cnk_bn_fwd_train_res_affine(const void* x, const float* gamma, const float* beta, const void* residual, const float* residual_scale_shift, void* y, uint8_t* relu_mask, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* partial, int64_t partial_slices, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(x && gamma && beta && save_mean && save_invstd && y && residual && residual_scale_shift, "cnk_bn_fwd_train_res_affine: null pointer");
+    CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_train_res_affine: empty tensor");
+    CNK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cnk_bn_fwd_train_res_affine: running stats must both be given or both NULL");
+    CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_fwd_train_res_affine: workspace too small");
+    CNK_CHECK_ARG((partial == nullptr) == (partial_slices == 0) && partial_slices >= 0, "cnk_bn_fwd_train_res_affine: partial and partial_slices must come together");
+    CNK_CHECK_ARG(!relu_mask || relu, "cnk_bn_fwd_train_res_affine: relu_mask without relu");
+    ProfScope ps(CNK_CLS_BN_FWD, S(stream), 0.0, (partial ? 3.0 : 4.0) * (double)M * C * esize(dtype));
+    return bn_fwd_train(x, gamma, beta, residual, y, relu_mask, running_mean, running_var, save_mean, save_invstd, partial, partial_slices, M, C, eps, momentum, relu, dtype, (float*)workspace, S(stream), residual_scale_shift);
 }
 
 int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var, const void* residual, void* y, int64_t M, int32_t C, float eps, int relu, int dtype, void* stream) {

@@ -494,16 +494,20 @@ template <typename T, int VEC> struct Raw {          // one thread's 16-byte pay
 };
 
 // y = act(x*scale + shift [+ res]); optional packed ReLU mask (one byte per vector: bit k = y_k > 0)
-template <typename T, int VEC, bool HAS_RES, bool RELU, bool WMASK>
+// RAFF: the residual operand is the INPUT of another training-mode BN layer without activation (a projection shortcut,
+// resnet.py:90-91) whose apply pass was deferred into this one: its value is round_T(r * rsc + rsh), exactly what that layer's
+// own apply pass would have stored, so the result is bit-identical and one full read + write pass of the block is gone.
+template <typename T, int VEC, bool HAS_RES, bool RELU, bool WMASK, bool RAFF = false>
 __device__ __forceinline__ void bn_apply_row(const Raw<T, VEC>& xv, const Raw<T, VEC>& rv, const float (&sc)[VEC],
                                              const float (&sh)[VEC], T* __restrict__ yp,
-                                             unsigned char* __restrict__ mp) {
+                                             unsigned char* __restrict__ mp, const float (&rsc)[VEC], const float (&rsh)[VEC]) {
     Raw<T, VEC> o;
     unsigned bits = 0;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         float a = xv.get(k) * sc[k] + sh[k];
-        if constexpr (HAS_RES) a += rv.get(k);
+        if constexpr (HAS_RES && RAFF) a += to_f32(from_f32<T>(rv.get(k) * rsc[k] + rsh[k]));
+        else if constexpr (HAS_RES) a += rv.get(k);
         if constexpr (RELU) a = a > 0.f ? a : 0.f;
         if constexpr (WMASK) bits |= (a > 0.f ? 1u : 0u) << k;
         o.set(k, a);
@@ -512,13 +516,13 @@ __device__ __forceinline__ void bn_apply_row(const Raw<T, VEC>& xv, const Raw<T,
     if constexpr (WMASK) *mp = (unsigned char)bits;
 }
 
-template <typename T, int VEC, bool HAS_RES, bool RELU, bool WMASK>
+template <typename T, int VEC, bool HAS_RES, bool RELU, bool WMASK, bool RAFF = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
                                                        const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        unsigned char* __restrict__ mask, int64_t M,
-                                                       int C, SliceGeom g) {
+                                                       int C, SliceGeom g, const float* __restrict__ raff) {
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     if (trow >= g.rpb || vcol >= g.cols) return;
@@ -527,9 +531,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
     const int64_t rstep = (int64_t)g.rpb * C;
     int64_t m = m0 + trow;
     int64_t off = m * C + (int64_t)vcol * VEC;
-    float sc[VEC], sh[VEC];
+    float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
     load_coef<VEC>(sc, scale + vcol * VEC);
     load_coef<VEC>(sh, shift + vcol * VEC);
+    if constexpr (RAFF) {
+        load_coef<VEC>(rsc, raff + vcol * VEC);
+        load_coef<VEC>(rsh, raff + C + vcol * VEC);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) rsc[k] = rsh[k] = 0.f;
+    }
     for (; m + (ROWS_U - 1) * g.rpb < m1; m += ROWS_U * g.rpb, off += ROWS_U * rstep) {
         Raw<T, VEC> xv[ROWS_U], rv[ROWS_U];
 #pragma unroll
@@ -542,14 +553,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < ROWS_U; ++u)
-            bn_apply_row<T, VEC, HAS_RES, RELU, WMASK>(xv[u], rv[u], sc, sh, y + off + u * rstep,
-                                                       mask + (m + (int64_t)u * g.rpb) * g.cols + vcol);
+            bn_apply_row<T, VEC, HAS_RES, RELU, WMASK, RAFF>(xv[u], rv[u], sc, sh, y + off + u * rstep,
+                                                             mask + (m + (int64_t)u * g.rpb) * g.cols + vcol, rsc, rsh);
     }
     for (; m < m1; m += g.rpb, off += rstep) {
         Raw<T, VEC> xv, rv;
         xv.load(x + off);
         if constexpr (HAS_RES) rv.load(res + off);
-        bn_apply_row<T, VEC, HAS_RES, RELU, WMASK>(xv, rv, sc, sh, y + off, mask + m * g.cols + vcol);
+        bn_apply_row<T, VEC, HAS_RES, RELU, WMASK, RAFF>(xv, rv, sc, sh, y + off, mask + m * g.cols + vcol, rsc, rsh);
     }
 }
 
@@ -1109,7 +1120,7 @@ template <typename T, int VEC>
 static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* res,
                           void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si,
                           const float* ext_partial, int64_t ext_slices, int64_t M, int C, float eps, float mom, int relu,
-                          float* ws, hipStream_t s) {
+                          float* ws, hipStream_t s, const float* raff = nullptr) {
     SliceGeom g = make_geom(M, C, VEC);
     float* scale = ws;
     float* shift = ws + C;
@@ -1141,9 +1152,20 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
     const dim3 grid(g.slices, g.colgroups);
 #define CNK_BN_APPLY(R, A, W)                                                                              \
     hipLaunchKernelGGL((bn_apply_kernel<T, VEC, R, A, W>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
-                       (T*)y, scale, shift, mask, M, C, g)
+                       (T*)y, scale, shift, mask, M, C, g, nullptr)
+#define CNK_BN_APPLY_RAFF(A, W)                                                                                        \
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, true, A, W, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
+                       (T*)y, scale, shift, mask, M, C, g, raff)
     const int key = (res ? 4 : 0) | (relu ? 2 : 0) | (mask ? 1 : 0);
     ProfScope kscope(CNK_KF_BN_APPLY, s, 0.0, (double)M * C * sizeof(T) * (res ? 3 : 2) + (mask ? (double)M * C / 8 : 0.0));
+    if (raff && res) {
+        switch (key & 3) {
+            case 0: CNK_BN_APPLY_RAFF(false, false); break;
+            case 1: CNK_BN_APPLY_RAFF(false, true); break;
+            case 2: CNK_BN_APPLY_RAFF(true, false); break;
+            default: CNK_BN_APPLY_RAFF(true, true); break;
+        }
+    } else
     switch (key) {
         case 0: CNK_BN_APPLY(false, false, false); break;
         case 1: CNK_BN_APPLY(false, false, true); break;
@@ -1155,19 +1177,20 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
         default: CNK_BN_APPLY(true, true, true); break;
     }
 #undef CNK_BN_APPLY
+#undef CNK_BN_APPLY_RAFF
     CNK_CHECK_LAUNCH("bn_apply");
     return 0;
 }
 
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y,
                  unsigned char* mask, float* rm, float* rv, float* sm, float* si, const float* ep, int64_t es, int64_t M, int C,
-                 float eps, float mom, int relu, int dtype, float* ws, hipStream_t s) {
+                 float eps, float mom, int relu, int dtype, float* ws, hipStream_t s, const float* raff) {
     if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_fwd_train_t<bf16, 8>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
-        return bn_fwd_train_t<bf16, 1>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+        if (C % 8 == 0) return bn_fwd_train_t<bf16, 8>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s, raff);
+        return bn_fwd_train_t<bf16, 1>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s, raff);
     }
-    if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
-    return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s);
+    if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s, raff);
+    return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s, raff);
 }
 
 template <typename T, int VEC>

@@ -87,7 +87,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     # model then bumps every layer's num_batches_tracked with ONE kernel per step, not one per layer
     _deferred_counter = None
 
-    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None, fold=None):
+    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None, fold=None, defer=False):
         """pool: the MaxPool2d module that consumes this layer's output (ConvBlock passes it for the stems, training
         mode only): BN, ReLU and the pooling then run as one autograd node and the POOLED tensor is returned."""
         if not (self.affine and self.track_running_stats):
@@ -102,12 +102,18 @@ class BatchNorm2d(nn.BatchNorm2d):
                                                     _pair(pool.kernel_size), _pair(pool.stride), _pair(pool.padding))
                 y._cnk_pooled_by = pool
             else:
-                rec = ops.BnRecord() if (torch.is_grad_enabled() and x.requires_grad) else None
+                rec = ops.BnRecord() if (torch.is_grad_enabled() and x.requires_grad and not defer) else None
+                # residual operand whose own BN apply pass was deferred into this call (see `defer` below)
+                res_affine = getattr(residual, '_cnk_defer', None) if residual is not None else None
+                holder = [] if defer else None
                 y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
                                              self.running_var, float(self.eps), float(self.momentum),
-                                             bool(relu), partial, link, rec, fold)
+                                             bool(relu), partial, link, rec, fold, holder, res_affine)
                 if rec is not None and rec.x is not None:
                     y._cnk_bn = rec
+                if defer:
+                    # statistics only: y aliases x; whoever adds it as a residual normalises it on the fly
+                    y._cnk_defer = holder[0]
             self._stats_epoch = getattr(self, '_stats_epoch', 0) + 1     # running statistics changed
             if self._deferred_counter is not None:
                 self._deferred_counter[0] += 1        # flushed for all BN layers at once by the model
@@ -266,14 +272,21 @@ class SKConv(nn.Module):
         return ops.SKSelectFn.apply(link, self.num_paths, *maps, *logits)
 
 
+import os as _os
+DEFER_SHORTCUT_BN = _os.environ.get('CNK_DEFER_SHORTCUT_BN', '1') != '0'      # A/B switch
+
+
 class ConvBlock(nn.Sequential):
     """conv -> [BN] -> [ReLU] as conv2d_block builds it (basemodel.py:999-1015): an nn.Sequential
     with children '0','1','2' (same state_dict keys), whose forward runs BN + ReLU (+ the residual
     add of the enclosing block) as ONE fused kernel pass instead of three."""
 
-    def forward(self, x, residual=None, relu_after_add=False, in_link=None, res_link=None):
+    def forward(self, x, residual=None, relu_after_add=False, in_link=None, res_link=None, defer_apply=False):
         """in_link: GradLink shared with the other consumer of x (fused gradient sum at a residual
-        block's input); res_link: the same link seen from the residual operand's side."""
+        block's input); res_link: the same link seen from the residual operand's side.
+        defer_apply: conv -> BN without activation whose ONLY consumer is the residual add of another ConvBlock (a
+        projection shortcut): training mode computes the statistics and returns the conv output itself, tagged with the
+        layer's scale | shift; the consuming block's BN pass normalises it on the fly (bit-identical, one pass less)."""
         mods = list(self)
         conv = mods[0]
         bn = mods[1] if len(mods) > 1 and isinstance(mods[1], BatchNorm2d) else None
@@ -288,6 +301,8 @@ class ConvBlock(nn.Sequential):
                 if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
                     return bn(y, relu=act, partial=partial, pool=pool)
+                if defer_apply and not act and residual is None and torch.is_grad_enabled() and DEFER_SHORTCUT_BN:
+                    return bn(y, partial=partial, defer=True)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
                           link=res_link, fold=fold if (fold is not None and fold.ok) else None)
             if not torch.is_grad_enabled():
@@ -300,6 +315,8 @@ class ConvBlock(nn.Sequential):
                 if y is not None:
                     return y
             return bn(conv(x), residual=residual, relu=act or relu_after_add)
+        if residual is not None and getattr(residual, '_cnk_defer', None) is not None:
+            raise RuntimeError('ConvBlock: a residual operand with a deferred BN apply pass needs a BatchNorm in this block')
         y = conv(x, link=in_link)
         if residual is not None:
             if act:

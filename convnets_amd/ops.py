@@ -603,7 +603,13 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu,
-                partial=None, link=None, rec=None, fold=None):
+                partial=None, link=None, rec=None, fold=None, defer=None, res_affine=None):
+        """defer (a list, or None): statistics only -- the apply pass of this layer (no activation, no residual: a projection
+        shortcut, resnet.py:90-91) is left to the ONE consumer of its output, the `output += identity` of the block's last
+        BN; the returned tensor aliases x (un-normalised) and the layer's scale | shift [2][C] are appended to the list
+        (layers.BatchNorm2d.forward attaches them to the output as `_cnk_defer`).  res_affine: such a deferred layer's
+        scale | shift for the residual operand of THIS call (cnk_bn_fwd_train_res_affine): bit-identical to the two-pass
+        sequence, without writing and re-reading the normalised shortcut tensor."""
         _require_gpu(x)
         lib = _lib.load()
         x_needs_grad = x.requires_grad
@@ -615,7 +621,8 @@ class BatchNormActFn(torch.autograd.Function):
                 raise ValueError('batch_norm: residual must match the input shape and dtype')
         N, C, H, W = x.shape
         M = N * H * W
-        y = torch.empty_like(x, memory_format=CL)
+        if defer is not None and (relu or residual is not None):
+            raise ValueError('batch_norm: a deferred apply pass takes neither an activation nor a residual operand')
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws_bytes, mask_bytes = bn_sizes(M, C, _dtype_code(x))
@@ -628,10 +635,27 @@ class BatchNormActFn(torch.autograd.Function):
         mask = None
         if relu and residual is not None and x_needs_grad:
             mask = torch.empty(mask_bytes, dtype=torch.uint8, device=x.device)
-        check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mask),
-                                   _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
-                                   M, C, eps, momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(),
-                                   _stream()))
+        if defer is not None:
+            # statistics only; scale | shift are left at the start of the (shared) workspace: keep a copy for the consumer
+            check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), None, None, None,
+                                       _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
+                                       M, C, eps, momentum, 0, _dtype_code(x), _p(ws), ws.numel(), _stream()))
+            defer.append(ws[:8 * C].view(torch.float32).clone())
+            y = x.detach()                   # alias: the consumer reads the un-normalised tensor + the coefficients
+        elif res_affine is not None:
+            if residual is None:
+                raise ValueError('batch_norm: res_affine without a residual operand')
+            y = torch.empty_like(x, memory_format=CL)
+            check(lib.cnk_bn_fwd_train_res_affine(_p(x), _p(gamma), _p(beta), _p(residual), _p(res_affine), _p(y), _p(mask),
+                                                  _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial),
+                                                  nsl, M, C, eps, momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(),
+                                                  _stream()))
+        else:
+            y = torch.empty_like(x, memory_format=CL)
+            check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(mask),
+                                       _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
+                                       M, C, eps, momentum, int(relu), _dtype_code(x), _p(ws), ws.numel(),
+                                       _stream()))
         # the ReLU mask needs y only with a residual operand; otherwise the backward re-derives it
         ctx.save_for_backward(x, y if (relu and residual is not None and mask is None) else None,
                               mask, gamma, beta, save_mean, save_invstd)
@@ -703,7 +727,7 @@ class BatchNormActFn(torch.autograd.Function):
             # identity shortcut: park the residual gradient for the block's first conv, whose
             # dgrad epilogue adds it (falls back to a plain add if this backward is the last one)
             dres = ctx.link.contribute(lambda parked: dres if parked is None else dres + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx, want_res, ext_partial, M, C):
@@ -741,7 +765,7 @@ class BatchNormActFn(torch.autograd.Function):
             dres = dy
             if ctx.link is not None:
                 dres = ctx.link.contribute(lambda parked: dy if parked is None else dy + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):

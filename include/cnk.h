@@ -179,6 +179,19 @@ int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const
                      int32_t C, float eps, float momentum, int relu, int dtype, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* The same with a residual operand whose own BatchNorm apply pass was DEFERRED into this call: a projection shortcut is
+ * conv -> BN without activation (resnet.py:90-91) and its only consumer is this layer's `output += identity`
+ * (resnet.py:191-194).  The shortcut's BN is then run with y == NULL (statistics only: its scale[C] | shift[C] are left at
+ * the start of its workspace; copy them out) and `residual` here is the shortcut CONV's output;
+ *   y = act( (x-mean)*invstd*gamma + beta + round_dtype(residual*scale + shift) )
+ * -- bit for bit what the two-call sequence stores, without writing and re-reading the normalised shortcut tensor.
+ * residual_scale_shift: fp32 [2][C]. */
+int cnk_bn_fwd_train_res_affine(const void* x, const float* gamma, const float* beta, const void* residual,
+                                const float* residual_scale_shift, void* y, uint8_t* relu_mask, float* running_mean,
+                                float* running_var, float* save_mean, float* save_invstd, const float* partial,
+                                int64_t partial_slices, int64_t M, int32_t C, float eps, float momentum, int relu,
+                                int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Eval mode (valid_model, basemodel.py:311): running statistics, same fused epilogue. */
 int cnk_bn_fwd_eval(const void* x, const float* gamma, const float* beta, const float* running_mean,
                     const float* running_var, const void* residual, void* y, int64_t M, int32_t C,

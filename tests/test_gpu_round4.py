@@ -333,3 +333,37 @@ def test_graphed_step_captured_at_zero_learning_rate():
     graphed.optimizer.param_groups[0]['weight_decay'] = 0.5
     with pytest.raises(RuntimeError):
         step.replay()
+
+
+@pytest.mark.parametrize('mixed', [False, True])
+def test_deferred_shortcut_bn_apply_is_bit_identical(mixed):
+    """The projection shortcut's BN (conv -> BN, no activation; /root/reference/src/resnet.py:90-91) is applied INSIDE the
+    apply pass of the block's last BN (`output += identity`, resnet.py:191-194; cnk_bn_fwd_train_res_affine) instead of in a
+    pass of its own: same loss, same gradients, same running statistics, bit for bit -- bottleneck and basic blocks."""
+    import convnets_amd as ca
+    from convnets_amd import layers
+    from oracle import torch_ref as tr
+    prev = layers.DEFER_SHORTCUT_BN
+    out = {}
+    try:
+        for kind in (26, 18):
+            for defer in (True, False):
+                layers.DEFER_SHORTCUT_BN = defer
+                torch.manual_seed(21)
+                s = ca.Settings(kind=kind, input_size=(3, 32, 32), num_classes=10, batch_size=16, dropout_rate=0,
+                                mixed_precision=mixed, device='cuda:0')
+                model = ca.ResNet(s).cuda()
+                model.init_optimizer()
+                model.train()
+                x, y = tr.synthetic_batch(16, (3, 32, 32), 10, seed=21)
+                loss, _ = model.train_batch((x, y))
+                torch.cuda.synchronize()
+                out[(kind, defer)] = (float(loss), model.optimizer.flat_g.clone(), model.optimizer.flat_p.clone(),
+                                      [b.clone() for b in model.buffers()])
+    finally:
+        layers.DEFER_SHORTCUT_BN = prev
+    for kind in (26, 18):
+        (l1, g1, p1, b1), (l0, g0, p0, b0) = out[(kind, True)], out[(kind, False)]
+        assert l1 == l0
+        assert torch.equal(g1, g0) and torch.equal(p1, p0)
+        assert all(torch.equal(a, b) for a, b in zip(b1, b0))
