@@ -17,11 +17,11 @@ size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
-int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, hipStream_t s);
+int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 bool bnfold_supported(const cnk_conv_desc* d);
 size_t bnfold_image_bytes(const cnk_conv_desc* d);
 int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s);
-int bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, float* ws, hipStream_t s);
+int bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* sm, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, int dtype, float* ws, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
 bool dwconv_supported(const cnk_conv_desc* d);
 int dwconv_fwd(const cnk_conv_desc* d, const void* x, const float* w, const float* bias, void* y, hipStream_t s);
@@ -472,11 +472,13 @@ int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d) {
 
 size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d) { return bnfold_image_bytes(d); }
 
-int cnk_bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* save_invstd, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int32_t C, void* workspace, size_t workspace_bytes, void* stream) {
-    CNK_CHECK_ARG(ext_partial && ext_slices > 0 && gamma && save_invstd && dgamma && dbeta && coef, "cnk_bn_bwd_coef: null pointer");
+int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int32_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    CNK_CHECK_ARG(gamma && save_mean && save_invstd && dgamma && dbeta && coef, "cnk_bn_bwd_coef: null pointer");
+    CNK_CHECK_ARG(ext_partial ? ext_slices > 0 : (dy && x && ext_slices == 0), "cnk_bn_bwd_coef: either the partial sums of a fused data gradient (ext_partial, ext_slices > 0) or (dy, x) for this call's own reduction");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd_coef: empty tensor");
     CNK_CHECK_ARG(workspace && workspace_bytes >= bn_workspace_bytes(M, C), "cnk_bn_bwd_coef: workspace too small");
-    return bn_bwd_coef(ext_partial, ext_slices, gamma, save_invstd, dgamma, dbeta, accumulate, coef, M, C, (float*)workspace, S(stream));
+    ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, ext_partial ? 0.0 : 2.0 * (double)M * C * esize(dtype));
+    return bn_bwd_coef(dy, x, ext_partial, ext_slices, gamma, save_mean, save_invstd, dgamma, dbeta, accumulate, coef, M, C, dtype, (float*)workspace, S(stream));
 }
 
 int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean, const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream) {
@@ -486,8 +488,9 @@ int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void
     return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef, w_fold, bias_fold, S(stream));
 }
 
-int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, void* stream) {
+int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_dgrad_bnfold")) return rc;
+    CNK_CHECK_ARG(!addend_mask || addend, "cnk_conv2d_dgrad_bnfold: addend_mask needs an addend");
     CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_dgrad_bnfold: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
     CNK_CHECK_ARG(g && x && w_fold && bias_fold && dx, "cnk_conv2d_dgrad_bnfold: null pointer");
     double fl, by;
@@ -501,8 +504,9 @@ int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x
         CNK_CHECK_ARG(bn->x && bn->mean && bn->invstd && bn->partial, "cnk_conv2d_dgrad_bnfold: bn fuse: null pointer");
         CNK_CHECK_ARG(!bn->relu || bn->relu_mask || (bn->gamma && bn->beta), "cnk_conv2d_dgrad_bnfold: bn fuse: ReLU without a mask needs gamma and beta");
     }
+    if (addend) by += px * d->Cin * esize(d->dtype);
     ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
-    return igemm_dgrad_bnfold(d, g, x, w_fold, bias_fold, dx, bn, S(stream));
+    return igemm_dgrad_bnfold(d, g, x, w_fold, bias_fold, dx, addend, addend_mask, bn, S(stream));
 }
 
 int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {

@@ -1291,28 +1291,54 @@ int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* ma
 
 // The finalisation half of the backward alone (cnk_bn_bwd_coef): dgamma / dbeta and the three coefficient vectors of
 //   dx = A * (dy' - B1 - xhat * B2),  A = gamma * invstd, B1 = mean(dy'), B2 = mean(dy' * xhat)
-// from the partial sums a consumer conv's data-gradient epilogue left (cnk_bn_bwd_fuse).  The apply pass is not run: the
-// caller folds it into the backward of the 1x1 conv in front of this layer (cnk_conv2d_dgrad_bnfold / _wgrad_bnfold).
-int bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* si, float* dgamma, float* dbeta,
-                int accumulate, float* coef, int64_t M, int C, float* ws, hipStream_t s) {
-    const SliceGeom g = make_geom(M, C, C % 8 == 0 ? 8 : 1);          // (scratch capacity only, as bn_bwd_t<bf16, 8>)
+// from the partial sums a consumer conv's data-gradient epilogue left (cnk_bn_bwd_fuse) -- or, for a layer WITHOUT activation
+// whose gradient arrives as a plain tensor (a projection shortcut's BN), from this call's own reduction pass over (dy, x).
+// The apply pass is not run: the caller folds it into the backward of the 1x1 conv in front of this layer
+// (cnk_conv2d_dgrad_bnfold / _wgrad_bnfold).
+template <typename T, int VEC>
+static int bn_bwd_coef_t(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma,
+                         const float* sm, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M,
+                         int C, float* ws, hipStream_t s) {
+    const SliceGeom g = make_geom(M, C, VEC);
     float* coefA = coef;
     float* coefB1 = coef + C;
     float* coefB2 = coef + 2 * (size_t)C;
     float* scratch = ws + ws_partials_off(C);
     const float* ep = ext_partial;
     int nslices = (int)ext_slices;
-    const BnFinalBwd fin = {gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate};
-    const int fused_final = bn_merge_final(ep, nslices, C, M, scratch, (int64_t)g.slices * C * 3, fin, s);
-    if (fused_final < 0) return -fused_final;
+    int fused_final = 0;
+    if (ext_partial) {
+        const BnFinalBwd fin = {gamma, si, dgamma, dbeta, coefA, coefB1, coefB2, accumulate};
+        fused_final = bn_merge_final(ep, nslices, C, M, scratch, (int64_t)g.slices * C * 3, fin, s);
+        if (fused_final < 0) return -fused_final;
+        if (!fused_final)
+            if (int rc = bn_premerge<2>(ep, nslices, C, scratch, (int64_t)g.slices * C * 3, s)) return rc;
+    } else {
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, ACT_NONE>), dim3(g.slices, g.colgroups), dim3(256), 0, s, (const T*)dy,
+                           (const T*)x, (const T*)nullptr, (const unsigned char*)nullptr, gamma, (const float*)nullptr, sm, si, scratch,
+                           M, C, g);
+        CNK_CHECK_LAUNCH("bn_bwd_reduce");
+        ep = scratch;
+        nslices = g.slices;
+    }
     if (!fused_final) {
-        if (int rc = bn_premerge<2>(ep, nslices, C, scratch, (int64_t)g.slices * C * 3, s)) return rc;
         hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, ep, nslices, C, M, gamma, si, dgamma, dbeta, coefA,
                            coefB1, coefB2, accumulate);
         CNK_CHECK_LAUNCH("bn_bwd_final");
         cnk_count(CNK_CNT_BN_FINAL_LAUNCH);
     }
     return 0;
+}
+
+int bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* sm,
+                const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, int dtype, float* ws,
+                hipStream_t s) {
+    if (dtype == CNK_BF16) {
+        if (C % 8 == 0) return bn_bwd_coef_t<bf16, 8>(dy, x, ext_partial, ext_slices, gamma, sm, si, dgamma, dbeta, accumulate, coef, M, C, ws, s);
+        return bn_bwd_coef_t<bf16, 1>(dy, x, ext_partial, ext_slices, gamma, sm, si, dgamma, dbeta, accumulate, coef, M, C, ws, s);
+    }
+    if (C % 4 == 0) return bn_bwd_coef_t<float, 4>(dy, x, ext_partial, ext_slices, gamma, sm, si, dgamma, dbeta, accumulate, coef, M, C, ws, s);
+    return bn_bwd_coef_t<float, 1>(dy, x, ext_partial, ext_slices, gamma, sm, si, dgamma, dbeta, accumulate, coef, M, C, ws, s);
 }
 
 namespace {

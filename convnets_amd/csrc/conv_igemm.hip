@@ -1032,9 +1032,10 @@ int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
 // Data gradient of a dense 1x1 / stride-1 conv with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
 // K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c.
 int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
-                       void* dx, const cnk_bn_bwd_fuse* bn, hipStream_t s) {
+                       void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s) {
     GatherParams p = {};
     p.src = g; p.src2 = x; p.C2 = d->Cin; p.wpk = w_fold; p.dst = dx; p.bias = bias_fold; p.is_dgrad = 1;
+    p.addend = addend; p.addend_mask = addend_mask;
     p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cout;
     p.OH = d->H; p.OW = d->W; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
     p.sm_h = 1; p.sm_w = 1; p.dm_h = 1; p.dm_w = 1; p.d_h0 = 0; p.d_w0 = 0;

@@ -294,7 +294,7 @@ class ConvBlock(nn.Sequential):
         if bn is not None:
             if bn.training:      # the conv epilogue also emits the BN statistics partials
                 # (fold: the BN backward's apply pass runs inside this conv's backward where the shape allows, ops.FoldRecord)
-                fold = ops.FoldRecord() if (ops.BN_FOLD and in_link is None and torch.is_grad_enabled()
+                fold = ops.FoldRecord() if (ops.BN_FOLD and torch.is_grad_enabled()
                                             and isinstance(conv, Conv2d) and conv.kernel_size == (1, 1)) else None
                 y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold)
                 pool = self._linked_pool()
@@ -302,7 +302,7 @@ class ConvBlock(nn.Sequential):
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
                     return bn(y, relu=act, partial=partial, pool=pool)
                 if defer_apply and not act and residual is None and torch.is_grad_enabled() and DEFER_SHORTCUT_BN:
-                    return bn(y, partial=partial, defer=True)
+                    return bn(y, partial=partial, defer=True, fold=fold if (fold is not None and fold.ok) else None)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
                           link=res_link, fold=fold if (fold is not None and fold.ok) else None)
             if not torch.is_grad_enabled():

@@ -465,11 +465,11 @@ class Conv2dFn(torch.autograd.Function):
         ctx.params = (weight, bias)
         ctx.link = link if x_needs_grad else None
         ctx.bn_rec = bn_rec if (x_needs_grad and BN_BWD_FUSE) else None
-        # conv -> BN with the BN backward folded into this conv's backward (FoldRecord): dense 1x1 bf16, no bias, and no
-        # gradient hand-over at the input (the folded data gradient takes no addend)
+        # conv -> BN with the BN backward folded into this conv's backward (FoldRecord): dense 1x1 bf16, no bias
         ctx.fold = None
-        if fold is not None and BN_FOLD and plan.bnfold and bias is None and ctx.link is None and w.dtype == torch.float32 \
-                and x_needs_grad and w_dgrad is not None and desc.N * plan.Ho * plan.Wo * desc.Cout >= BN_FOLD_MIN_ELEMS:
+        if fold is not None and BN_FOLD and plan.bnfold and bias is None and w.dtype == torch.float32 \
+                and x_needs_grad and w_dgrad is not None and desc.N * plan.Ho * plan.Wo * desc.Cout >= BN_FOLD_MIN_ELEMS \
+                and desc.Cout >= 2 * desc.Cin:         # (K grows by Cin / Cout: a 4f -> f conv would read 4f more to save f)
             fold.ok = True
             ctx.fold = fold
         if want_bn_partial:
@@ -532,9 +532,9 @@ class Conv2dFn(torch.autograd.Function):
                                               rec.gamma.data_ptr(), rec.beta.data_ptr(),
                                               rec.mask.data_ptr() if rec.mask is not None else None,
                                               partial.data_ptr(), int(rec.relu))
-                if fold is not None:           # (ctx.link is None: no addend)
+                if fold is not None:
                     check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(desc), _p(dy), _p(x), _p(w_fold), _p(bias_fold), _p(out),
-                                                      ctypes.byref(fuse) if fuse else None, _stream()))
+                                                      _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None, _stream()))
                 else:
                     check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(out),
                                                _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None,
@@ -714,9 +714,19 @@ class BatchNormActFn(torch.autograd.Function):
             dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(bn_sizes(M, C, _dtype_code(x))[0], x.device)
-        check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(mask), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
-                             _p(dx), _p(dres_out), _p(dg_buf), _p(db_buf), int(direct), None, 0, M, C,
-                             int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
+        fold = ctx.fold
+        if fold is not None and fold.ok and not ctx.relu and not ctx.has_res:
+            # a BN without activation behind a foldable 1x1 conv (a projection shortcut): this call runs the reduction pass
+            # only; the apply pass is folded into the conv's backward (FoldRecord), which receives dy itself
+            coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+            check(lib.cnk_bn_bwd_coef(_p(dy), _p(x), None, 0, _p(gamma), _p(save_mean), _p(save_invstd), _p(dg_buf), _p(db_buf),
+                                      int(direct), _p(coef), M, C, _dtype_code(x), _p(ws), ws.numel(), _stream()))
+            fold.g, fold.y, fold.mean, fold.invstd, fold.coef = dy, x, save_mean, save_invstd, coef
+            dx = dy
+        else:
+            check(lib.cnk_bn_bwd(_p(dy), _p(x), _p(y), _p(mask), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                 _p(dx), _p(dres_out), _p(dg_buf), _p(db_buf), int(direct), None, 0, M, C,
+                                 int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(), _stream()))
         if direct:
             _grad_written(pg)
             _grad_written(pb)
@@ -748,8 +758,9 @@ class BatchNormActFn(torch.autograd.Function):
             # the apply pass is folded into the backward of the 1x1 conv that produced x (FoldRecord): finalise only, and
             # hand dy itself on as that conv's incoming "gradient"
             coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
-            check(lib.cnk_bn_bwd_coef(_p(ext_partial), ext_partial.shape[0], _p(gamma), _p(save_invstd), _p(dg_buf),
-                                      _p(db_buf), int(direct), _p(coef), M, C, _p(ws), ws.numel(), _stream()))
+            check(lib.cnk_bn_bwd_coef(None, None, _p(ext_partial), ext_partial.shape[0], _p(gamma), _p(save_mean), _p(save_invstd),
+                                      _p(dg_buf), _p(db_buf), int(direct), _p(coef), M, C, _dtype_code(x), _p(ws), ws.numel(),
+                                      _stream()))
             fold.g, fold.y, fold.mean, fold.invstd, fold.coef = dy, x, save_mean, save_invstd, coef
             dx = dy
         else:

@@ -220,22 +220,24 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
  * is ONE GEMM over K = Cout + Cin and the [M][Cout] tensor dy_conv is never written (csrc/bnfold.hip).  Sequence:
  *   1. a consumer's cnk_conv2d_dgrad with a cnk_bn_bwd_fuse record leaves g (masked) and the partial sums;
  *   2. cnk_bn_bwd_coef: dgamma / dbeta and coef[3][C] = A | B1 | B2 (fp32) from those partials (no apply pass);
- *      workspace: cnk_bn_workspace_bytes(M, C);
+ *      workspace: cnk_bn_workspace_bytes(M, C).  With ext_partial == NULL (and ext_slices == 0) the call runs the
+ *      reduction pass itself over (dy, x): for a BN layer WITHOUT activation whose gradient arrives as a plain tensor (a
+ *      projection shortcut, resnet.py:90-91);
  *   3. cnk_conv2d_bnfold_prepare: the per-step weight image w_fold (cnk_conv2d_bnfold_image_bytes) and bias_fold[Cin] from
  *      the fp32 master weights w [Cout][Cin], the packed data-gradient image w_dgrad and coef;
- *   4. cnk_conv2d_dgrad_bnfold(g, x = the conv input, ...) -> dx, with the same optional fused BN backward of the layer that
- *      produced x as cnk_conv2d_dgrad;  cnk_conv2d_wgrad_bnfold(g, y = the conv output, x, ...) -> dw, which forms dy_conv
+ *   4. cnk_conv2d_dgrad_bnfold(g, x = the conv input, ...) -> dx, with the same optional gradient addend (+ packed mask) and
+ *      fused BN backward of the layer that produced x as cnk_conv2d_dgrad;  cnk_conv2d_wgrad_bnfold(g, y = the conv output, x, ...) -> dw, which forms dy_conv
  *      while staging its tiles, bit for bit the tensor cnk_bn_bwd would have written (workspace as cnk_conv2d_wgrad).
  * cnk_conv2d_bnfold_supported: bf16, 1x1, stride 1, no padding, dense, both channel counts multiples of 64. */
 int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d);
 size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d);
-int cnk_bn_bwd_coef(const float* ext_partial, int64_t ext_slices, const float* gamma, const float* save_invstd,
-                    float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int32_t C, void* workspace,
-                    size_t workspace_bytes, void* stream);
+int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int accumulate,
+                    float* coef, int64_t M, int32_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean,
                               const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream);
 int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
-                            void* dx, const cnk_bn_bwd_fuse* bn, void* stream);
+                            void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream);
 int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean,
                             const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace,
                             size_t workspace_bytes, void* stream);

@@ -84,8 +84,8 @@ class FoldCase:
         coef = torch.empty(3 * C, device=dev)
         nws = lib.cnk_bn_workspace_bytes(self.M, C)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        _lib.check(lib.cnk_bn_bwd_coef(P(self.partial), 1, P(self.gamma), P(self.invstd), P(dgamma), P(dbeta), 0, P(coef), self.M, C,
-                                       P(ws), nws, _stream()))
+        _lib.check(lib.cnk_bn_bwd_coef(None, None, P(self.partial), 1, P(self.gamma), P(self.mean), P(self.invstd), P(dgamma), P(dbeta), 0,
+                                       P(coef), self.M, C, _lib.CNK_BF16, P(ws), nws, _stream()))
         return coef, dgamma, dbeta
 
     def unfolded_dxconv(self, lib, _lib):
@@ -179,7 +179,7 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
     with _lib.switches(CNK_GEMM1X1=g1):
         c0 = cnt(counter)
         da_f = torch.empty_like(fc.a, memory_format=CL)
-        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da_f), None, _stream()))
+        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da_f), None, None, None, _stream()))
         assert cnt(counter) == c0 + 1, 'the folded data gradient did not run on the expected kernel'
         da_u = torch.empty_like(fc.a, memory_format=CL)
         _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da_u), None, None, None, None, 0, _stream()))
@@ -222,8 +222,8 @@ def test_bnfold_dgrad_with_fused_bn_backward_in_front(case):
                                   part.data_ptr(), 1)
             da = torch.empty_like(fc.a, memory_format=CL)
             if folded:
-                _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da), ctypes.byref(fuse),
-                                                       _stream()))
+                _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da), None, None,
+                                                       ctypes.byref(fuse), _stream()))
             else:
                 _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da), None, None, ctypes.byref(fuse), None, 0,
                                                 _stream()))
@@ -367,3 +367,45 @@ def test_deferred_shortcut_bn_apply_is_bit_identical(mixed):
         assert l1 == l0
         assert torch.equal(g1, g0) and torch.equal(p1, p0)
         assert all(torch.equal(a, b) for a, b in zip(b1, b0))
+
+
+def test_fold_of_a_projection_shortcut_bn_with_gradient_handover():
+    """The projection shortcut of a stage's first block (conv 1x1 -> BN, no activation; /root/reference/src/resnet.py:90-91):
+    its BN backward runs the reduction pass only (cnk_bn_bwd_coef with (dy, x)) and the apply pass is folded into the conv's
+    backward, whose data gradient also takes the main branch's gradient as addend (ops.GradLink).  Fold on / off on a
+    ResNet-26 step: same loss, gradients within bf16 rounding; the stride-1 shortcut of the first stage folds."""
+    import convnets_amd as ca
+    from convnets_amd import ops
+    from oracle import torch_ref as tr
+    prev, prev_min = ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS
+    ops.BN_FOLD_MIN_ELEMS = 0
+    res = {}
+    try:
+        for fold in (True, False):
+            ops.BN_FOLD = fold
+            torch.manual_seed(5)
+            s = ca.Settings(kind=26, input_size=(3, 64, 64), num_classes=10, batch_size=32, dropout_rate=0, mixed_precision=True,
+                            device='cuda:0')
+            model = ca.ResNet(s)
+            tr.damp_residual_branches(model, 0.1)
+            model = model.cuda()
+            model.init_optimizer()
+            model.train()
+            x, y = tr.synthetic_batch(32, (3, 64, 64), 10, seed=5)
+            ops.FOLD_COUNTS['folded'] = 0
+            loss, _ = model.train_batch((x, y))
+            torch.cuda.synchronize()
+            res[fold] = (float(loss), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()},
+                         ops.FOLD_COUNTS['folded'])
+    finally:
+        ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS = prev, prev_min
+    (l1, g1, n1), (l0, g0, n0) = res[True], res[False]
+    assert n0 == 0 and n1 >= 8, n1                  # 7 last-block convs + the stride-1 projection shortcut of stage 1
+    assert l1 == l0
+    key = 'features.2.dim_synch.0.weight'           # the folded shortcut conv's own weight gradient
+    e = float((g1[key] - g0[key]).norm() / g0[key].norm())
+    print('shortcut conv weight gradient, fold on vs off: %.2e' % e)
+    assert e < 2e-2
+    num = sum(float(((g1[k] - g0[k]) ** 2).sum()) for k in g0)
+    den = sum(float((g0[k] ** 2).sum()) for k in g0)
+    assert math.sqrt(num / den) < 3e-2

@@ -48,9 +48,9 @@ for Cin, Cout, H, count in LAYERS:
                                            P(part_in), nsl_in, M, Cout, 0, _lib.CNK_BF16, P(wsbn), nbn, st()),
         'dgrad': lambda i: lib.cnk_conv2d_dgrad(D, P(dxc[i]), P(wd), P(da[i]), None, None, ctypes.byref(fuses[i]), None, 0, st()),
         'wgrad': lambda i: lib.cnk_conv2d_wgrad(D, P(dxc[i]), P(a[i]), P(dw), None, 0, P(ws), nws, st()),
-        'coef': lambda i: lib.cnk_bn_bwd_coef(P(part_in), nsl_in, P(gamma), P(invstd), P(dgamma), P(dbeta), 0, P(coef), M, Cout, P(wsbn), nbn, st()),
+        'coef': lambda i: lib.cnk_bn_bwd_coef(None, None, P(part_in), nsl_in, P(gamma), P(mean), P(invstd), P(dgamma), P(dbeta), 0, P(coef), M, Cout, _lib.CNK_BF16, P(wsbn), nbn, st()),
         'prep': lambda i: lib.cnk_conv2d_bnfold_prepare(D, P(w), P(wd), P(mean), P(invstd), P(coef), P(w_fold), P(bias_fold), st()),
-        'dgrad_f': lambda i: lib.cnk_conv2d_dgrad_bnfold(D, P(g[i]), P(a[i]), P(w_fold), P(bias_fold), P(da[i]), ctypes.byref(fuses[i]), st()),
+        'dgrad_f': lambda i: lib.cnk_conv2d_dgrad_bnfold(D, P(g[i]), P(a[i]), P(w_fold), P(bias_fold), P(da[i]), None, None, ctypes.byref(fuses[i]), st()),
         'wgrad_f': lambda i: lib.cnk_conv2d_wgrad_bnfold(D, P(g[i]), P(y[i]), P(a[i]), P(mean), P(invstd), P(coef), P(dw), 0, P(ws), nws, st()),
     }
     res = {}
