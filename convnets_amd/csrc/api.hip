@@ -496,8 +496,13 @@ int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x
     double fl, by;
     conv_cost(d, &fl, &by);
     const double px = (double)d->N * d->H * d->W;
-    fl += 2.0 * px * d->Cin * d->Cin;                                   // the second K segment
-    by += px * d->Cin * esize(d->dtype);                                // ... reads the conv input
+    {
+        int Ho, Wo;
+        cnk_conv2d_out_hw(d, &Ho, &Wo);
+        const double pxo = (double)d->N * Ho * Wo;                      // the pixels the conv samples (stride)
+        fl += 2.0 * pxo * d->Cin * d->Cin;                              // the second K segment
+        by += pxo * d->Cin * esize(d->dtype);                           // ... reads the conv input there
+    }
     if (bn) {
         by += px * d->Cin * esize(d->dtype);
         CNK_CHECK_ARG(cnk_conv2d_dgrad_bn_slices(d) > 0, "cnk_conv2d_dgrad_bnfold: this conv shape cannot fuse the BN backward (cnk_conv2d_dgrad_bn_slices == 0)");
@@ -517,7 +522,11 @@ int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y
     CNK_CHECK_ARG(workspace && workspace_bytes >= slab, "cnk_conv2d_wgrad_bnfold: workspace too small (%zu < %zu)", workspace_bytes, slab);
     double fl, by;
     conv_cost(d, &fl, &by);
-    by += (double)d->N * d->H * d->W * d->Cout * esize(d->dtype);       // the BN input is read beside the gradient
+    {
+        int Ho, Wo;
+        cnk_conv2d_out_hw(d, &Ho, &Wo);
+        by += (double)d->N * Ho * Wo * d->Cout * esize(d->dtype);       // the BN input is read beside the gradient
+    }
     ProfScope ps(conv_cls(d, 2), S(stream), fl, by);
     const size_t planned = wgrad_mfma_workspace(d);
     const size_t avail = workspace_bytes & ~(size_t)255;

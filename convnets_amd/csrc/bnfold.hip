@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256) void bnfold_prep_kernel(const FoldPrepParams p
 }  // namespace
 
 bool bnfold_supported(const cnk_conv_desc* d) {
-    return d->dtype == CNK_BF16 && conv_groups(d) == 1 && conv_dil(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h == 1 &&
-           d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 && d->Cout % 64 == 0 && d->Cout <= FP_MAXC;
+    return d->dtype == CNK_BF16 && conv_groups(d) == 1 && conv_dil(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h >= 1 &&
+           d->stride_w >= 1 && d->stride_h * d->stride_w <= 16 && d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 &&
+           d->Cout % 64 == 0 && d->Cout <= FP_MAXC;
 }
 
 size_t bnfold_image_bytes(const cnk_conv_desc* d) { return (size_t)d->Cin * (d->Cout + d->Cin) * sizeof(bf16); }

@@ -439,8 +439,6 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
         if (!seg2 && ++ld_cs == csteps) { ld_cs = 0; ++ld_t; }
         const int tp = seg2 ? 0 : tap_tab[t];        // LDS (uniform address: broadcast), lgkmcnt only
         const int dh = tp >> 16, dw = (int)(short)(tp & 0xffff);
-        const T* sp = seg2 ? (const T*)p.src2 : src;
-        const int sC = seg2 ? p.C2 : p.C;
         const size_t wo = seg2 ? (size_t)p.ntaps * p.Cpad + cb : (size_t)t * p.Cpad + cb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -449,8 +447,16 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
             const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
             const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW &&
                             (!EDGE || cb + c * PER16 < p.C);
-            const T* gp = ok ? sp + ((size_t)(a_base[i] + ih) * p.IW + iw) * sC + cb + c * PER16
+            const T* gp = ok ? src + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C + cb + c * PER16
                              : (const T*)cnk_zero16;
+            if constexpr (CAT) {
+                // second segment: the row of src2 is the DESTINATION pixel of this tile row (the conv input at the pixel whose
+                // gradient the row computes; row_dst also carries the stride-parity class of a strided 1x1 conv)
+                if (seg2) {
+                    const int pix = row_dst[r];
+                    gp = pix >= 0 ? (const T*)p.src2 + (size_t)pix * p.C2 + cb + c * PER16 : (const T*)cnk_zero16;
+                }
+            }
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
         }
 #pragma unroll
@@ -871,8 +877,9 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         a.algo_bytes = gather_bytes(p, sizeof(T));
         return pp3x3_launch(a, s);
     }
-    if (p.src2) CNK_CHECK_ARG(sizeof(T) == 2 && !p.chunked && dense_1x1(p) && p.C2 % KS == 0 && !p.relu && !p.stats && p.bias,
-                              "igemm: a second K segment needs a dense bf16 1x1 launch with C2 on the K-step grid");
+    if (p.src2) CNK_CHECK_ARG(sizeof(T) == 2 && !p.chunked && p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.sm_h == 1 && p.sm_w == 1 &&
+                                  (p.Cpad == 0 || p.Cpad == p.C) && p.C2 % KS == 0 && !p.relu && !p.stats && p.bias,
+                              "igemm: a second K segment needs a bf16 one-tap launch with C2 on the K-step grid and a bias");
     if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.relu && !(p.stats && (p.addend || p.bnf_x)))
         if (const int nj = gemm1x1_pick(p.M, p.C + (p.src2 ? p.C2 : 0), p.Nout, p.addend || p.bnf_x)) {
             G1Args a = {};
@@ -1029,27 +1036,45 @@ int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     return n;
 }
 
-// Data gradient of a dense 1x1 / stride-1 conv with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
-// K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c.
+// Data gradient of a 1x1 conv (no padding, any stride) with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
+// K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c -- for the stride-parity class that
+// holds the conv's one tap; the other classes of a strided conv see no output pixel: zeros (+ addend, + fused BN backward).
 int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
                        void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s) {
-    GatherParams p = {};
-    p.src = g; p.src2 = x; p.C2 = d->Cin; p.wpk = w_fold; p.dst = dx; p.bias = bias_fold; p.is_dgrad = 1;
-    p.addend = addend; p.addend_mask = addend_mask;
-    p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cout;
-    p.OH = d->H; p.OW = d->W; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
-    p.sm_h = 1; p.sm_w = 1; p.dm_h = 1; p.dm_w = 1; p.d_h0 = 0; p.d_w0 = 0;
-    p.ntaps = 1; p.dh[0] = 0; p.dw[0] = 0;
-    p.M = d->N * d->H * d->W;
-    if (p.M == 0) return 0;
-    if (bn) {
-        p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;
-        p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
-        p.bnf_relu = bn->relu; p.bnf_tile0 = 0;
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    DgradClass cls[16];
+    CNK_CHECK_ARG(d->stride_h * d->stride_w <= 16, "igemm_dgrad_bnfold: stride too large");
+    const int nc = dgrad_classes(d, cls);
+    int tile0 = 0;
+    for (int c = 0; c < nc; ++c) {
+        const DgradClass& k = cls[c];
+        GatherParams p = {};
+        p.src = g; p.wpk = w_fold; p.dst = dx; p.is_dgrad = 1;
+        p.addend = addend; p.addend_mask = addend_mask;
+        p.N = d->N; p.IH = Ho; p.IW = Wo; p.C = d->Cout;
+        p.OH = k.OH; p.OW = k.OW; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
+        p.sm_h = 1; p.sm_w = 1;
+        p.dm_h = d->stride_h; p.dm_w = d->stride_w; p.d_h0 = k.ph; p.d_w0 = k.pw;
+        p.ntaps = k.ntaps;
+        for (int t = 0; t < k.ntaps; ++t) { p.dh[t] = k.dh[t]; p.dw[t] = k.dw[t]; }
+        if (k.ntaps) {                               // the class of the tap: the folded GEMM
+            CNK_CHECK_ARG(k.ntaps == 1 && k.dh[0] == 0 && k.dw[0] == 0, "igemm_dgrad_bnfold: not a 1x1 conv");
+            p.src2 = x; p.C2 = d->Cin; p.bias = bias_fold;
+        }
+        p.M = d->N * k.OH * k.OW;
+        if (p.M == 0) continue;
+        if (bn) {
+            p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;
+            p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
+            p.bnf_relu = bn->relu; p.bnf_tile0 = tile0;
+            tile0 += ceil_div(p.M, BM);
+        }
+        p.fd_ohw = make_fastdiv(k.OH * k.OW);
+        p.fd_ow = make_fastdiv(k.OW);
+        if (int rc = launch_gather_bn<bf16>(p, s)) return rc;
     }
-    p.fd_ohw = make_fastdiv(d->H * d->W);
-    p.fd_ow = make_fastdiv(d->W);
-    return launch_gather_bn<bf16>(p, s);
+    return 0;
 }
 
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,

@@ -257,6 +257,10 @@ BN_FOLD = os.environ.get('CNK_BN_FOLD', '1') != '0'
 # BN input read beside the gradient): measured per ResNet-50 stage at batch 256 (tools/bench_fold.py) 366 -> 163 / 203 -> 110 /
 # 119 -> 83 / 87 -> 91 us on the compute stream, i.e. not at 7x7; the rule below is M * Cout elements of the BN tensor.
 BN_FOLD_MIN_ELEMS = float(os.environ.get('CNK_BN_FOLD_MIN', '4e7'))
+# strided projection shortcuts too?  The library folds them (the stride-parity class of the tap; tests/test_gpu_round4.py), but
+# in the ResNet-50 step it measured neutral (19.23 vs 19.26 ms, four alternating pairs): the removed apply pass is a quarter of
+# the stride-1 one's size and the data gradient's K grows by a half.  Off by default.
+BN_FOLD_STRIDED = os.environ.get('CNK_BN_FOLD_STRIDED', '0') != '0'
 FOLD_COUNTS = {'folded': 0}               # folded conv backward passes (tests read this)
 BN_BWD_FUSE = os.environ.get('CNK_BN_BWD_FUSE', '1') != '0'
 # the same fusion for the stride-1 3x3 convs only (A/B switch, DESIGN.md: break-even per layer, see there)
@@ -469,7 +473,8 @@ class Conv2dFn(torch.autograd.Function):
         ctx.fold = None
         if fold is not None and BN_FOLD and plan.bnfold and bias is None and w.dtype == torch.float32 \
                 and x_needs_grad and w_dgrad is not None and desc.N * plan.Ho * plan.Wo * desc.Cout >= BN_FOLD_MIN_ELEMS \
-                and desc.Cout >= 2 * desc.Cin:         # (K grows by Cin / Cout: a 4f -> f conv would read 4f more to save f)
+                and desc.Cout >= 2 * desc.Cin \
+                and (desc.stride_h == 1 or BN_FOLD_STRIDED):   # (K grows by Cin / Cout: a 4f -> f conv would read 4f more to save f)
             fold.ok = True
             ctx.fold = fold
         if want_bn_partial:

@@ -228,7 +228,8 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
  *   4. cnk_conv2d_dgrad_bnfold(g, x = the conv input, ...) -> dx, with the same optional gradient addend (+ packed mask) and
  *      fused BN backward of the layer that produced x as cnk_conv2d_dgrad;  cnk_conv2d_wgrad_bnfold(g, y = the conv output, x, ...) -> dw, which forms dy_conv
  *      while staging its tiles, bit for bit the tensor cnk_bn_bwd would have written (workspace as cnk_conv2d_wgrad).
- * cnk_conv2d_bnfold_supported: bf16, 1x1, stride 1, no padding, dense, both channel counts multiples of 64. */
+ * cnk_conv2d_bnfold_supported: bf16, 1x1, no padding, any stride (a strided conv's data gradient folds in the stride-parity
+ * class that holds its tap), dense, both channel counts multiples of 64. */
 int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d);
 size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d);
 int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma,

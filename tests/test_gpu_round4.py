@@ -43,22 +43,24 @@ class FoldCase:
     """One conv(1x1, Cin -> Cout) -> BN layer pair in the middle of a backward pass: the conv input a (a ReLU output), the
     conv output y, the masked gradient g w.r.t. the BN output and the partial sums a consumer's epilogue would have left."""
 
-    def __init__(self, N, Cin, Cout, H, W, seed):
+    def __init__(self, N, Cin, Cout, H, W, seed, stride=1):
         from convnets_amd import _lib, ops
         lib = _lib.load()
         gen = torch.Generator().manual_seed(seed)
         dev = 'cuda'
-        self.N, self.Cin, self.Cout, self.H, self.W = N, Cin, Cout, H, W
-        self.M = M = N * H * W
+        self.N, self.Cin, self.Cout, self.H, self.W, self.stride = N, Cin, Cout, H, W, stride
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        self.Ho, self.Wo = Ho, Wo
+        self.M = M = N * Ho * Wo                     # rows of the conv output / BN tensors
         a = torch.relu(torch.randn(N, Cin, H, W, generator=gen)).bfloat16()
         w = torch.randn(Cout, Cin, 1, 1, generator=gen) / math.sqrt(Cin)
         self.a = a.to(dev).contiguous(memory_format=CL)
         self.w = w.to(dev)
-        self.desc = d = ops.make_desc(self.a.shape, self.w.shape, (1, 1), (0, 0), _lib.CNK_BF16)
+        self.desc = d = ops.make_desc(self.a.shape, self.w.shape, (stride, stride), (0, 0), _lib.CNK_BF16)
         self.w_fwd = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_FWD), dtype=torch.uint8, device=dev)
         self.w_dgrad = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_DGRAD), dtype=torch.uint8, device=dev)
         _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(self.w), P(self.w_fwd), P(self.w_dgrad), _stream()))
-        self.y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=dev, memory_format=CL)
+        self.y = torch.empty((N, Cout, Ho, Wo), dtype=torch.bfloat16, device=dev, memory_format=CL)
         _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(self.a), P(self.w_fwd), None, P(self.y), None, None, 0, _stream()))
         y64 = self.y.permute(0, 2, 3, 1).reshape(M, Cout).double().cpu()
         mean = y64.mean(0)
@@ -70,7 +72,7 @@ class FoldCase:
         xhat = ((y64 - mean) * invstd).float()
         g = torch.randn(M, Cout, generator=gen) * 0.5 + 0.1 * torch.randn(Cout, generator=gen) + 0.2 * xhat * torch.randn(Cout, generator=gen)
         g = g * (torch.rand(M, Cout, generator=gen) > 0.4)
-        self.g = g.bfloat16().reshape(N, H, W, Cout).permute(0, 3, 1, 2).to(dev).contiguous(memory_format=CL)
+        self.g = g.bfloat16().reshape(N, Ho, Wo, Cout).permute(0, 3, 1, 2).to(dev).contiguous(memory_format=CL)
         g64 = self.g.permute(0, 2, 3, 1).reshape(M, Cout).double().cpu()
         m32, i32 = self.mean.double().cpu(), self.invstd.double().cpu()
         S = g64.sum(0)
@@ -107,7 +109,17 @@ class FoldCase:
         A, B1, B2 = c[:C], c[C:2 * C], c[2 * C:]
         m, i = self.mean.double().cpu(), self.invstd.double().cpu()
         dxc = A * (self.g64 - B1 - (self.y64 - m) * i * B2)
-        return dxc, dxc @ self.w.double().cpu().reshape(C, self.Cin)
+        da = dxc @ self.w.double().cpu().reshape(C, self.Cin)
+        if self.stride > 1:                          # the gradient lands on the sampled pixels, zeros elsewhere
+            full = torch.zeros(self.N, self.H, self.W, self.Cin, dtype=torch.float64)
+            full[:, ::self.stride, ::self.stride, :] = da.reshape(self.N, self.Ho, self.Wo, self.Cin)
+            da = full.reshape(-1, self.Cin)
+        return dxc, da
+
+    def a_sampled64(self):
+        """The conv input at the pixels the conv reads, [M][Cin] fp64."""
+        a = self.a.permute(0, 2, 3, 1)[:, ::self.stride, ::self.stride, :]
+        return a.reshape(self.M, self.Cin).double().cpu()
 
 
 # (N, Cin, Cout, H, W, CNK_GEMM1X1, expected launch counter)
@@ -118,7 +130,10 @@ FOLD_CASES = {
     'ring2_n64_256_1024_14': (64, 256, 1024, 14, 14, '1', CNT_G1_2),         # the rule's choice at this size: 256 x 128 tiles
     'ring4_n64_256_1024_14': (64, 256, 1024, 14, 14, '4', CNT_G1_4),         # 256 x 256 tiles forced
     'ring2_n40_512_2048_7': (40, 512, 2048, 7, 7, '2', CNT_G1_2),            # 7x7, K = 2048 + 512, M = 1960 (ragged)
+    'strided_n8_128_256_14': (8, 128, 256, 14, 14, '1', CNT_GATHER),         # stride 2 (a projection shortcut): 4 parity classes
+    'strided_n6_64_128_9x13': (6, 64, 128, 9, 13, '1', CNT_GATHER),          # stride 2 on an odd image: ragged classes
 }
+FOLD_STRIDE = {'strided_n8_128_256_14': 2, 'strided_n6_64_128_9x13': 2}
 
 
 @pytest.mark.parametrize('case', sorted(FOLD_CASES))
@@ -126,7 +141,7 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
     from convnets_amd import ops
     _lib, lib, cnt = _lib_and_counter()
     N, Cin, Cout, H, W, g1, counter = FOLD_CASES[case]
-    fc = FoldCase(N, Cin, Cout, H, W, seed=4 + len(case))
+    fc = FoldCase(N, Cin, Cout, H, W, seed=4 + len(case), stride=FOLD_STRIDE.get(case, 1))
     d, dev = fc.desc, 'cuda'
     assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)) == 1
     coef, dgamma, dbeta = fc.coef(lib, _lib)
@@ -146,7 +161,7 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
         _lib.check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.y), P(fc.a), P(fc.mean), P(fc.invstd), P(coef), P(dw_f), 0,
                                                P(ws), budget, _stream()))
         assert torch.equal(dw_u, dw_f), 'folded weight gradient differs from bn_bwd + wgrad (share %.1f)' % share
-    dw64 = dxc64.t() @ fc.a.permute(0, 2, 3, 1).reshape(fc.M, Cin).double().cpu()
+    dw64 = dxc64.t() @ fc.a_sampled64()
     assert rel_l2(dw_f.reshape(Cout, Cin).double().cpu().numpy(), dw64.numpy()) < 4e-3
     # accumulate flag
     dw_acc = torch.ones(Cout, Cin, 1, 1, device=dev)
@@ -180,13 +195,17 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
         c0 = cnt(counter)
         da_f = torch.empty_like(fc.a, memory_format=CL)
         _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da_f), None, None, None, _stream()))
-        assert cnt(counter) == c0 + 1, 'the folded data gradient did not run on the expected kernel'
+        assert cnt(counter) == c0 + (1 if fc.stride == 1 else fc.stride ** 2), 'the folded data gradient did not run on the expected kernel'
         da_u = torch.empty_like(fc.a, memory_format=CL)
         _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da_u), None, None, None, None, 0, _stream()))
     torch.cuda.synchronize()
     ref = da64.numpy()
-    e_f = rel_l2(da_f.permute(0, 2, 3, 1).reshape(fc.M, Cin).double().cpu().numpy(), ref)
-    e_u = rel_l2(da_u.permute(0, 2, 3, 1).reshape(fc.M, Cin).double().cpu().numpy(), ref)
+    e_f = rel_l2(da_f.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), ref)
+    e_u = rel_l2(da_u.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), ref)
+    if fc.stride > 1:                                # pixels the conv never read: exact zeros
+        zmask = torch.ones(fc.N, fc.H, fc.W, dtype=torch.bool)
+        zmask[:, ::fc.stride, ::fc.stride] = False
+        assert torch.all(da_f.permute(0, 2, 3, 1).cpu()[zmask] == 0)
     print('%s: folded %.2e unfolded %.2e (vs fp64)' % (case, e_f, e_u))
     assert e_f < 4e-3 and e_u < 4e-3
 
