@@ -17,10 +17,10 @@ size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
-int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
+int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x2, int mode, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 bool bnfold_supported(const cnk_conv_desc* d);
-size_t bnfold_image_bytes(const cnk_conv_desc* d);
-int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s);
+size_t bnfold_image_bytes(const cnk_conv_desc* d, int mode);
+int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, int mode, void* w_fold, float* bias_fold, hipStream_t s);
 int bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* sm, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, int dtype, float* ws, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
 bool dwconv_supported(const cnk_conv_desc* d);
@@ -470,7 +470,7 @@ int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d) {
            wgrad_mfma_supported(d);
 }
 
-size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d) { return bnfold_image_bytes(d); }
+size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d, int mode) { return bnfold_image_bytes(d, mode); }
 
 int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int32_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(gamma && save_mean && save_invstd && dgamma && dbeta && coef, "cnk_bn_bwd_coef: null pointer");
@@ -481,14 +481,16 @@ int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int
     return bn_bwd_coef(dy, x, ext_partial, ext_slices, gamma, save_mean, save_invstd, dgamma, dbeta, accumulate, coef, M, C, dtype, (float*)workspace, S(stream));
 }
 
-int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean, const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream) {
+int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean, const float* save_invstd, const float* coef, int mode, void* w_fold, float* bias_fold, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_bnfold_prepare")) return rc;
     CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_bnfold_prepare: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
     CNK_CHECK_ARG(w && w_dgrad && save_mean && save_invstd && coef && w_fold && bias_fold, "cnk_conv2d_bnfold_prepare: null pointer");
-    return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef, w_fold, bias_fold, S(stream));
+    CNK_CHECK_ARG(mode == 0 || mode == 1, "cnk_conv2d_bnfold_prepare: mode is 0 (second segment = the conv input) or 1 (= the conv output)");
+    return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef, mode, w_fold, bias_fold, S(stream));
 }
 
-int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream) {
+int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, int mode, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream) {
+    CNK_CHECK_ARG(mode == 0 || mode == 1, "cnk_conv2d_dgrad_bnfold: mode is 0 (x = the conv input) or 1 (x = the conv output)");
     if (int rc = check_desc(d, "cnk_conv2d_dgrad_bnfold")) return rc;
     CNK_CHECK_ARG(!addend_mask || addend, "cnk_conv2d_dgrad_bnfold: addend_mask needs an addend");
     CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_dgrad_bnfold: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
@@ -500,8 +502,9 @@ int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x
         int Ho, Wo;
         cnk_conv2d_out_hw(d, &Ho, &Wo);
         const double pxo = (double)d->N * Ho * Wo;                      // the pixels the conv samples (stride)
-        fl += 2.0 * pxo * d->Cin * d->Cin;                              // the second K segment
-        by += pxo * d->Cin * esize(d->dtype);                           // ... reads the conv input there
+        const int c2 = mode ? d->Cout : d->Cin;
+        fl += 2.0 * pxo * d->Cin * c2;                                  // the second K segment
+        by += pxo * c2 * esize(d->dtype);                               // ... reads the conv input (mode 1: output) there
     }
     if (bn) {
         by += px * d->Cin * esize(d->dtype);
@@ -511,7 +514,7 @@ int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x
     }
     if (addend) by += px * d->Cin * esize(d->dtype);
     ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
-    return igemm_dgrad_bnfold(d, g, x, w_fold, bias_fold, dx, addend, addend_mask, bn, S(stream));
+    return igemm_dgrad_bnfold(d, g, x, mode, w_fold, bias_fold, dx, addend, addend_mask, bn, S(stream));
 }
 
 int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {

@@ -41,6 +41,7 @@ struct GatherParams {
     // layer behind the conv (cnk_conv2d_dgrad_bnfold): K = [dy' | conv input].
     const void* src2;
     int C2;
+    int src2_at_src;         // 0: src2 rows are the row's DESTINATION pixel; 1: the row's SOURCE pixel (src2 shaped like src)
     const void* addend;      // optional tensor shaped like dst: dst = conv + addend (fused grad sum)
     const unsigned char* addend_mask;   // optional packed ReLU mask (1 byte per 16-B vector) gating addend
     float* stats;            // optional [tiles_m][Nout][3] BN partials (n, mean, M2) of the OUTPUT
@@ -453,8 +454,13 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
                 // second segment: the row of src2 is the DESTINATION pixel of this tile row (the conv input at the pixel whose
                 // gradient the row computes; row_dst also carries the stride-parity class of a strided 1x1 conv)
                 if (seg2) {
-                    const int pix = row_dst[r];
-                    gp = pix >= 0 ? (const T*)p.src2 + (size_t)pix * p.C2 + cb + c * PER16 : (const T*)cnk_zero16;
+                    if (p.src2_at_src) {
+                        gp = ok ? (const T*)p.src2 + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C2 + cb + c * PER16
+                                : (const T*)cnk_zero16;
+                    } else {
+                        const int pix = row_dst[r];
+                        gp = pix >= 0 ? (const T*)p.src2 + (size_t)pix * p.C2 + cb + c * PER16 : (const T*)cnk_zero16;
+                    }
                 }
             }
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
@@ -1039,7 +1045,8 @@ int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
 // Data gradient of a 1x1 conv (no padding, any stride) with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
 // K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c -- for the stride-parity class that
 // holds the conv's one tap; the other classes of a strided conv see no output pixel: zeros (+ addend, + fused BN backward).
-int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
+// mode 1: the second segment is the conv OUTPUT y (Cout channels, at the source pixel of the row) instead of the conv input.
+int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, int mode, const void* w_fold, const float* bias_fold,
                        void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
@@ -1060,7 +1067,7 @@ int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, con
         for (int t = 0; t < k.ntaps; ++t) { p.dh[t] = k.dh[t]; p.dw[t] = k.dw[t]; }
         if (k.ntaps) {                               // the class of the tap: the folded GEMM
             CNK_CHECK_ARG(k.ntaps == 1 && k.dh[0] == 0 && k.dw[0] == 0, "igemm_dgrad_bnfold: not a 1x1 conv");
-            p.src2 = x; p.C2 = d->Cin; p.bias = bias_fold;
+            p.src2 = x; p.C2 = mode ? d->Cout : d->Cin; p.src2_at_src = mode; p.bias = bias_fold;
         }
         p.M = d->N * k.OH * k.OW;
         if (p.M == 0) continue;

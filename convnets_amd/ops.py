@@ -188,7 +188,7 @@ def conv_plan(x_shape, weight_shape, stride, padding, dtype_code, groups, dilati
         pl.wgrad_min_ws_bias = lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(d), 1)
         pl.accepts_mask = bool(lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(d)))
         pl.bnfold = bool(lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)))
-        pl.fold_bytes = lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)) if pl.bnfold else 0
+        pl.fold_bytes = tuple(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), m) for m in (0, 1)) if pl.bnfold else (0, 0)
         if len(_conv_plans) > 4096:
             _conv_plans.clear()
         _conv_plans[key] = pl
@@ -244,10 +244,11 @@ class FoldRecord:
     (dgamma, dbeta, the three coefficient vectors), parks them here together with the gradient w.r.t. the BN OUTPUT, and hands
     that very tensor to autograd as the "gradient" of the conv output; Conv2dFn.backward recognises it (same storage) and runs
     cnk_conv2d_dgrad_bnfold / cnk_conv2d_wgrad_bnfold.  The [M][Cout] gradient w.r.t. the conv output is never written."""
-    __slots__ = ('ok', 'g', 'y', 'mean', 'invstd', 'coef')
+    __slots__ = ('ok', 'mode', 'g', 'y', 'mean', 'invstd', 'coef')
 
     def __init__(self):
         self.ok = False                   # set by Conv2dFn.forward when the conv shape can fold
+        self.mode = 0                     # 0: K = [g | conv input] (widening convs); 1: K = [g | conv output] (narrowing convs)
         self.g = self.y = self.mean = self.invstd = self.coef = None
 
 
@@ -257,6 +258,12 @@ BN_FOLD = os.environ.get('CNK_BN_FOLD', '1') != '0'
 # BN input read beside the gradient): measured per ResNet-50 stage at batch 256 (tools/bench_fold.py) 366 -> 163 / 203 -> 110 /
 # 119 -> 83 / 87 -> 91 us on the compute stream, i.e. not at 7x7; the rule below is M * Cout elements of the BN tensor.
 BN_FOLD_MIN_ELEMS = float(os.environ.get('CNK_BN_FOLD_MIN', '4e7'))
+# mode 1 (a conv that narrows, Cout <= Cin: a bottleneck's first block): second segment = the BN input, K = 2 Cout, no M matrix.
+# Correct (tests/test_gpu_round4.py: 2.5e-3 against fp64) and measured SLOWER in the ResNet-50 step (19.80 -> 19.95 ms with
+# stages 1-2 folded, 19.87 with stage 1 only, three alternating pairs): the pass it removes is f channels wide, the data gradient
+# it lengthens is the step's largest launch.  Off by default.
+BN_FOLD_Y = os.environ.get('CNK_BN_FOLD_Y', '0') != '0'
+BN_FOLD_MIN_ELEMS_Y = float(os.environ.get('CNK_BN_FOLD_MIN_Y', '2e7'))
 # strided projection shortcuts too?  The library folds them (the stride-parity class of the tap; tests/test_gpu_round4.py), but
 # in the ResNet-50 step it measured neutral (19.23 vs 19.26 ms, four alternating pairs): the removed apply pass is a quarter of
 # the stride-1 one's size and the data gradient's K grows by a half.  Off by default.
@@ -472,11 +479,14 @@ class Conv2dFn(torch.autograd.Function):
         # conv -> BN with the BN backward folded into this conv's backward (FoldRecord): dense 1x1 bf16, no bias
         ctx.fold = None
         if fold is not None and BN_FOLD and plan.bnfold and bias is None and w.dtype == torch.float32 \
-                and x_needs_grad and w_dgrad is not None and desc.N * plan.Ho * plan.Wo * desc.Cout >= BN_FOLD_MIN_ELEMS \
-                and desc.Cout >= 2 * desc.Cin \
-                and (desc.stride_h == 1 or BN_FOLD_STRIDED):   # (K grows by Cin / Cout: a 4f -> f conv would read 4f more to save f)
-            fold.ok = True
-            ctx.fold = fold
+                and x_needs_grad and w_dgrad is not None and (desc.stride_h == 1 or BN_FOLD_STRIDED):
+            elems = desc.N * plan.Ho * plan.Wo * desc.Cout
+            if desc.Cout >= 2 * desc.Cin and elems >= BN_FOLD_MIN_ELEMS:
+                fold.ok, fold.mode = True, 0          # K grows by Cin / Cout
+                ctx.fold = fold
+            elif desc.Cout <= desc.Cin and BN_FOLD_Y and desc.stride_h == 1 and elems >= BN_FOLD_MIN_ELEMS_Y:
+                fold.ok, fold.mode = True, 1          # K doubles, but the narrow BN input is read instead of the wide conv input
+                ctx.fold = fold
         if want_bn_partial:
             if partial is None:
                 partial = torch.empty(0, device=x.device)         # placeholder: "not available"
@@ -502,10 +512,10 @@ class Conv2dFn(torch.autograd.Function):
         w_fold = bias_fold = None
         if fold is not None:
             FOLD_COUNTS['folded'] += 1
-            w_fold = torch.empty(ctx.plan.fold_bytes, dtype=torch.uint8, device=x.device)
+            w_fold = torch.empty(ctx.plan.fold_bytes[fold.mode], dtype=torch.uint8, device=x.device)
             bias_fold = torch.empty(desc.Cin, dtype=torch.float32, device=x.device)
             check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(desc), _p(w), _p(ctx.w_dgrad), _p(fold.mean), _p(fold.invstd),
-                                                _p(fold.coef), _p(w_fold), _p(bias_fold), _stream()))
+                                                _p(fold.coef), fold.mode, _p(w_fold), _p(bias_fold), _stream()))
         # dy is complete on the compute stream HERE: the weight gradient (issued below on the second
         # stream) waits for this point only, so it also overlaps this conv's own data gradient
         dy_ready = None
@@ -538,8 +548,9 @@ class Conv2dFn(torch.autograd.Function):
                                               rec.mask.data_ptr() if rec.mask is not None else None,
                                               partial.data_ptr(), int(rec.relu))
                 if fold is not None:
-                    check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(desc), _p(dy), _p(x), _p(w_fold), _p(bias_fold), _p(out),
-                                                      _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None, _stream()))
+                    check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fold.y if fold.mode else x), fold.mode,
+                                                      _p(w_fold), _p(bias_fold), _p(out), _p(addend), _p(amask),
+                                                      ctypes.byref(fuse) if fuse else None, _stream()))
                 else:
                     check(lib.cnk_conv2d_dgrad(ctypes.byref(desc), _p(dy), _p(ctx.w_dgrad), _p(out),
                                                _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None,

@@ -228,17 +228,22 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
  *   4. cnk_conv2d_dgrad_bnfold(g, x = the conv input, ...) -> dx, with the same optional gradient addend (+ packed mask) and
  *      fused BN backward of the layer that produced x as cnk_conv2d_dgrad;  cnk_conv2d_wgrad_bnfold(g, y = the conv output, x, ...) -> dw, which forms dy_conv
  *      while staging its tiles, bit for bit the tensor cnk_bn_bwd would have written (workspace as cnk_conv2d_wgrad).
+ * mode (prepare / image_bytes / dgrad_bnfold): 0 = the second K segment is the conv INPUT (K = Cout + Cin, image
+ * [A W ; -W^T diag(E) W]: for convs that widen, Cout > Cin); 1 = it is the conv OUTPUT y, the BN input (K = 2 Cout, image
+ * [A W ; -diag(E) W]: for convs that narrow, e.g. a bottleneck's first block 4f -> f) -- pass that tensor as `x`.
  * cnk_conv2d_bnfold_supported: bf16, 1x1, no padding, any stride (a strided conv's data gradient folds in the stride-parity
  * class that holds its tap), dense, both channel counts multiples of 64. */
 int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d);
-size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d);
+size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d, int mode);
 int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int accumulate,
                     float* coef, int64_t M, int32_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean,
-                              const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream);
-int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
-                            void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream);
+                              const float* save_invstd, const float* coef, int mode, void* w_fold, float* bias_fold,
+                              void* stream);
+int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, int mode, const void* w_fold,
+                            const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask,
+                            const cnk_bn_bwd_fuse* bn, void* stream);
 int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean,
                             const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace,
                             size_t workspace_bytes, void* stream);

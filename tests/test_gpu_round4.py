@@ -173,9 +173,9 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
     assert torch.equal(dw_acc, dw_one + 1.0)
 
     # ---- data gradient
-    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device=dev)
     bias_fold = torch.empty(Cin, device=dev)
-    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), P(w_fold),
+    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), 0, P(w_fold),
                                              P(bias_fold), _stream()))
     # the image against its definition (fp64): [A W ; -W^T diag(E) W], bias
     C = Cout
@@ -194,7 +194,7 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
     with _lib.switches(CNK_GEMM1X1=g1):
         c0 = cnt(counter)
         da_f = torch.empty_like(fc.a, memory_format=CL)
-        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da_f), None, None, None, _stream()))
+        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), 0, P(w_fold), P(bias_fold), P(da_f), None, None, None, _stream()))
         assert cnt(counter) == c0 + (1 if fc.stride == 1 else fc.stride ** 2), 'the folded data gradient did not run on the expected kernel'
         da_u = torch.empty_like(fc.a, memory_format=CL)
         _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da_u), None, None, None, None, 0, _stream()))
@@ -220,9 +220,9 @@ def test_bnfold_dgrad_with_fused_bn_backward_in_front(case):
     d, dev = fc.desc, 'cuda'
     coef, _, _ = fc.coef(lib, _lib)
     dxc, _, _ = fc.unfolded_dxconv(lib, _lib)
-    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device=dev)
     bias_fold = torch.empty(Cin, device=dev)
-    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), P(w_fold),
+    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), 0, P(w_fold),
                                              P(bias_fold), _stream()))
     # the BN layer in front: a = relu(bn(u)); mask re-derived from u (no residual)
     gen = torch.Generator().manual_seed(5)
@@ -241,7 +241,7 @@ def test_bnfold_dgrad_with_fused_bn_backward_in_front(case):
                                   part.data_ptr(), 1)
             da = torch.empty_like(fc.a, memory_format=CL)
             if folded:
-                _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da), None, None,
+                _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), 0, P(w_fold), P(bias_fold), P(da), None, None,
                                                        ctypes.byref(fuse), _stream()))
             else:
                 _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da), None, None, ctypes.byref(fuse), None, 0,
@@ -428,3 +428,51 @@ def test_fold_of_a_projection_shortcut_bn_with_gradient_handover():
     num = sum(float(((g1[k] - g0[k]) ** 2).sum()) for k in g0)
     den = sum(float((g0[k] ** 2).sum()) for k in g0)
     assert math.sqrt(num / den) < 3e-2
+
+
+# narrowing convs (a bottleneck's first block, 4f -> f): the second K segment is the BN INPUT y (mode 1), K = 2 Cout
+FOLD_Y_CASES = {
+    'y_gather_n8_256_64_14': (8, 256, 64, 14, 14, '1', CNT_GATHER),          # Nout = 256, K = 64 + 64
+    'y_gather_n16_128_128_9x13': (16, 128, 128, 9, 13, '1', CNT_GATHER),     # Cout == Cin, odd image
+    'y_gather128_n96_512_128_28': (96, 512, 128, 28, 28, '0', CNT_GATHER),   # 588 x 4 tiles of 128 x 128, K = 128 + 128
+    'y_ring_n64_1024_512_14': (64, 1024, 512, 14, 14, '2', CNT_G1_2),        # ring GEMM, K = 512 + 512, Nout = 1024
+}
+
+
+@pytest.mark.parametrize('case', sorted(FOLD_Y_CASES))
+def test_bnfold_mode1_second_segment_is_the_bn_input(case):
+    _lib, lib, cnt = _lib_and_counter()
+    N, Cin, Cout, H, W, g1, counter = FOLD_Y_CASES[case]
+    fc = FoldCase(N, Cin, Cout, H, W, seed=9 + len(case))
+    d, dev = fc.desc, 'cuda'
+    coef, _, _ = fc.coef(lib, _lib)
+    dxc, _, _ = fc.unfolded_dxconv(lib, _lib)
+    _, da64 = fc.fp64_da(coef)
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), 1), dtype=torch.uint8, device=dev)
+    assert w_fold.numel() == Cin * 2 * Cout * 2
+    bias_fold = torch.empty(Cin, device=dev)
+    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), 1, P(w_fold),
+                                             P(bias_fold), _stream()))
+    C = Cout
+    c64 = coef.double().cpu()
+    A, B1, B2 = c64[:C], c64[C:2 * C], c64[2 * C:]
+    m64, i64 = fc.mean.double().cpu(), fc.invstd.double().cpu()
+    w64 = fc.w.double().cpu().reshape(C, Cin)
+    E = A * i64 * B2
+    img = w_fold.view(torch.bfloat16).reshape(Cin, 2 * C).double().cpu()
+    assert rel_l2(img[:, :C].numpy(), (w64 * A[:, None]).t().numpy()) < 3e-3
+    assert rel_l2(img[:, C:].numpy(), (-(w64 * E[:, None])).t().numpy()) < 3e-3
+    assert rel_l2(bias_fold.double().cpu().numpy(), (w64 * (E * m64 - A * B1)[:, None]).sum(0).numpy()) < 1e-5
+    with _lib.switches(CNK_GEMM1X1=g1):
+        c0 = cnt(counter)
+        da_f = torch.empty_like(fc.a, memory_format=CL)
+        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.y), 1, P(w_fold), P(bias_fold), P(da_f), None, None, None,
+                                               _stream()))
+        assert cnt(counter) == c0 + 1
+        da_u = torch.empty_like(fc.a, memory_format=CL)
+        _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da_u), None, None, None, None, 0, _stream()))
+    torch.cuda.synchronize()
+    e_f = rel_l2(da_f.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), da64.numpy())
+    e_u = rel_l2(da_u.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), da64.numpy())
+    print('%s: folded %.2e unfolded %.2e (vs fp64)' % (case, e_f, e_u))
+    assert e_f < 4e-3 and e_u < 4e-3
