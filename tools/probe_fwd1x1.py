@@ -1,3 +1,6 @@
+"""Each 1x1 / stride-1 forward conv of the ResNet-50 step (batch 256, cold operands) on the implicit-GEMM kernel and on the ring
+GEMM (CNK_GEMM1X1 = 0 / rule / 2 / 4), with and without the BN statistics partials in the epilogue: what the statistics cost
+per shape.      python tools/probe_fwd1x1.py"""
 import ctypes, sys, os, statistics
 sys.path.insert(0, '/root/repo')
 import torch
