@@ -2,7 +2,7 @@
 GEMM (CNK_GEMM1X1 = 0 / rule / 2 / 4), with and without the BN statistics partials in the epilogue: what the statistics cost
 per shape.      python tools/probe_fwd1x1.py"""
 import ctypes, sys, os, statistics
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from convnets_amd import _lib, ops
 CL = torch.channels_last
