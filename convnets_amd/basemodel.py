@@ -184,9 +184,13 @@ class MultiClassBaseModel(nn.Module):
             t = torch.tensor([timings[c] for c in candidates], dtype=torch.float64, device=self.setting.device.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=getattr(red, 'group', None))
             timings = {c: float(v) for c, v in zip(candidates, t.tolist())}
-        best = min(timings, key=timings.get)
-        if 1.0 in timings and timings[best] > 0.995 * timings[1.0]:
-            best = 1.0
+        # The SMALLEST share within 1 % of the fastest candidate.  The probe times eager steps; where those are host-bound (ResNet-152:
+        # ~1,900 launches per step) every candidate measures the same and the choice used to fall to 1.0 by its tie-break -- the
+        # worst one for the captured step (25.6-26.1 ms at 0.5, 26.3-26.4 at 1.0, A/B in one call).  Where the share matters to
+        # the eager step it shows by far more than 1 % (VGG-16: -10 % at 0.5), and the captured ResNet-50 step is as fast at 0.5
+        # as at 0.75.
+        fastest = min(timings.values())
+        best = min(c for c in timings if timings[c] <= 1.01 * fastest)
         ops.WGRAD_SHARE[0] = best
         return timings
 

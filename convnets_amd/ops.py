@@ -110,7 +110,8 @@ WGRAD_STREAM = os.environ.get('CNK_WGRAD_STREAM', '1') != '0'
 # than cnk_conv2d_workspace_bytes bounds the number of pixel-range splits, include/cnk.h).  The gradients only have to be done
 # when the backward pass ends, and every CU holding one of their 112-KiB-LDS workgroups admits one implicit-GEMM workgroup of
 # the compute stream instead of four: ResNet-50 / 152 step 1.7-2.3 % faster at 0.5, VGG-16 10 % slower (its weight gradients
-# are the critical path) -- a property of the MODEL, so it is measured: calibrate_wgrad_share() below.
+# are the critical path) -- a property of the MODEL, so it is measured: MultiClassBaseModel.calibrate_wgrad_share() (the
+# smallest candidate within 1 % of the fastest: eager probe steps of a host-bound model cannot tell the candidates apart).
 WGRAD_SHARE = [float(os.environ.get('CNK_WGRAD_SHARE', '1.0'))]
 _side_streams = {}
 
