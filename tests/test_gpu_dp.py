@@ -164,3 +164,58 @@ def test_graphed_dp_step_with_rccl_allreduce_equals_eager(tmp_path):
     r = torch.load(out % 0)
     assert r['graph']['losses'] == r['eager']['losses']
     assert torch.equal(r['graph']['flat_p'], r['eager']['flat_p'])
+
+
+def _fold_worker(rank, world, port, out):
+    """Two ranks, bottleneck ResNet in bf16 with the folded BN backward forced on (round 4: the folded weight gradients are
+    written on the side stream straight into the gradient arena and must reach their buckets like every other gradient)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from convnets_amd import dp, ops
+    from oracle import torch_ref as tr
+    ops.BN_FOLD_MIN_ELEMS = 0
+    m = _make('resnet', 26, (3, 32, 32), True, mixed=True)
+    red = dp.attach(m, bucket_bytes=1 << 20)
+    assert len(red.buckets) >= 2
+    x, y = tr.synthetic_batch(16, (3, 32, 32), 10, seed=5)
+    xs, ys = x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8]
+    ops.FOLD_COUNTS['folded'] = 0
+    loss, _ = m.train_batch((xs, ys))
+    torch.cuda.synchronize()
+    res = dict(loss=float(loss), g1=m.optimizer.flat_g.cpu().clone(), p1=m.optimizer.flat_p.cpu().clone(), folded=ops.FOLD_COUNTS['folded'])
+    red.remove()
+    dist.barrier()
+    torch.save(res, out % rank)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_folded_bn_backward(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'f%d.pt')
+    mp.start_processes(_fold_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method='spawn')
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert r0['folded'] >= 8 and r1['folded'] >= 8
+    assert torch.equal(r0['g1'], r1['g1']) and torch.equal(r0['p1'], r1['p1'])          # replicas stay identical
+    from convnets_amd import ops
+    from oracle import torch_ref as tr
+    prev = ops.BN_FOLD_MIN_ELEMS
+    ops.BN_FOLD_MIN_ELEMS = 0
+    try:
+        x, y = tr.synthetic_batch(16, (3, 32, 32), 10, seed=5)
+        shard_g, shard_loss = [], []
+        for r in range(2):
+            m = _make('resnet', 26, (3, 32, 32), True, mixed=True)
+            loss, _ = m.train_batch((x[r * 8:(r + 1) * 8], y[r * 8:(r + 1) * 8]))
+            torch.cuda.synchronize()
+            shard_g.append(m.optimizer.flat_g.cpu().clone())
+            shard_loss.append(float(loss))
+    finally:
+        ops.BN_FOLD_MIN_ELEMS = prev
+    g_sum = shard_g[0] + shard_g[1]
+    err = float((r0['g1'] - g_sum).norm() / g_sum.norm())
+    print('resnet26 bf16, fold on: reduced gradient vs the sum of the single-process shard gradients: rel %.3e' % err)
+    assert err < 1e-6
+    assert shard_loss[0] == r0['loss'] and shard_loss[1] == r1['loss']
