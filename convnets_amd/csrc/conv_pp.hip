@@ -988,11 +988,12 @@ static int pp_pick(int N, int H, int W, int C, int Nout, int dgrad, int fused) {
     if (forced >= 0 && forced < 4 && fits(forced) && !(dgrad && forced >= 2)) return forced;      // (bench / test runs only)
     // 64 -> 64 channels: the weight-stationary kernel (filter bank in registers), forward and data gradient alike; its patch
     // must fit the WSCfg::PPW pieces a wave issues per job
-    // The fused data gradients stay on the halo kernel unless CNK_PP_FULL=1: solo the full-epilogue variant wins (113-120 vs
-    // 126 us), inside the step, beside the weight-gradient stream, it does not (rocprofv3 traces of graph replays: 153 vs 147 us
-    // on the same launches, step time equal within noise -- one workgroup per CU has nobody to cover its epilogue when the CU's
-    // other tenant slows it down).
-    if (cnk_sw().pp_ws && !(dgrad && fused && cnk_sw().pp_full != 1) && forced < 0 && C == 64 && Nout == 64 &&
+    // The fused data gradients too (CNK_PP_FULL=0 sends them back to the halo kernel): solo the full-epilogue variant wins
+    // (113-120 vs 126 us).  In round 3's step it did not (153 vs 147 us on the same launches of a traced replay, step time
+    // equal); in round 4's step -- the folded BN backward moved traffic from the compute stream to the weight-gradient stream,
+    // the halo kernel's three launches now take 167-170 us there -- it does by a little: 19.32 -> 19.23 ms over four
+    // alternating pairs.
+    if (cnk_sw().pp_ws && !(dgrad && fused && cnk_sw().pp_full == 0) && forced < 0 && C == 64 && Nout == 64 &&
         pp_npg(H, W, PP_GEOM[4]) <= 8 * WSCfg::PPW && fits(4))
         return 4;
     // Rule in work per CU (one persistent workgroup per CU, 256 CUs): the biggest tile -- 256 x 256, then 512 x 128, both
