@@ -186,6 +186,13 @@ def _fold_worker(rank, world, port, out):
     loss, _ = m.train_batch((xs, ys))
     torch.cuda.synchronize()
     res = dict(loss=float(loss), g1=m.optimizer.flat_g.cpu().clone(), p1=m.optimizer.flat_p.cpu().clone(), folded=ops.FOLD_COUNTS['folded'])
+    # the start-up probe of the split-K share under data parallelism: every rank must come out with the SAME share (it is the
+    # fp32 summation order of the weight gradients) and with its training state untouched
+    timings = m.calibrate_wgrad_share((xs, ys))
+    torch.cuda.synchronize()
+    res['share'] = ops.WGRAD_SHARE[0]
+    res['timings'] = timings
+    res['p_after_probe'] = m.optimizer.flat_p.cpu().clone()
     red.remove()
     dist.barrier()
     torch.save(res, out % rank)
@@ -199,6 +206,8 @@ def test_two_ranks_with_the_folded_bn_backward(tmp_path):
     r0, r1 = torch.load(out % 0), torch.load(out % 1)
     assert r0['folded'] >= 8 and r1['folded'] >= 8
     assert torch.equal(r0['g1'], r1['g1']) and torch.equal(r0['p1'], r1['p1'])          # replicas stay identical
+    assert r0['share'] == r1['share'] and r0['timings'] == r1['timings'], (r0['share'], r1['share'])
+    assert torch.equal(r0['p_after_probe'], r0['p1']) and torch.equal(r1['p_after_probe'], r1['p1'])
     from convnets_amd import ops
     from oracle import torch_ref as tr
     prev = ops.BN_FOLD_MIN_ELEMS
