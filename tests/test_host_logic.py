@@ -60,6 +60,22 @@ def test_host_side_planning_queries_run_without_gpu():
     assert rc != 0 and b'kernel larger' in lib.cnk_last_error()
     with pytest.raises(_lib.CnkError):
         _lib.check(rc)
+    # round 4: which convs can take the folded BN backward, the image sizes of its two forms, the smallest weight-gradient workspace
+    c3 = D(256, 56, 56, 64, 256, 1, 1, 1, 1, 0, 0, _lib.CNK_BF16)                  # a bottleneck's last conv
+    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(c3)) == 1
+    assert lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(c3), 0) == 64 * (256 + 64) * 2
+    assert lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(c3), 1) == 64 * (2 * 256) * 2
+    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(D(256, 56, 56, 256, 512, 1, 1, 2, 2, 0, 0, _lib.CNK_BF16))) == 1    # strided shortcut
+    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(D(256, 56, 56, 64, 256, 1, 1, 1, 1, 0, 0, _lib.CNK_F32))) == 0      # bf16 only
+    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)) == 0                                                        # 3x3
+    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(D(8, 14, 14, 48, 96, 1, 1, 1, 1, 0, 0, _lib.CNK_BF16))) == 0        # off the 64 grid
+    rc = lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                       ctypes.c_void_p(16), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), None)
+    assert rc != 0 and b'cnk_conv2d_bnfold_supported' in lib.cnk_last_error()
+    slab = 256 * 64 * 4
+    assert lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(c3), 0) == slab
+    assert lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(c3), 1) > slab                                            # + the bias sum's scratch
+    assert lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(c3), 0) <= lib.cnk_conv2d_workspace_bytes(ctypes.byref(c3), _lib.PASS_WGRAD)
 
 
 def test_ops_refuse_cpu_tensors_no_fallback():
