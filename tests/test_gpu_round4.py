@@ -476,3 +476,42 @@ def test_bnfold_mode1_second_segment_is_the_bn_input(case):
     e_u = rel_l2(da_u.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), da64.numpy())
     print('%s: folded %.2e unfolded %.2e (vs fp64)' % (case, e_f, e_u))
     assert e_f < 4e-3 and e_u < 4e-3
+
+
+def test_bnfold_random_geometries():
+    """Twelve random (N, H, W, Cin, Cout, stride, form) draws, small and ragged (M below one tile, odd images, one K step): the
+    folded data gradient against the fp64 restatement, the folded weight gradient bit-identical to bn_bwd + wgrad."""
+    _lib, lib, cnt = _lib_and_counter()
+    rng = np.random.RandomState(4)
+    dev = 'cuda'
+    worst = 0.0
+    for it in range(12):
+        N = int(rng.randint(1, 9))
+        H, W = int(rng.randint(3, 20)), int(rng.randint(3, 20))
+        Cin, Cout = 64 * int(rng.randint(1, 5)), 64 * int(rng.randint(1, 9))
+        stride = int(rng.choice([1, 1, 2]))
+        mode = int(rng.randint(0, 2)) if stride == 1 else 0
+        fc = FoldCase(N, Cin, Cout, H, W, seed=100 + it, stride=stride)
+        d = fc.desc
+        coef, _, _ = fc.coef(lib, _lib)
+        dxc, _, _ = fc.unfolded_dxconv(lib, _lib)
+        _, da64 = fc.fp64_da(coef)
+        w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), mode), dtype=torch.uint8, device=dev)
+        bias_fold = torch.empty(Cin, device=dev)
+        _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), mode, P(w_fold),
+                                                 P(bias_fold), _stream()))
+        da = torch.empty_like(fc.a, memory_format=CL)
+        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.y if mode else fc.a), mode, P(w_fold), P(bias_fold), P(da), None,
+                                               None, None, _stream()))
+        nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), _lib.PASS_WGRAD)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        dw_u, dw_f = torch.zeros(Cout, Cin, 1, 1, device=dev), torch.zeros(Cout, Cin, 1, 1, device=dev)
+        _lib.check(lib.cnk_conv2d_wgrad(ctypes.byref(d), P(dxc), P(fc.a), P(dw_u), None, 0, P(ws), nws, _stream()))
+        _lib.check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.y), P(fc.a), P(fc.mean), P(fc.invstd), P(coef), P(dw_f), 0, P(ws),
+                                               nws, _stream()))
+        torch.cuda.synchronize()
+        e = rel_l2(da.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), da64.numpy())
+        worst = max(worst, e)
+        assert e < 5e-3, (it, N, H, W, Cin, Cout, stride, mode, e)
+        assert torch.equal(dw_u, dw_f), (it, N, H, W, Cin, Cout, stride, mode)
+    print('worst folded data gradient vs fp64 over 12 draws: %.2e' % worst)
