@@ -17,6 +17,7 @@ size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
+int igemm_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* coef, const void* residual, const float* rcoef, int relu, void* y, unsigned char* mask, hipStream_t s);
 int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x2, int mode, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 bool bnfold_supported(const cnk_conv_desc* d);
 size_t bnfold_image_bytes(const cnk_conv_desc* d, int mode);
@@ -353,10 +354,30 @@ int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d) {
     return cnk_sw().rowpatch_stats && rowpatch_supported(d) ? rowpatch_fwd_stat_slices(d) : 0;
 }
 
+int cnk_conv2d_fwd_bn_apply_supported(const cnk_conv_desc* d) {
+    return check_desc(d, "cnk_conv2d_fwd_bn_apply_supported") == 0 && conv_groups(d) == 1 && conv_dil(d) == 1 && d->kh == 1 && d->kw == 1 &&
+           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && igemm_supported(d, CNK_PASS_FWD) && igemm_on_grid(d, CNK_PASS_FWD);
+}
+
+int cnk_conv2d_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* scale_shift, const void* residual, const float* residual_scale_shift, int relu, void* y, uint8_t* relu_mask, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_fwd_bn_apply")) return rc;
+    CNK_CHECK_ARG(cnk_conv2d_fwd_bn_apply_supported(d), "cnk_conv2d_fwd_bn_apply: this conv shape has no fused BN apply (cnk_conv2d_fwd_bn_apply_supported == 0)");
+    CNK_CHECK_ARG(x && w_fwd && scale_shift && y, "cnk_conv2d_fwd_bn_apply: null pointer");
+    CNK_CHECK_ARG(!residual_scale_shift || residual, "cnk_conv2d_fwd_bn_apply: residual_scale_shift without a residual operand");
+    CNK_CHECK_ARG(!relu_mask || relu, "cnk_conv2d_fwd_bn_apply: relu_mask without relu");
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    if (residual) by += (double)d->N * d->H * d->W * d->Cout * esize(d->dtype);
+    ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
+    return igemm_fwd_bn_apply(d, x, w_fwd, scale_shift, residual, residual_scale_shift, relu, y, relu_mask, S(stream));
+}
+
 int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (int rc = check_desc(d, "cnk_conv2d_fwd")) return rc;
-    CNK_CHECK_ARG(x && w_fwd && y, "cnk_conv2d_fwd: null pointer");
+    CNK_CHECK_ARG(x && w_fwd, "cnk_conv2d_fwd: null pointer");
+    // y == NULL: statistics only (the partials are the call's output) -- on the implicit-GEMM kernel
+    CNK_CHECK_ARG(y || (bn_partial && !bias && cnk_conv2d_fwd_bn_apply_supported(d)), "cnk_conv2d_fwd: y == NULL (statistics only) needs bn_partial, no bias and a shape with cnk_conv2d_fwd_bn_apply_supported");
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 0), S(stream), fl, by);

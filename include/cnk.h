@@ -157,6 +157,19 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
  * scratch) for the split-K kernels, cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD) for every other kernel. */
 size_t cnk_conv2d_wgrad_min_workspace_bytes(const cnk_conv_desc* d, int has_bias);
 
+/* conv2d_block without ever storing the conv output (round 4; the last block of a bottleneck: conv 1x1 -> BN -> += identity ->
+ * ReLU, resnet.py:172-176,191-194).  Training-mode BN needs the batch statistics of the conv output before it can be applied, so
+ * the conv runs TWICE: cnk_conv2d_fwd with y == NULL leaves only the statistics partials; cnk_bn_fwd_train with y == NULL turns
+ * them into scale | shift (start of its workspace; copy them out); cnk_conv2d_fwd_bn_apply recomputes the conv and writes
+ *     y = act( round_dtype(conv) * scale + shift + residual ),  residual optionally round_dtype(r * rscale + rshift)
+ * plus the packed ReLU mask -- bit for bit what cnk_conv2d_fwd + cnk_bn_fwd_train store (the second pass reproduces the
+ * accumulators), with 10 instead of 17 element transfers per pixel and channel of the narrow width.  A backward that needs
+ * the conv output recomputes it (cnk_conv2d_fwd).  _supported: 1x1 / stride 1 / no padding, dense, on the 64-channel grid. */
+int cnk_conv2d_fwd_bn_apply_supported(const cnk_conv_desc* d);
+int cnk_conv2d_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* scale_shift,
+                            const void* residual, const float* residual_scale_shift, int relu, void* y,
+                            uint8_t* relu_mask, void* stream);
+
 /* nn.BatchNorm2d in training mode (basemodel.py:1008,1061), optionally fused with the ReLU that
  * follows it in conv2d_block (:1012) and with the residual add + F.relu of the ResNet blocks
  * (resnet.py:151-154,191-194):   y = act( (x-mean)*invstd*gamma + beta [+ residual] ).

@@ -515,3 +515,69 @@ def test_bnfold_random_geometries():
         assert e < 5e-3, (it, N, H, W, Cin, Cout, stride, mode, e)
         assert torch.equal(dw_u, dw_f), (it, N, H, W, Cin, Cout, stride, mode)
     print('worst folded data gradient vs fp64 over 12 draws: %.2e' % worst)
+
+
+@pytest.mark.parametrize('case', ['n8_64_256_14', 'n96_128_512_28', 'n5_64_128_9x13_raff', 'n4_64_64_14_f32', 'n8_64_256_14_nores'])
+def test_conv_bn_apply_without_storing_the_conv_output(case):
+    """conv(1x1) -> BN -> += residual -> ReLU as two conv passes (statistics only; conv + BN apply in the epilogue,
+    cnk_conv2d_fwd_bn_apply) against the stored-output sequence cnk_conv2d_fwd + cnk_bn_fwd_train: output, packed mask, saved
+    statistics and running statistics bit for bit (reference: /root/reference/src/resnet.py:172-176,191-194)."""
+    from convnets_amd import ops
+    _lib, lib, cnt = _lib_and_counter()
+    cfg = {'n8_64_256_14': (8, 64, 256, 14, 14, torch.bfloat16, True, False),
+           'n96_128_512_28': (96, 128, 512, 28, 28, torch.bfloat16, True, False),      # 128-wide tiles
+           'n5_64_128_9x13_raff': (5, 64, 128, 9, 13, torch.bfloat16, True, True),     # residual with its own deferred BN
+           'n4_64_64_14_f32': (4, 64, 64, 14, 14, torch.float32, True, False),
+           'n8_64_256_14_nores': (8, 64, 256, 14, 14, torch.bfloat16, False, False)}[case]
+    N, Cin, Cout, H, W, dt, has_res, raff = cfg
+    dev = 'cuda'
+    gen = torch.Generator().manual_seed(len(case))
+    code = _lib.CNK_BF16 if dt == torch.bfloat16 else _lib.CNK_F32
+    M = N * H * W
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=gen)).to(dt).to(dev).contiguous(memory_format=CL)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=gen) / math.sqrt(Cin)).to(dev)
+    res = torch.randn(N, Cout, H, W, generator=gen).to(dt).to(dev).contiguous(memory_format=CL) if has_res else None
+    rcoef = torch.cat([0.5 + torch.rand(Cout, generator=gen), 0.1 * torch.randn(Cout, generator=gen)]).to(dev) if raff else None
+    gamma, beta = (0.5 + torch.rand(Cout, generator=gen)).to(dev), (0.1 * torch.randn(Cout, generator=gen)).to(dev)
+    d = ops.make_desc(x.shape, w.shape, (1, 1), (0, 0), code)
+    assert lib.cnk_conv2d_fwd_bn_apply_supported(ctypes.byref(d)) == 1
+    w_fwd = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_FWD), dtype=torch.uint8, device=dev)
+    _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(w), P(w_fwd), None, _stream()))
+    nws = lib.cnk_bn_workspace_bytes(M, Cout)
+    nmask = lib.cnk_bn_mask_bytes(M, Cout, code)
+
+    def bn_state():
+        return dict(rm=torch.zeros(Cout, device=dev), rv=torch.ones(Cout, device=dev), sm=torch.empty(Cout, device=dev),
+                    si=torch.empty(Cout, device=dev), ws=torch.empty(nws, dtype=torch.uint8, device=dev),
+                    mask=torch.zeros(nmask, dtype=torch.uint8, device=dev))
+    # ---- stored-output sequence
+    a = bn_state()
+    with _lib.switches(CNK_GEMM1X1='0'):
+        nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d))
+        part_a = torch.zeros(nsl, Cout, 3, device=dev)
+        y3 = torch.empty(N, Cout, H, W, dtype=dt, device=dev).contiguous(memory_format=CL)
+        _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(x), P(w_fwd), None, P(y3), P(part_a), None, 0, _stream()))
+    ya = torch.empty_like(y3, memory_format=CL)
+    if raff:
+        _lib.check(lib.cnk_bn_fwd_train_res_affine(P(y3), P(gamma), P(beta), P(res), P(rcoef), P(ya), P(a['mask']), P(a['rm']), P(a['rv']),
+                                                   P(a['sm']), P(a['si']), P(part_a), nsl, M, Cout, 1e-5, 0.1, 1, code, P(a['ws']), nws, _stream()))
+    else:
+        _lib.check(lib.cnk_bn_fwd_train(P(y3), P(gamma), P(beta), P(res), P(ya), P(a['mask']) if has_res else None, P(a['rm']), P(a['rv']),
+                                        P(a['sm']), P(a['si']), P(part_a), nsl, M, Cout, 1e-5, 0.1, 1, code, P(a['ws']), nws, _stream()))
+    # ---- two conv passes, the conv output never stored
+    b = bn_state()
+    nsl_b = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d))
+    part_b = torch.zeros(nsl_b, Cout, 3, device=dev)
+    _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(x), P(w_fwd), None, None, P(part_b), None, 0, _stream()))
+    _lib.check(lib.cnk_bn_fwd_train(P(x), P(gamma), P(beta), None, None, None, P(b['rm']), P(b['rv']), P(b['sm']), P(b['si']), P(part_b), nsl_b,
+                                    M, Cout, 1e-5, 0.1, 1, code, P(b['ws']), nws, _stream()))
+    coef = b['ws'][:8 * Cout].view(torch.float32).clone()
+    yb = torch.empty_like(y3, memory_format=CL)
+    _lib.check(lib.cnk_conv2d_fwd_bn_apply(ctypes.byref(d), P(x), P(w_fwd), P(coef), P(res), P(rcoef), 1, P(yb), P(b['mask']) if has_res else None,
+                                           _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(a['sm'], b['sm']) and torch.equal(a['si'], b['si']), 'saved statistics differ'
+    assert torch.equal(a['rm'], b['rm']) and torch.equal(a['rv'], b['rv'])
+    assert torch.equal(ya, yb), 'conv + BN apply in one launch differs from the stored-output sequence'
+    if has_res:
+        assert torch.equal(a['mask'], b['mask'])
