@@ -53,6 +53,7 @@ SIGNATURES = {
     'cnk_conv2d_fwd_bn_partial_slices': (_i64, [_dp]),
     'cnk_conv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'cnk_conv2d_fwd_bn_apply_supported': (ctypes.c_int, [_dp]),
+    'cnk_conv2d_fwd_stats_only_slices': (_i64, [_dp]),
     'cnk_conv2d_fwd_bn_apply': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     'cnk_conv2d_fwd_act_supported': (ctypes.c_int, [_dp]),
     'cnk_conv2d_fwd_act': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),

@@ -18,6 +18,7 @@ int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const fl
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 int igemm_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* coef, const void* residual, const float* rcoef, int relu, void* y, unsigned char* mask, hipStream_t s);
+int64_t igemm_fwd_stats_only_slices(const cnk_conv_desc* d);
 int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x2, int mode, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 bool bnfold_supported(const cnk_conv_desc* d);
 size_t bnfold_image_bytes(const cnk_conv_desc* d, int mode);
@@ -359,6 +360,10 @@ int cnk_conv2d_fwd_bn_apply_supported(const cnk_conv_desc* d) {
            d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && igemm_supported(d, CNK_PASS_FWD) && igemm_on_grid(d, CNK_PASS_FWD);
 }
 
+int64_t cnk_conv2d_fwd_stats_only_slices(const cnk_conv_desc* d) {
+    return cnk_conv2d_fwd_bn_apply_supported(d) ? igemm_fwd_stats_only_slices(d) : 0;
+}
+
 int cnk_conv2d_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* scale_shift, const void* residual, const float* residual_scale_shift, int relu, void* y, uint8_t* relu_mask, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_fwd_bn_apply")) return rc;
     CNK_CHECK_ARG(cnk_conv2d_fwd_bn_apply_supported(d), "cnk_conv2d_fwd_bn_apply: this conv shape has no fused BN apply (cnk_conv2d_fwd_bn_apply_supported == 0)");
@@ -563,7 +568,8 @@ size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(
 size_t cnk_bn_mask_bytes(int64_t M, int32_t C, int dtype) { return bn_mask_bytes(M, C, dtype); }
 
 int cnk_bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* residual, void* y, uint8_t* relu_mask, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* partial, int64_t partial_slices, int64_t M, int32_t C, float eps, float momentum, int relu, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
-    CNK_CHECK_ARG(x && gamma && beta && save_mean && save_invstd, "cnk_bn_fwd_train: null pointer");
+    // x may be NULL when it is never read: statistics from the caller's partials, no apply pass
+    CNK_CHECK_ARG((x || (!y && partial)) && gamma && beta && save_mean && save_invstd, "cnk_bn_fwd_train: null pointer");
     CNK_CHECK_ARG(y || (!residual && !relu_mask), "cnk_bn_fwd_train: y == NULL (statistics only) takes no residual / mask");
     CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_train: empty tensor");
     CNK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cnk_bn_fwd_train: running stats must both be given or both NULL");

@@ -1058,6 +1058,13 @@ int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
     return ceil_div(d->N * Ho * Wo, BM);
 }
 
+// y == NULL (statistics only) always runs the gather kernel: one slice per BM-row tile
+int64_t igemm_fwd_stats_only_slices(const cnk_conv_desc* d) {
+    int Ho, Wo;
+    cnk_conv2d_out_hw(d, &Ho, &Wo);
+    return ceil_div(d->N * Ho * Wo, BM);
+}
+
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
               float* stats, const void* residual, int relu, hipStream_t s) {
     int Ho, Wo;

@@ -59,7 +59,7 @@ class Conv2d(nn.Conv2d):
             new.__dict__[k] = ops.PackedWeights() if k == '_packed' else copy.deepcopy(v, memo)
         return new
 
-    def forward(self, x, want_bn_partial=False, link=None, fold=None):
+    def forward(self, x, want_bn_partial=False, link=None, fold=None, lazy=None):
         if self._depthwise:                      # conv2d_depthwise (basemodel.py:981-997)
             y = ops.DepthwiseConv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
             return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
@@ -76,7 +76,7 @@ class Conv2d(nn.Conv2d):
                                       self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), 1)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
                                   self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups,
-                                  self._dil, fold)
+                                  self._dil, fold, lazy)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -87,7 +87,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     # model then bumps every layer's num_batches_tracked with ONE kernel per step, not one per layer
     _deferred_counter = None
 
-    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None, fold=None, defer=False):
+    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None, fold=None, defer=False, lazy=None):
         """pool: the MaxPool2d module that consumes this layer's output (ConvBlock passes it for the stems, training
         mode only): BN, ReLU and the pooling then run as one autograd node and the POOLED tensor is returned."""
         if not (self.affine and self.track_running_stats):
@@ -108,7 +108,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                 holder = [] if defer else None
                 y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
                                              self.running_var, float(self.eps), float(self.momentum),
-                                             bool(relu), partial, link, rec, fold, holder, res_affine)
+                                             bool(relu), partial, link, rec, fold, holder, res_affine, lazy)
                 if rec is not None and rec.x is not None:
                     y._cnk_bn = rec
                 if defer:
@@ -296,7 +296,12 @@ class ConvBlock(nn.Sequential):
                 # (fold: the BN backward's apply pass runs inside this conv's backward where the shape allows, ops.FoldRecord)
                 fold = ops.FoldRecord() if (ops.BN_FOLD and torch.is_grad_enabled()
                                             and isinstance(conv, Conv2d) and conv.kernel_size == (1, 1)) else None
-                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold)
+                # (lazy: a widening 1x1 conv in front of a BN with a residual operand -- a bottleneck's last block -- may leave
+                # its output out of the forward, ops.LazyConvOut)
+                lazy = ops.LazyConvOut() if (ops.LAZY_CONV_OUT and residual is not None and not defer_apply
+                                             and torch.is_grad_enabled() and isinstance(conv, Conv2d)
+                                             and conv.kernel_size == (1, 1) and conv.stride == (1, 1)) else None
+                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold, lazy=lazy)
                 pool = self._linked_pool()
                 if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
@@ -304,7 +309,8 @@ class ConvBlock(nn.Sequential):
                 if defer_apply and not act and residual is None and torch.is_grad_enabled() and DEFER_SHORTCUT_BN:
                     return bn(y, partial=partial, defer=True, fold=fold if (fold is not None and fold.ok) else None)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
-                          link=res_link, fold=fold if (fold is not None and fold.ok) else None)
+                          link=res_link, fold=fold if (fold is not None and fold.ok) else None,
+                          lazy=lazy if (lazy is not None and lazy.ok) else None)
             if not torch.is_grad_enabled():
                 # inference: BN folded into the conv, ReLU / residual add in its epilogue (one kernel)
                 fold = self.__dict__.setdefault('_fold', ops.FoldedConv())

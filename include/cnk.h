@@ -166,6 +166,9 @@ size_t cnk_conv2d_wgrad_min_workspace_bytes(const cnk_conv_desc* d, int has_bias
  * accumulators), with 10 instead of 17 element transfers per pixel and channel of the narrow width.  A backward that needs
  * the conv output recomputes it (cnk_conv2d_fwd).  _supported: 1x1 / stride 1 / no padding, dense, on the 64-channel grid. */
 int cnk_conv2d_fwd_bn_apply_supported(const cnk_conv_desc* d);
+/* slices of the partials a y == NULL call of cnk_conv2d_fwd writes (it may differ from cnk_conv2d_fwd_bn_partial_slices, which
+ * describes the storing call's kernel); 0 when the shape is not _supported */
+int64_t cnk_conv2d_fwd_stats_only_slices(const cnk_conv_desc* d);
 int cnk_conv2d_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* scale_shift,
                             const void* residual, const float* residual_scale_shift, int relu, void* y,
                             uint8_t* relu_mask, void* stream);
@@ -176,7 +179,8 @@ int cnk_conv2d_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w
  * x,y,residual: [M][C] NHWC-flattened, M = N*H*W.  Batch mean / biased variance are computed in
  * fp32; running_mean/var (may be NULL) get momentum updates with the UNBIASED variance;
  * save_mean/save_invstd (fp32[C]) are outputs kept for the backward.  partial/partial_slices:
- * optional statistics partials from cnk_conv2d_fwd (NULL/0: computed here).
+ * optional statistics partials from cnk_conv2d_fwd (NULL/0: computed here).  y == NULL: statistics only (scale[C] | shift[C]
+ * are left at the start of the workspace); x may then be NULL too when the partials are given (it is never read).
  * relu_mask (may be NULL; cnk_bn_mask_bytes(M, C, dtype) bytes): packed ReLU mask of the output,
  * one bit per element; handing it to cnk_bn_bwd replaces two full reads of y by 1/16 of the bytes.
  * workspace: cnk_bn_workspace_bytes(M, C). */

@@ -581,3 +581,119 @@ def test_conv_bn_apply_without_storing_the_conv_output(case):
     assert torch.equal(ya, yb), 'conv + BN apply in one launch differs from the stored-output sequence'
     if has_res:
         assert torch.equal(a['mask'], b['mask'])
+
+
+def _lazy_model(kind=26, size=64, bs=32):
+    import convnets_amd as ca
+    from oracle import torch_ref as tr
+    torch.manual_seed(33)
+    s = ca.Settings(kind=kind, input_size=(3, size, size), num_classes=10, batch_size=bs, dropout_rate=0, mixed_precision=True,
+                    device='cuda:0')
+    m = ca.ResNet(s)
+    tr.damp_residual_branches(m, 0.1)
+    m = m.cuda()
+    m.init_optimizer()
+    m.train()
+    return m
+
+
+@pytest.mark.parametrize('fold', [True, False])
+def test_conv_output_left_out_of_the_forward_is_bit_identical(fold):
+    """ops.LazyConvOut: a bottleneck's last conv output is never stored in the forward (two conv passes) and recomputed on the
+    weight-gradient stream for the backward.  Same kernels, same arithmetic: loss, every gradient and the parameters after
+    two steps carry the same bits as the stored path -- with the folded BN backward behind it and without."""
+    from convnets_amd import ops
+    from oracle import torch_ref as tr
+    saved = (ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS, ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS)
+    ops.LAZY_MIN_ELEMS, ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS = 0, fold, 0
+    try:
+        res = {}
+        for lazy in (True, False):
+            ops.LAZY_CONV_OUT = lazy
+            ops.LAZY_COUNTS.update(left_out=0, recomputed=0)
+            model = _lazy_model()
+            x, y = tr.synthetic_batch(32, (3, 64, 64), 10, seed=33)
+            losses = []
+            for _ in range(2):
+                loss, _c = model.train_batch((x, y))
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            params = {n: p.detach().clone() for n, p in model.named_parameters()}
+            stats = {n: b.detach().clone() for n, b in model.named_buffers()}
+            res[lazy] = (losses, grads, params, stats, dict(ops.LAZY_COUNTS))
+    finally:
+        ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS, ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS = saved
+    (l1, g1, p1, s1, c1), (l0, g0, p0, s0, c0) = res[True], res[False]
+    assert c0 == {'left_out': 0, 'recomputed': 0}
+    assert c1['left_out'] == 16 and c1['recomputed'] == 16, c1            # 8 bottlenecks x 2 steps
+    assert l1 == l0
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), 'gradient of %s differs' % k
+    for k in p0:
+        assert torch.equal(p1[k], p0[k]), 'parameter %s differs' % k
+    for k in s0:
+        assert torch.equal(s1[k], s0[k]), 'buffer %s differs' % k
+
+
+def test_conv_output_left_out_in_a_captured_step():
+    """The same inside a hipGraph: the recomputation is captured on the side stream; three replays equal three eager steps of
+    a twin model that stores the conv outputs."""
+    from convnets_amd import ops
+    from convnets_amd.graph import GraphedTrainStep
+    from oracle import torch_ref as tr
+    saved = (ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS)
+    ops.LAZY_MIN_ELEMS = 0
+    try:
+        x, y = tr.synthetic_batch(32, (3, 64, 64), 10, seed=33)
+        x, y = x.cuda(), y.cuda()
+        ops.LAZY_CONV_OUT = False
+        eager = _lazy_model()
+        for _ in range(3):
+            le, _c = eager.train_batch((x, y))
+        ops.LAZY_CONV_OUT = True
+        ops.LAZY_COUNTS.update(left_out=0, recomputed=0)
+        graphed = _lazy_model()
+        step = GraphedTrainStep(graphed, (x, y))
+        assert ops.LAZY_COUNTS['left_out'] >= 8 and ops.LAZY_COUNTS['recomputed'] == ops.LAZY_COUNTS['left_out']
+        for _ in range(3):
+            lg, _c = step.replay()
+        torch.cuda.synchronize()
+    finally:
+        ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS = saved
+    assert float(lg) == float(le)
+    for (n, a), (_, b) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert torch.equal(a, b), n
+
+
+def test_conv_output_left_out_without_a_backward_and_twice():
+    """A training-mode forward that is never followed by a backward leaves nothing behind (weak references); two forwards
+    before the first backward (gradient accumulation) recompute both graphs' tensors; a second backward over a retained
+    graph is refused loudly instead of reading freed memory."""
+    import gc
+    from convnets_amd import ops
+    saved = (ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS)
+    ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS = True, 0
+    try:
+        model = _lazy_model()
+        x = torch.randn(32, 3, 64, 64, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+        out = model(x)
+        assert len(ops._lazy_pending) == 8
+        del out
+        gc.collect()
+        assert all(w() is None for w in ops._lazy_pending)
+        ops.LAZY_COUNTS.update(left_out=0, recomputed=0)
+        o1 = model(x).float().sum()
+        o2 = model(x * 0.5).float().sum()
+        o1.backward(retain_graph=True)
+        assert ops.LAZY_COUNTS['recomputed'] == 16 and not ops._lazy_pending
+        o2.backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        with pytest.raises(RuntimeError, match='LazyConvOut'):
+            o1.backward()
+    finally:
+        ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS = saved
+        ops.join_side_streams()
+        torch.cuda.synchronize()
