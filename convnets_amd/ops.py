@@ -317,7 +317,11 @@ class LazyConvOut:
 # Leave the conv output of a bottleneck's last block out of the forward?  Per block the forward moves 10 instead of 17 element
 # transfers per pixel and narrow channel and the conv runs three times instead of once (tools/bench_y3free.py, forward at batch
 # 256: 386 -> 316 us at 56x56, 219 -> 195 at 28x28, 115 -> 139 at 14x14): the rule below is M * Cout elements of that tensor.
-LAZY_CONV_OUT = os.environ.get('CNK_LAZY_CONV_OUT', '1') != '0'
+# In the ResNet-50 step the backward gives the forward's gain back and more (19.65 -> 19.88 ms, three alternating pairs): the
+# weight-gradient stream already carries ~9.7 ms of kernels inside a ~12 ms backward, so the seven replayed convs (0.6 ms) land
+# on its critical path, and each replay re-writes the tensor the forward saved (net traffic saved per step: ~1 GB of ~65).
+# What it does buy is memory: 2.1 GB of activations less at batch 256.  Off by default; bit-identical when on.
+LAZY_CONV_OUT = os.environ.get('CNK_LAZY_CONV_OUT', '0') != '0'
 LAZY_MIN_ELEMS = float(os.environ.get('CNK_LAZY_CONV_OUT_MIN', '8e7'))
 LAZY_COUNTS = {'left_out': 0, 'recomputed': 0}
 _lazy_pending = []                        # weak references, in forward order
