@@ -8,6 +8,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['Queue_Id']), r['Kernel_Name']))
 rows.sort()
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[3]]
+# (the optimizer may be split into up to three launches around the last weight gradient: a step ends at the LAST of a group)
+adam = [i for k, i in enumerate(adam) if k + 1 == len(adam) or rows[adam[k + 1]][0] - rows[i][1] > 2000000]
 if len(adam) < 3:
     sys.exit('fewer than three optimizer launches in the trace')
 
@@ -64,3 +66,36 @@ for g, p, n in gl:
 print('idle time by (kernel before -> kernel after), top 25:')
 for k, (c, g) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     print('  %-72s n=%3d  %.1f us total, %.2f us each' % (k, c, g / 1e3, g / 1e3 / c))
+# where the step's time goes: forward (up to the loss kernel), backward (up to the last kernel in front of the optimizer), tail;
+# and whether the optimizer waited for the weight-gradient queue
+qs = sorted(byq, key=lambda q: -len(byq[q]))
+main_q = qs[0]
+mainr = byq[main_q]
+ce = [i for i, r in enumerate(mainr) if 'softmax_ce' in r[3]]
+if ce:
+    fwd_end = mainr[ce[-1]][1]
+    first_adam = min(i for i, r in enumerate(mainr) if 'adam_kernel' in r[3] and r[0] > fwd_end)
+    adam_start = mainr[first_adam][0]
+    before_adam = mainr[first_adam - 1][1]
+    print('main queue %d: forward %.3f ms, backward %.3f ms (to its last kernel), optimizer starts %.1f us after that kernel'
+          % (main_q, (fwd_end - t0) / 1e6, (before_adam - fwd_end) / 1e6, (adam_start - before_adam) / 1e3))
+    for q in qs[1:]:
+        rs = byq[q]
+        print('queue %d: first kernel %.3f ms into the step, last kernel ends %.1f us %s the main queue\'s last backward kernel'
+              % (q, (rs[0][0] - t0) / 1e6, abs(rs[-1][1] - before_adam) / 1e3, 'AFTER' if rs[-1][1] > before_adam else 'before'))
+        # how far the queue lags: for its kernels, time between becoming launchable (previous kernel on the same queue ended) -- not
+        # known from the trace -- so report its idle share inside its own span instead
+        busy = sum(e - s for s, e, _, _ in rs)
+        print('          busy %.3f ms of a %.3f ms span (%.0f %%)' % (busy / 1e6, (rs[-1][1] - rs[0][0]) / 1e6,
+                                                                   100.0 * busy / max(rs[-1][1] - rs[0][0], 1)))
+    print('tail of the step (ms into it, queue, duration us):')
+    for r in sorted(step, key=lambda r: r[0])[-8:]:
+        print('   %.3f  q%d  %6.1f  %s' % ((r[0] - t0) / 1e6, r[2], (r[1] - r[0]) / 1e3, short(r[3])))
+    print('head of the step:')
+    for r in sorted(step, key=lambda r: r[0])[:8]:
+        print('   %.3f  q%d  %6.1f  %s' % ((r[0] - t0) / 1e6, r[2], (r[1] - r[0]) / 1e3, short(r[3])))
+    big = sorted(((mainr[i + 1][0] - mainr[i][1], short(mainr[i][3]), short(mainr[i + 1][3]), (mainr[i][1] - t0) / 1e6)
+                  for i in range(len(mainr) - 1)), reverse=True)[:12]
+    print('longest gaps on the main queue:')
+    for g, p, n, at in big:
+        print('  %7.1f us at %.2f ms  %s -> %s' % (g / 1e3, at, p, n))
