@@ -138,6 +138,13 @@ extern "C" void cnk_debug_reload_switches() { g_switches = read_switches(); }
 
 static std::atomic<int64_t> g_counters[CNK_CNT_MAX];
 void cnk_count(int id) { g_counters[id].fetch_add(1, std::memory_order_relaxed); }
+// test / tool hook (not in include/cnk.h): one thread writes the device's 100 MHz wall clock to *slot -- a time stamp that also
+// works inside a captured graph, where events cannot be read (tools/probe_graph_schedule.py)
+__global__ void debug_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+extern "C" int cnk_debug_stamp(void* slot, void* stream) {
+    hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 extern "C" int64_t cnk_debug_counter(int id) { return id >= 0 && id < CNK_CNT_MAX ? g_counters[id].load(std::memory_order_relaxed) : -1; }
 
 // ---- error text -----------------------------------------------------------------------------------

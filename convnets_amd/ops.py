@@ -116,6 +116,17 @@ WGRAD_STREAM = os.environ.get('CNK_WGRAD_STREAM', '1') != '0'
 # smallest candidate within 1 % of the fastest: eager probe steps of a host-bound model cannot tell the candidates apart).
 WGRAD_SHARE = [float(os.environ.get('CNK_WGRAD_SHARE', '1.0'))]
 _side_streams = {}
+# tools/probe_graph_schedule.py: [uint64 device buffer, list of labels] -- device-clock stamps around the weight-gradient launches,
+# readable after a graph replay (None: off, the product setting)
+STAMP = [None]
+
+
+def _stamp(label):
+    buf, log = STAMP[0]
+    if len(log) < buf.numel():
+        _lib.load().cnk_debug_stamp(ctypes.c_void_p(buf.data_ptr() + 8 * len(log)), _stream())
+        log.append(label)
+
 
 
 def wgrad_stream(device):
@@ -701,8 +712,14 @@ class Conv2dFn(torch.autograd.Function):
                 # the main stream without knowing about the side stream
                 side = wgrad_stream(x.device)
                 side.wait_event(dy_ready)                                    # dy, x (and zero_grad) are ready
+                if STAMP[0] is not None:
+                    _stamp('main')
                 with torch.cuda.stream(side):
+                    if STAMP[0] is not None:
+                        _stamp('side_begin')
                     run_wgrad(WGRAD_SHARE[0])
+                    if STAMP[0] is not None:
+                        _stamp('side_end')
                 dy.record_stream(side)
                 x.record_stream(side)
                 if fold is not None:

@@ -1,6 +1,8 @@
 """Timeline of one training step from a rocprofv3 --kernel-trace CSV (tools/run_profiles.sh: gpurun_out/<tag>_stats): per
 hardware queue the busy time and the idle gaps between consecutive kernels, the union over queues, and the kernels that sit in
-front of the longest gaps.  A step = from one adam_kernel end to the next.      python tools/trace_gaps.py <kernel_trace.csv>"""
+front of the longest gaps.  A step = from one adam_kernel end to the next.
+    python tools/trace_gaps.py <kernel_trace.csv> [steps to skip at the end]
+(bench.py with the graph runs up to five EAGER steps with per-launch events after its timed replays: skip 6 to look at a replay)"""
 import collections, csv, re, sys
 
 rows = []
@@ -20,8 +22,10 @@ def short(n):
     return (m.group(1) if m else re.sub(r'[<(].*', '', n))[:34]
 
 
-# the LAST complete step of the trace (graph replays when bench.py ran with the graph)
-a, b = adam[-2], adam[-1]
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+walls = [(rows[adam[i + 1]][1] - rows[adam[i]][1]) / 1e6 for i in range(len(adam) - 1)]
+print('step walls (ms), oldest first:', ' '.join('%.2f' % w for w in walls[-16:]))
+a, b = adam[-2 - skip], adam[-1 - skip]
 step = rows[a + 1:b + 1]
 t0, t1 = rows[a][1], rows[b][1]
 print('step wall %.3f ms, %d kernels' % ((t1 - t0) / 1e6, len(step)))
@@ -99,3 +103,10 @@ if ce:
     print('longest gaps on the main queue:')
     for g, p, n, at in big:
         print('  %7.1f us at %.2f ms  %s -> %s' % (g / 1e3, at, p, n))
+    for q in qs[1:]:
+        rs = byq[q]
+        print('queue %d, its first 12 kernels (start ms, duration us, gap to the previous one us | main-queue kernel running at that start):' % q)
+        for i, r in enumerate(rs[:12]):
+            cur = [m for m in mainr if m[0] <= r[0] < m[1]]
+            print('   %.3f  %6.1f  %7.1f  %-28s | %s' % ((r[0] - t0) / 1e6, (r[1] - r[0]) / 1e3, (r[0] - rs[i - 1][1]) / 1e3 if i else 0.0,
+                                                    short(r[3]), short(cur[0][3]) if cur else '-'))
