@@ -288,7 +288,7 @@ def main():
             rocprof_cross = {'avg_launch_us': traffic['avg_launch_us'], 'achieved': round(ach, 2), 'frac': round(ach / peak, 4),
                              'traffic_over_algorithmic': round(traffic['total'] / (by_l / n_l), 3) if by_l else None,
                              'note': 'algorithmic bytes (or flops) per launch of THIS run / the family\'s average launch duration in the '
-                                     'committed rocprofv3 --kernel-trace --stats summary; same launch population as `traffic`'}
+                                     'committed rocprofv3 --kernel-trace --stats summary; same launch population as `traffic_detail`'}
         conv_classes = {c: {'tflops': round(table[c][2] / table[c][1] / 1e9, 1), 'frac_of_mfma_peak': round(table[c][2] / table[c][1] / 1e9 / peak_tf, 4),
                             'calls_per_step': table[c][0], 'step_ms': round(table[c][1], 3)} for c in CONV_CLASSES if table[c][1] > 0}
         out = {
@@ -303,7 +303,9 @@ def main():
                        'final_loss': round(loss_val, 4)},
             'roofline': {'bound': bound, 'kernel': dom_kernel, 'kernel_runs': KERNEL_NOTE[dom_kernel], 'achieved': round(achieved, 2), 'peak': peak,
                          'unit': unit, 'frac': round(achieved / peak, 4),
-                         'traffic': traffic, 'rocprof': rocprof_cross,
+                         # `traffic`: HBM bytes per launch (FETCH_SIZE corrected + WRITE_SIZE, separate --pmc passes), a number
+                         # as the bench contract words it; the passes' breakdown beside it
+                         'traffic': traffic.get('total') if traffic else None, 'traffic_detail': traffic, 'rocprof': rocprof_cross,
                          'launches': n_l, 'avg_launch_ms': round(ms_l / n_l, 4) if n_l else None,
                          'avg_launch_gflop': round(fl_l / n_l / 1e9, 3) if n_l else None,
                          'avg_launch_alg_mbytes': round(by_l / n_l / 1e6, 2) if n_l else None,
