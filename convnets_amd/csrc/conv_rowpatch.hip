@@ -448,8 +448,14 @@ __global__ __launch_bounds__(64 * RP_FWD_WAVES) void rowpatch_fwd_kernel(const R
 // ---------------------------------------------------------------------------------------------------
 // wgrad: dW[co][k'] += sum_px dy[px][co] * patch(px, k').  32x32 output blocks (2 co-blocks x
 // Kp/32 k'-blocks) are dealt round-robin to the 4 waves; each wave sweeps every 32-pixel chunk.
-template <typename T, int NBLK>
+// PAIR (bf16): the wave pair (2w, 2w + 1) owns the k' blocks nj = w, w + 2, ... for BOTH co halves, and the two waves of a pair
+// take alternate 32-pixel chunks of the row; their accumulators meet in LDS once, at the end.  A wave then reads each dy^T
+// fragment once per step for all its blocks and each patch fragment (eight 2-byte LDS reads, the expensive one) once for two
+// MFMAs: 4.7 LDS reads per MFMA instead of 8.7 -- this kernel is bound by the LDS pipe, not by the matrix pipe.
+template <typename T, int NBLK, bool PAIR = false>
 __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParams p) {
+    static_assert(!PAIR || sizeof(T) == 2, "PAIR: bf16 only");
+    constexpr int NACC = PAIR ? 2 * NBLK : NBLK;
     constexpr int CH = RpCfg<T>::CH, ES = (int)sizeof(T);
     constexpr int DS = 64 * ES + (ES == 2 ? 64 : 0);              // dy image row stride (tr-read friendly)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -460,9 +466,9 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
     const T* dy = (const T*)p.dy;
     const int WoPad = (p.Wo + 31) / 32 * 32;
     const int nblk = 2 * (p.Kp / 32);                            // 32x32 blocks of dW
-    f32x16 acc[NBLK];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b)
+    for (int b = 0; b < NACC; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     for (int i = tid; i < p.PWE; i += 256) patch[(size_t)p.KH * p.PWE + i] = from_f32<T>(0.f);
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
     int koff[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
-        const int kp = ((wave + 4 * b) >> 1) * 32 + (lane & 31);
+        const int kp = (PAIR ? (wave >> 1) + 2 * b : (wave + 4 * b) >> 1) * 32 + (lane & 31);
         int kh = kp / p.Rp;
         const int jj = kp - kh * p.Rp;
         kh = kh < p.KH ? kh : p.KH;
@@ -556,24 +562,61 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
         __syncthreads();
         }
         for (int c0 = 0; c0 < WoPad; c0 += 32) {
-            if constexpr (ES == 2) {
+            if constexpr (PAIR) {
+                if (((c0 >> 5) & 1) != (wave & 1)) continue;      // the other wave of the pair takes this chunk
+                const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int prow = c0 + ss * 16 + 8 * h;
+                    bf16x8 fa[2];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const unsigned char* a0 = Dl + (prow + q) * DS + (mi * 32 + 16 * (g & 1) + 4 * pp) * 2;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * DS));
+                        const s16x8 w8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        fa[mi] = __builtin_bit_cast(bf16x8, w8);
+                    }
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        if ((wave >> 1) + 2 * b < (nblk >> 1)) {
+                            const unsigned short* prw = (const unsigned short*)patch + koff[b];
+                            const int stp = p.s * p.Cin;
+                            unsigned short e[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                int px = prow + u;
+                                px = px < p.Wo ? px : p.Wo - 1;   // dy is zero there; keep the read in range
+                                e[u] = prw[px * stp];
+                            }
+                            const u32x4 fbv = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                               (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+                            const bf16x8 fb = __builtin_bit_cast(bf16x8, fbv);
+                            acc[2 * b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb, acc[2 * b], 0, 0, 0);
+                            acc[2 * b + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb, acc[2 * b + 1], 0, 0, 0);
+                        }
+                    }
+                }
+            } else if constexpr (ES == 2) {
                 const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
                 const int l31 = lane & 31;
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {                  // two 16-pixel reduction steps
                     const int prow = c0 + ss * 16 + 8 * h;       // first of this lane half's 8 pixels
+                    // A: dy^T fragment (rows co) through the transposing read.  Its co half mi = blk & 1 = wave & 1 is the same for
+                    // all of a wave's blocks (blk = wave + 4 b): read ONCE per step, not once per block
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const unsigned char* a0 = Dl + (prow + q) * DS + ((wave & 1) * 32 + 16 * (g & 1) + 4 * pp) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * DS));
+                    const s16x8 w8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, w8);
 #pragma unroll
                     for (int b = 0; b < NBLK; ++b) {
                         const int blk = wave + 4 * b;
                         if (blk < nblk) {
-                            const int mi = blk & 1, nj = blk >> 1;
-                            // A: dy^T fragment (rows co) through the transposing read
-                            const unsigned char* a0 = Dl + (prow + q) * DS + (mi * 32 + 16 * (g & 1) + 4 * pp) * 2;
-                            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-                            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * DS));
-                            typedef __attribute__((ext_vector_type(8))) short s16x8;
-                            s16x8 w8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            bf16x8 fa = __builtin_bit_cast(bf16x8, w8);
+                            const int nj = blk >> 1;
                             // B: column k' = nj*32 + l31 of the virtual im2col, pixels prow..prow+7
                             const unsigned short* prw = (const unsigned short*)patch + koff[b];
                             const int stp = p.s * p.Cin;
@@ -616,6 +659,42 @@ __global__ __launch_bounds__(256) void rowpatch_wgrad_kernel(const RowPatchParam
     }
     const int l31 = lane & 31, lh = lane >> 5;
     float* slab = p.slab + (size_t)blockIdx.x * 64 * p.Kp;
+    if constexpr (PAIR) {
+        // the odd wave of each pair hands its partial sums over through LDS (one pair at a time: NACC * 16 floats per lane,
+        // 24 KiB for the ResNet stem -- the operand images are no longer needed)
+        float* hand = (float*)smem;
+        for (int pr = 0; pr < 2; ++pr) {
+            __syncthreads();
+            if (wave == 2 * pr + 1) {
+#pragma unroll
+                for (int b = 0; b < NACC; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hand[(b * 16 + r) * 64 + lane] = acc[b][r];
+            }
+            __syncthreads();
+            if (wave == 2 * pr) {
+#pragma unroll
+                for (int b = 0; b < NACC; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][r] += hand[(b * 16 + r) * 64 + lane];
+            }
+        }
+        if (wave & 1) return;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int nj = (wave >> 1) + 2 * b;
+            if (nj < (nblk >> 1)) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        slab[(size_t)co * p.Kp + nj * 32 + l31] = acc[2 * b + mi][r];
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int blk = wave + 4 * b;
@@ -831,6 +910,15 @@ int rowpatch_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float*
     size_t lds = (size_t)(p.KH + 1) * p.PWE * es + (size_t)((p.Wo + 31) / 32 * 32) * (64 * es + (es == 2 ? 64 : 0));
     int nblk = 2 * (p.Kp / 32), per_wave = ceil_div(nblk, 4);
 #define RP_LAUNCH(TT, NB) hipLaunchKernelGGL((rowpatch_wgrad_kernel<TT, NB>), dim3(grid), dim3(256), lds, s, p)
+    // bf16, up to eight k' blocks (the 7x7 stems: six): the pair layout; its hand-over needs NACC * 16 * 64 floats of LDS
+    const int njw = ceil_div(p.Kp / 32, 2);
+    if (d->dtype == CNK_BF16 && njw >= 2 && njw <= 4 && d->Cout == 64 && !(RP_ABL & 2048)) {
+        const size_t hand = (size_t)2 * njw * 16 * 64 * sizeof(float);
+        if (hand > lds) lds = hand;
+        if (njw == 2) hipLaunchKernelGGL((rowpatch_wgrad_kernel<bf16, 2, true>), dim3(grid), dim3(256), lds, s, p);
+        else if (njw == 3) hipLaunchKernelGGL((rowpatch_wgrad_kernel<bf16, 3, true>), dim3(grid), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((rowpatch_wgrad_kernel<bf16, 4, true>), dim3(grid), dim3(256), lds, s, p);
+    } else
     if (d->dtype == CNK_BF16) {
         if (per_wave <= 1) RP_LAUNCH(bf16, 1); else if (per_wave <= 2) RP_LAUNCH(bf16, 2);
         else if (per_wave <= 3) RP_LAUNCH(bf16, 3); else if (per_wave <= 4) RP_LAUNCH(bf16, 4);
