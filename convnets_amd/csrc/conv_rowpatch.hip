@@ -885,8 +885,15 @@ int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const f
     return 0;
 }
 
-static int rp_wgrad_grid(const RowPatchParams& p, int* rows_per_wg) {
-    *rows_per_wg = rp_rows_per_wg(p, 1024);
+// bf16, 64 output channels, four to eight k' blocks (the 7x7 stems: six): the pair layout of rowpatch_wgrad_kernel
+static bool rp_wgrad_pair(const cnk_conv_desc* d, const RowPatchParams& p) {
+    const int njw = ceil_div(p.Kp / 32, 2);
+    return d->dtype == CNK_BF16 && njw >= 2 && njw <= 4 && d->Cout == 64 && !(RP_ABL & 2048);
+}
+static int rp_wgrad_grid(const cnk_conv_desc* d, const RowPatchParams& p, int* rows_per_wg) {
+    // one resident round: the pair layout holds two workgroups per CU (232 registers), the others three -- and half the
+    // slabs to sum behind it (512 instead of 1024 workgroups: 224 -> 201 us on the ResNet stem)
+    *rows_per_wg = rp_rows_per_wg(p, rp_wgrad_pair(d, p) ? 512 : 1024);
     return ceil_div(p.rows_total, *rows_per_wg);
 }
 
@@ -894,7 +901,7 @@ size_t rowpatch_wgrad_workspace(const cnk_conv_desc* d) {
     RowPatchParams p;
     make_rp(d, &p);
     int rpw;
-    int grid = rp_wgrad_grid(p, &rpw);
+    int grid = rp_wgrad_grid(d, p, &rpw);
     return (size_t)grid * 64 * p.Kp * sizeof(float);
 }
 
@@ -902,7 +909,7 @@ int rowpatch_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float*
                    void* ws, size_t ws_bytes, hipStream_t s) {
     RowPatchParams p;
     make_rp(d, &p);
-    int grid = rp_wgrad_grid(p, &p.rows_per_wg);
+    int grid = rp_wgrad_grid(d, p, &p.rows_per_wg);
     size_t need = (size_t)grid * 64 * p.Kp * sizeof(float);
     CNK_CHECK_ARG(ws && ws_bytes >= need, "conv2d_wgrad(rowpatch): workspace too small (%zu < %zu)", ws_bytes, need);
     p.x = x; p.dy = dy; p.slab = (float*)ws;
@@ -910,9 +917,9 @@ int rowpatch_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float*
     size_t lds = (size_t)(p.KH + 1) * p.PWE * es + (size_t)((p.Wo + 31) / 32 * 32) * (64 * es + (es == 2 ? 64 : 0));
     int nblk = 2 * (p.Kp / 32), per_wave = ceil_div(nblk, 4);
 #define RP_LAUNCH(TT, NB) hipLaunchKernelGGL((rowpatch_wgrad_kernel<TT, NB>), dim3(grid), dim3(256), lds, s, p)
-    // bf16, up to eight k' blocks (the 7x7 stems: six): the pair layout; its hand-over needs NACC * 16 * 64 floats of LDS
+    // the pair layout's hand-over needs NACC * 16 * 64 floats of LDS
     const int njw = ceil_div(p.Kp / 32, 2);
-    if (d->dtype == CNK_BF16 && njw >= 2 && njw <= 4 && d->Cout == 64 && !(RP_ABL & 2048)) {
+    if (rp_wgrad_pair(d, p)) {
         const size_t hand = (size_t)2 * njw * 16 * 64 * sizeof(float);
         if (hand > lds) lds = hand;
         if (njw == 2) hipLaunchKernelGGL((rowpatch_wgrad_kernel<bf16, 2, true>), dim3(grid), dim3(256), lds, s, p);
