@@ -831,9 +831,12 @@ int rowpatch_pack(const cnk_conv_desc* d, const float* w, void* out, hipStream_t
     return 0;
 }
 
-static int rp_fwd_grid(const RowPatchParams& p, int* rows_per_wg) {
-    // ~2048 workgroups, each a whole number of output rows; the weight image (64 x Kp) is staged once per workgroup
-    *rows_per_wg = rp_rows_per_wg(p, 2048);
+static int rp_fwd_grid(const cnk_conv_desc* d, const RowPatchParams& p, int* rows_per_wg) {
+    // ~2048 workgroups, each a whole number of output rows; the weight image (64 x Kp) is staged once per workgroup.
+    // The 7x7 stems' wide bf16 variant (12 unrolled k-steps, 234 registers: two workgroups per CU) gets ONE resident round of
+    // 512 instead -- 243 -> 221 us on the ResNet stem at batch 256, and a quarter of the statistics partials to merge
+    const bool stem_wide = cnk_sw().rowpatch_wide && d->Cout == 64 && d->dtype == CNK_BF16 && p.Kp / 16 == 12 && p.Rp / 8 >= 2;
+    *rows_per_wg = rp_rows_per_wg(p, stem_wide ? 512 : 2048);
     return ceil_div(p.rows_total, *rows_per_wg);
 }
 
@@ -841,7 +844,7 @@ int64_t rowpatch_fwd_stat_slices(const cnk_conv_desc* d) {
     RowPatchParams p;
     if (!make_rp(d, &p) || d->Cout != 64) return 0;      // the statistics ride on the 64-channel copy-out
     int rpw;
-    return rp_fwd_grid(p, &rpw);
+    return rp_fwd_grid(d, p, &rpw);
 }
 
 int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const float* bias, void* y, float* stats,
@@ -850,7 +853,7 @@ int rowpatch_fwd(const cnk_conv_desc* d, const void* x, const void* wpk, const f
     make_rp(d, &p);
     CNK_CHECK_ARG(!stats || d->Cout == 64, "cnk_conv2d_fwd: this conv shape cannot emit BN partials (cnk_conv2d_fwd_bn_partial_slices == 0)");
     p.x = x; p.wpk = wpk; p.y = y; p.bias = bias; p.stats = stats;
-    int grid = rp_fwd_grid(p, &p.rows_per_wg);
+    int grid = rp_fwd_grid(d, p, &p.rows_per_wg);
     const int es = d->dtype == CNK_BF16 ? 2 : 4, ch = 16 / es;
     p.ksteps = ceil_div(p.KH * p.Rp, 2 * ch);
     size_t lds = rp_fwd_lds(p, es);

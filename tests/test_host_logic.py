@@ -52,7 +52,7 @@ def test_host_side_planning_queries_run_without_gpu():
     assert lib.cnk_conv2d_packed_bytes(ctypes.byref(stem), _lib.PASS_FWD) == 64 * 192 * 2   # 7 runs of 24 -> K' 192
     assert lib.cnk_bn_workspace_bytes(256 * 56 * 56, 64) > 0
     assert lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d)) == 256 * 56 * 56 // 64    # one per 64-row wave tile (ws3x3)
-    assert lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(stem)) == 256 * 112 // 14    # row-patch stem: one per workgroup (14 output rows)
+    assert lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(stem)) == 256 * 112 // 56    # row-patch stem: one per workgroup (56 output rows: one resident round of 512)
     # argument errors come back as codes + text, never exit/abort
     bad = D(1, 4, 4, 8, 8, 9, 9, 1, 1, 0, 0, _lib.CNK_F32)
     rc = lib.cnk_conv2d_fwd(ctypes.byref(bad), ctypes.c_void_p(16), ctypes.c_void_p(16), None,
