@@ -207,3 +207,30 @@ def test_integration_snippet_matches_header():
     assert len(call.split(',')) == n_params
     ctor = re.search(r'd = ConvDesc\((.*?)\)', block).group(1)
     assert len(ctor.split(',')) == n_fields
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The newest committed bench line (profiles/r04e_bench.json, written by `python bench.py` on an MI355X) carries every field
+    of the bench contract with the agreed types: one JSON object, metric / config of BASELINE.json's headline, a numeric
+    roofline.traffic, the cpu_baseline object."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_bench.json')))
+    assert files
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k, t in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int),
+                 ('ms_per_step', float), ('higher_is_better', bool), ('scaling', str), ('dtype', str), ('data', str),
+                 ('config', dict), ('roofline', dict), ('cpu_baseline', dict)):
+        assert isinstance(d[k], t), (k, d.get(k))
+    assert 'vs_baseline' in d and d['vs_baseline'] is None           # BASELINE.md holds no published number for this metric
+    assert d['scaling'] == 'weak' and d['higher_is_better'] is True and d['dtype'] == 'bf16' and d['n_gpus'] == 1
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert 'images/sec' in d['metric'] and 'ResNet-50' in d['metric'], (d['metric'], base.get('metric'))
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert r['traffic'] is None or isinstance(r['traffic'], (int, float))
+    c = d['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
+    assert abs(d['value'] - 256 * 1000.0 / d['ms_per_step']) / d['value'] < 1e-2     # value and ms_per_step describe the same run
