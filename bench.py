@@ -79,7 +79,7 @@ def pmc_traffic(kernel):
 def cpu_baseline(model_key, dtype_note):
     """The oracle ('port' of the reference's torch-CPU step) timed on the host cores."""
     from oracle import torch_ref as tr
-    family, kind, in_size, classes, _ = MODEL_CFG[model_key]
+    family, kind, in_size, classes, _bs_default = MODEL_CFG[model_key]
     nproc = os.cpu_count() or 1
     try:
         nproc = len(os.sched_getaffinity(0))             # the cores this process may be scheduled on
@@ -99,26 +99,50 @@ def cpu_baseline(model_key, dtype_note):
     threads = granted                                    # all host cores this process is granted
     torch.set_num_threads(threads)
     print('bench: CPU baseline on %d threads (nproc %d, cgroup cpu share %s) ...' % (threads, nproc, quota), file=sys.stderr, flush=True)
-    bs = 64                                              # bs 256 if it fits, else bs 64 (throughput is flat in batch on CPU)
-    torch.manual_seed(21)
-    m = tr.MODELS[family](tr.RefSettings(kind, in_size, classes, batch_size=bs, dropout_rate=0.5))
-    m.init_optimizer()
-    x, y = tr.synthetic_batch(bs, in_size, classes, seed=21)
-    tr.ref_training_step(m, x, y)                      # warm-up
+    # the metric's batch (bs 256) if it fits and stays inside the bounded sample, else bs 64 (throughput is flat in
+    # batch on CPU: 13-18 img/s either way on the 16 granted cores).  One warm-up step decides: it must neither run out of
+    # memory nor take longer than WARM_LIMIT seconds (two more timed steps of that length have to fit the bench's few minutes).
+    WARM_LIMIT = 30.0
+    fallback = None
+    for bs in ((_bs_default, 64) if _bs_default != 64 else (64,)):
+        try:
+            torch.manual_seed(21)
+            m = tr.MODELS[family](tr.RefSettings(kind, in_size, classes, batch_size=bs, dropout_rate=0.5))
+            m.init_optimizer()
+            x, y = tr.synthetic_batch(bs, in_size, classes, seed=21)
+            t0 = time.perf_counter()
+            tr.ref_training_step(m, x, y)                      # warm-up
+            warm = time.perf_counter() - t0
+        except (MemoryError, RuntimeError) as e:               # torch reports a failed host allocation as RuntimeError
+            if bs == 64:
+                raise
+            fallback = 'bs %d did not fit (%s)' % (bs, type(e).__name__)
+            m = x = y = None
+            import gc
+            gc.collect()
+            continue
+        print('bench: CPU warm-up step at bs %d: %.2f s' % (bs, warm), file=sys.stderr, flush=True)
+        if bs != 64 and warm > WARM_LIMIT:
+            fallback = 'bs %d warm-up step took %.0f s (> %.0f s): outside the bounded sample' % (bs, warm, WARM_LIMIT)
+            m = x = y = None
+            continue
+        break
     times = []
     t_end = time.perf_counter() + 20.0
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 5):
+    nmin, nmax = (2, 3) if bs != 64 else (3, 5)
+    while len(times) < nmin or (time.perf_counter() < t_end and len(times) < nmax):
         t0 = time.perf_counter()
         tr.ref_training_step(m, x, y)
         times.append(time.perf_counter() - t0)
         print('bench: CPU step %d: %.2f s' % (len(times), times[-1]), file=sys.stderr, flush=True)
     times.sort()
-    med = times[len(times) // 2]
+    med = times[(len(times) - 1) // 2]
     cfg = torch.__config__.show()
     build = '; '.join(l.strip(' -') for l in cfg.splitlines() if any(k in l for k in ('oneAPI', 'oneDNN', 'MKL-DNN', 'OpenMP', 'CPU capability')))
     return {'value': round(bs / med, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'nproc': nproc, 'cgroup_cpus': quota, 'threads': torch.get_num_threads(), 'torch': torch.__version__, 'torch_build': build[:400],
-            'sample': '%d fp32 training steps of %s at bs=%d on torch-CPU (oracle/torch_ref.py), median'
+            'batch': bs, 'batch_fallback': fallback,
+            'sample': '%d fp32 training steps of %s at bs=%d on torch-CPU (oracle/torch_ref.py) after one warm-up step, median'
                       % (len(times), model_key, bs)}
 
 
@@ -134,8 +158,9 @@ def main():
     ap.add_argument('--breakdown', action='store_true', help='print the per-class kernel time table to stderr')
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
                     help='time hipGraph replays of the step (convnets_amd.GraphedTrainStep: one launch per step) or the '
-                    'eager step.  auto = on for a single process, off under torch.distributed (the captured RCCL '
-                    'all-reduce is verified on one rank only).  Per-kernel HIP events cannot be read inside a replay, '
+                    'eager step.  auto = on for a single process; under torch.distributed on only with CNK_GRAPH_DP=1 (the '
+                    'replay of captured RCCL all-reduces is verified on one rank only; the capture is then a collective '
+                    'operation, GraphedTrainStep.build_collective).  Per-kernel HIP events cannot be read inside a replay, '
                     'so with the graph the roofline launch durations come from eager steps after the timed region')
     args = ap.parse_args()
 
@@ -207,16 +232,10 @@ def main():
                   (name, n, ms, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0), file=sys.stderr)
 
     graphed = None
-    if args.graph == 'on' or (args.graph == 'auto' and not distributed):
-        try:
-            graphed = ca.GraphedTrainStep(model, batch, wgrad_share='auto')
-        except Exception as e:                      # capture refused: time the eager step (every rank must agree)
-            print('bench: hipGraph capture failed (%s: %s); timing the eager step' % (type(e).__name__, e), file=sys.stderr)
-        if distributed:
-            ok = torch.tensor([1 if graphed is not None else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                graphed = None
+    if args.graph == 'on' or (args.graph == 'auto' and (not distributed or os.environ.get('CNK_GRAPH_DP') == '1')):
+        # (under torch.distributed every rank enters here together: warm-up, split-K probe and capture issue the bucket
+        # all-reduces, and the ranks agree on the outcome -- a refused capture anywhere means the eager step everywhere)
+        graphed = ca.GraphedTrainStep.build_collective(model, batch, wgrad_share='auto')
     share_ms = graphed.wgrad_share_ms if graphed is not None else None
     if graphed is None and args.dtype == 'bf16':
         # eager step (data parallel runs): the same measurement on eager steps, every rank alike
@@ -289,6 +308,22 @@ def main():
                              'traffic_over_algorithmic': round(traffic['total'] / (by_l / n_l), 3) if by_l else None,
                              'note': 'algorithmic bytes (or flops) per launch of THIS run / the family\'s average launch duration in the '
                                      'committed rocprofv3 --kernel-trace --stats summary; same launch population as `traffic_detail`'}
+        # whole step against both roofs: algorithmic conv + head flops of the step (the C-ABI class scopes of
+        # the serial breakdown step) over the measured step time, and the step's HBM-side bytes from the committed PMC passes
+        step_flops = sum(table[c][2] for c in table)
+        step_tf = step_flops / (ms_per_step * 1e-3) / 1e12
+        step_traffic = None
+        try:
+            step_traffic = (json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('step') or {}).get('bytes')
+        except Exception:
+            pass
+        step_level = {'step_tflops': round(step_tf, 1), 'step_tflops_frac': round(step_tf / peak_tf, 4),
+                      'step_algorithmic_tflop': round(step_flops / 1e12, 3),
+                      'step_hbm_gbytes': round(step_traffic / 1e9, 2) if step_traffic and args.model == 'resnet50' and bs == def_bs else None,
+                      'step_hbm_frac': round(step_traffic / (ms_per_step * 1e-3) / (PEAK_HBM_GBPS * 1e9), 4)
+                      if step_traffic and args.model == 'resnet50' and bs == def_bs else None,
+                      'note': 'flops: algorithmic, all conv / linear classes of one step; bytes: profiles/pmc_traffic.json `step` (sum over '
+                              'kernels of PMC bytes per launch x launches per step, headline config only) / this run\'s step time'}
         conv_classes = {c: {'tflops': round(table[c][2] / table[c][1] / 1e9, 1), 'frac_of_mfma_peak': round(table[c][2] / table[c][1] / 1e9 / peak_tf, 4),
                             'calls_per_step': table[c][0], 'step_ms': round(table[c][1], 3)} for c in CONV_CLASSES if table[c][1] > 0}
         out = {
@@ -324,6 +359,7 @@ def main():
             # fraction north_star names is conv3x3_fwd / conv3x3_dgrad here)
             'roofline_by_kernel': by_kernel,
             'conv_classes_serial': conv_classes,
+            'step_level': step_level,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.model, args.dtype)

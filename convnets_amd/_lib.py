@@ -52,9 +52,6 @@ SIGNATURES = {
     'cnk_pack_batch': (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     'cnk_conv2d_fwd_bn_partial_slices': (_i64, [_dp]),
     'cnk_conv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'cnk_conv2d_fwd_bn_apply_supported': (ctypes.c_int, [_dp]),
-    'cnk_conv2d_fwd_stats_only_slices': (_i64, [_dp]),
-    'cnk_conv2d_fwd_bn_apply': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     'cnk_conv2d_fwd_act_supported': (ctypes.c_int, [_dp]),
     'cnk_conv2d_fwd_act': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
     'cnk_conv2d_dgrad_accepts_mask': (ctypes.c_int, [_dp]),
@@ -63,11 +60,11 @@ SIGNATURES = {
     'cnk_conv2d_wgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_conv2d_wgrad_min_workspace_bytes': (_sz, [_dp, ctypes.c_int]),
     'cnk_conv2d_bnfold_supported': (ctypes.c_int, [_dp]),
-    'cnk_conv2d_bnfold_image_bytes': (_sz, [_dp, ctypes.c_int]),
+    'cnk_conv2d_bnfold_image_bytes': (_sz, [_dp]),
     'cnk_bn_bwd_coef': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _i64, _i32, ctypes.c_int, _vp,
                                        _sz, _vp]),
-    'cnk_conv2d_bnfold_prepare': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
-    'cnk_conv2d_dgrad_bnfold': (ctypes.c_int, [_dp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnBwdFuse), _vp]),
+    'cnk_conv2d_bnfold_prepare': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cnk_conv2d_dgrad_bnfold': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnBwdFuse), _vp]),
     'cnk_conv2d_wgrad_bnfold': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_bn_workspace_bytes': (_sz, [_i64, _i32]),
     'cnk_bn_mask_bytes': (_sz, [_i64, _i32, ctypes.c_int]),

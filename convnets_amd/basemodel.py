@@ -141,16 +141,25 @@ class MultiClassBaseModel(nn.Module):
         self.flush_bn_counters()
         return loss.detach(), score
 
-    def calibrate_wgrad_share(self, batch, candidates=(1.0, 0.75, 0.5), steps=3):
+    def calibrate_wgrad_share(self, batch, candidates=(1.0, 0.75, 0.5), steps=3, reps=3):
         """Measures ops.WGRAD_SHARE for the EAGER step of this model (see convnets_amd/ops.py; GraphedTrainStep does the same
-        for the captured step): a few steps per candidate on a snapshot of the training state, the fastest stays.  Under
-        data parallelism every rank must call it (the steps issue the gradient all-reduces).  Returns {share: ms}."""
+        for the captured step): per candidate `reps` timings of `steps` steps on a snapshot of the training state, the median
+        counts.  Under data parallelism every rank must call it (the steps issue the gradient all-reduces).  Returns {share: ms}.
+        The share is the fp32 summation order of the split-K weight gradients, i.e. it decides the bits of a run: the choice is
+        kept on the model (`self.wgrad_share`), logged, and CNK_WGRAD_SHARE in the environment PINS it (no measurement) for
+        runs that must reproduce bit for bit across boxes."""
+        import logging
+        import os
         import time
         from . import ops
         from .graph import GraphedTrainStep
         if self.optimizer is None:
             self.init_optimizer()
         if not (ops.WGRAD_STREAM and self.setting.mixed_precision):
+            return {}
+        if os.environ.get('CNK_WGRAD_SHARE'):
+            ops.WGRAD_SHARE[0] = self.wgrad_share = float(os.environ['CNK_WGRAD_SHARE'])
+            logging.getLogger('convnets_amd').info('wgrad split-K share pinned by CNK_WGRAD_SHARE=%s', ops.WGRAD_SHARE[0])
             return {}
         probe = GraphedTrainStep.__new__(GraphedTrainStep)          # borrow its snapshot / restore of the training state
         probe.model = self
@@ -164,12 +173,16 @@ class MultiClassBaseModel(nn.Module):
             for share in candidates:
                 ops.WGRAD_SHARE[0] = share
                 self.train_batch(batch)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    self.train_batch(batch)
-                torch.cuda.synchronize()
-                timings[share] = (time.perf_counter() - t0) / steps * 1e3
+                samples = []
+                for _ in range(reps):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        self.train_batch(batch)
+                    torch.cuda.synchronize()
+                    samples.append((time.perf_counter() - t0) / steps * 1e3)
+                samples.sort()
+                timings[share] = samples[len(samples) // 2]
                 probe._restore(snap)
         except BaseException:
             # a failed probe step must leave neither a candidate share nor a half-trained state behind
@@ -191,7 +204,9 @@ class MultiClassBaseModel(nn.Module):
         # as at 0.75.
         fastest = min(timings.values())
         best = min(c for c in timings if timings[c] <= 1.01 * fastest)
-        ops.WGRAD_SHARE[0] = best
+        ops.WGRAD_SHARE[0] = self.wgrad_share = best
+        logging.getLogger('convnets_amd').info('wgrad split-K share %s chosen from %s (ms per eager step; CNK_WGRAD_SHARE pins it)',
+                                               best, {c: round(v, 3) for c, v in timings.items()})
         return timings
 
     @torch.enable_grad()
@@ -214,17 +229,26 @@ class MultiClassBaseModel(nn.Module):
 
     def _graphed_batch(self, batch):
         """setting.hipgraph: the loop body as one hipGraph launch (convnets_amd/graph.py), one captured graph per
-        batch shape (the last, smaller batch of an epoch gets its own)."""
+        batch shape (the last, smaller batch of an epoch gets its own).
+        Under data parallelism (setting.hipgraph_dp) constructing the graph is a COLLECTIVE operation -- its warm-up steps, the
+        split-K probe and the captured step itself issue the bucket all-reduces -- so there is exactly one point where it
+        happens: the first training batch of the model, which every rank reaches together.  No rank can enter a capture
+        alone afterwards: a batch of another shape runs the EAGER step (it issues the same collectives in the same order as
+        a replay, so ranks may even mix the two), and a learning-rate change rides on the device record (graph.py)."""
         from .graph import GraphedTrainStep
         red = getattr(self, 'grad_reducer', None)
-        if red is not None and red.world > 1:
-            # Capture and every re-capture (new batch shape, new learning rate) issue collectives in their warm-up
-            # steps, so they are COLLECTIVE operations every rank must enter together, and the replay of captured RCCL
-            # nodes has only been verified with one rank: multi-rank data parallel training runs the eager step.
-            return self.train_batch(batch)
+        dp = red is not None and (red.world > 1 or red.force)
+        if dp and red.world > 1 and not self.setting.hipgraph_dp:
+            return self.train_batch(batch)        # multi-rank replays of captured RCCL nodes: opt-in (Settings.hipgraph_dp)
         x, y = self.setting.device.move(batch)
         steps = self.__dict__.setdefault('_graphed_steps', {})
         key = (tuple(x.shape), x.dtype, tuple(y.shape))
+        if dp:
+            if not self.__dict__.get('_graph_dp_built'):
+                self.__dict__['_graph_dp_built'] = True
+                steps[key] = GraphedTrainStep.build_collective(self, (x, y), group=red.group if red.world > 1 else None)
+            st = steps.get(key)
+            return st.replay((x, y)) if st is not None else self.train_batch((x, y))
         if key not in steps:
             steps[key] = GraphedTrainStep(self, (x, y))
         return steps[key].replay((x, y))

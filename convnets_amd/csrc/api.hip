@@ -17,12 +17,10 @@ size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps);
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
-int igemm_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* coef, const void* residual, const float* rcoef, int relu, void* y, unsigned char* mask, hipStream_t s);
-int64_t igemm_fwd_stats_only_slices(const cnk_conv_desc* d);
-int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x2, int mode, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
+int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x2, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 bool bnfold_supported(const cnk_conv_desc* d);
-size_t bnfold_image_bytes(const cnk_conv_desc* d, int mode);
-int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, int mode, void* w_fold, float* bias_fold, hipStream_t s);
+size_t bnfold_image_bytes(const cnk_conv_desc* d);
+int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s);
 int bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* sm, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, int dtype, float* ws, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
 bool dwconv_supported(const cnk_conv_desc* d);
@@ -362,34 +360,10 @@ int64_t cnk_conv2d_fwd_bn_partial_slices(const cnk_conv_desc* d) {
     return cnk_sw().rowpatch_stats && rowpatch_supported(d) ? rowpatch_fwd_stat_slices(d) : 0;
 }
 
-int cnk_conv2d_fwd_bn_apply_supported(const cnk_conv_desc* d) {
-    return check_desc(d, "cnk_conv2d_fwd_bn_apply_supported") == 0 && conv_groups(d) == 1 && conv_dil(d) == 1 && d->kh == 1 && d->kw == 1 &&
-           d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && igemm_supported(d, CNK_PASS_FWD) && igemm_on_grid(d, CNK_PASS_FWD);
-}
-
-int64_t cnk_conv2d_fwd_stats_only_slices(const cnk_conv_desc* d) {
-    return cnk_conv2d_fwd_bn_apply_supported(d) ? igemm_fwd_stats_only_slices(d) : 0;
-}
-
-int cnk_conv2d_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* scale_shift, const void* residual, const float* residual_scale_shift, int relu, void* y, uint8_t* relu_mask, void* stream) {
-    if (int rc = check_desc(d, "cnk_conv2d_fwd_bn_apply")) return rc;
-    CNK_CHECK_ARG(cnk_conv2d_fwd_bn_apply_supported(d), "cnk_conv2d_fwd_bn_apply: this conv shape has no fused BN apply (cnk_conv2d_fwd_bn_apply_supported == 0)");
-    CNK_CHECK_ARG(x && w_fwd && scale_shift && y, "cnk_conv2d_fwd_bn_apply: null pointer");
-    CNK_CHECK_ARG(!residual_scale_shift || residual, "cnk_conv2d_fwd_bn_apply: residual_scale_shift without a residual operand");
-    CNK_CHECK_ARG(!relu_mask || relu, "cnk_conv2d_fwd_bn_apply: relu_mask without relu");
-    double fl, by;
-    conv_cost(d, &fl, &by);
-    if (residual) by += (double)d->N * d->H * d->W * d->Cout * esize(d->dtype);
-    ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
-    return igemm_fwd_bn_apply(d, x, w_fwd, scale_shift, residual, residual_scale_shift, relu, y, relu_mask, S(stream));
-}
-
 int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* bn_partial, void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
     if (int rc = check_desc(d, "cnk_conv2d_fwd")) return rc;
-    CNK_CHECK_ARG(x && w_fwd, "cnk_conv2d_fwd: null pointer");
-    // y == NULL: statistics only (the partials are the call's output) -- on the implicit-GEMM kernel
-    CNK_CHECK_ARG(y || (bn_partial && !bias && cnk_conv2d_fwd_bn_apply_supported(d)), "cnk_conv2d_fwd: y == NULL (statistics only) needs bn_partial, no bias and a shape with cnk_conv2d_fwd_bn_apply_supported");
+    CNK_CHECK_ARG(x && w_fwd && y, "cnk_conv2d_fwd: null pointer");
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
@@ -503,7 +477,7 @@ int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d) {
            wgrad_mfma_supported(d);
 }
 
-size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d, int mode) { return bnfold_image_bytes(d, mode); }
+size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d) { return bnfold_image_bytes(d); }
 
 int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int32_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     CNK_CHECK_ARG(gamma && save_mean && save_invstd && dgamma && dbeta && coef, "cnk_bn_bwd_coef: null pointer");
@@ -514,16 +488,14 @@ int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int
     return bn_bwd_coef(dy, x, ext_partial, ext_slices, gamma, save_mean, save_invstd, dgamma, dbeta, accumulate, coef, M, C, dtype, (float*)workspace, S(stream));
 }
 
-int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean, const float* save_invstd, const float* coef, int mode, void* w_fold, float* bias_fold, void* stream) {
+int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean, const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_bnfold_prepare")) return rc;
     CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_bnfold_prepare: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
     CNK_CHECK_ARG(w && w_dgrad && save_mean && save_invstd && coef && w_fold && bias_fold, "cnk_conv2d_bnfold_prepare: null pointer");
-    CNK_CHECK_ARG(mode == 0 || mode == 1, "cnk_conv2d_bnfold_prepare: mode is 0 (second segment = the conv input) or 1 (= the conv output)");
-    return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef, mode, w_fold, bias_fold, S(stream));
+    return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef, w_fold, bias_fold, S(stream));
 }
 
-int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, int mode, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream) {
-    CNK_CHECK_ARG(mode == 0 || mode == 1, "cnk_conv2d_dgrad_bnfold: mode is 0 (x = the conv input) or 1 (x = the conv output)");
+int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_dgrad_bnfold")) return rc;
     CNK_CHECK_ARG(!addend_mask || addend, "cnk_conv2d_dgrad_bnfold: addend_mask needs an addend");
     CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_dgrad_bnfold: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
@@ -535,9 +507,8 @@ int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x
         int Ho, Wo;
         cnk_conv2d_out_hw(d, &Ho, &Wo);
         const double pxo = (double)d->N * Ho * Wo;                      // the pixels the conv samples (stride)
-        const int c2 = mode ? d->Cout : d->Cin;
-        fl += 2.0 * pxo * d->Cin * c2;                                  // the second K segment
-        by += pxo * c2 * esize(d->dtype);                               // ... reads the conv input (mode 1: output) there
+        fl += 2.0 * pxo * d->Cin * d->Cin;                              // the second K segment
+        by += pxo * d->Cin * esize(d->dtype);                           // ... reads the conv input there
     }
     if (bn) {
         by += px * d->Cin * esize(d->dtype);
@@ -547,7 +518,7 @@ int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x
     }
     if (addend) by += px * d->Cin * esize(d->dtype);
     ProfScope ps(conv_cls(d, 1), S(stream), fl, by);
-    return igemm_dgrad_bnfold(d, g, x, mode, w_fold, bias_fold, dx, addend, addend_mask, bn, S(stream));
+    return igemm_dgrad_bnfold(d, g, x, w_fold, bias_fold, dx, addend, addend_mask, bn, S(stream));
 }
 
 int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {

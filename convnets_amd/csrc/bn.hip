@@ -273,12 +273,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 // __threadfence() in every block of the STREAMING pass lost 1.4 ms per step); the last block of a group runs one acquire
 // (L1 invalidate of its own CU) and reads the shares with sc1 loads.  cdna_hip_programming.md 5, "Projection GEMM" item 2.
 // Tickets live in a __device__ array (zero at module load; the last block resets its counter for the slot's next user).  The
-// 64 slots are 16 BANKS of 4: a bank belongs to ONE stream (host table, first come first served), so two launches that can be
+// 128 slots are 32 BANKS of 4: a bank belongs to ONE stream (host table, first come first served), so two launches that can be
 // in flight together -- different streams -- never share a counter, and launches of one stream, which execute in order, walk
-// their bank round-robin.  A 17th stream takes the two-kernel path.  (the slots used to be handed out from one
+// their bank round-robin.  Once every bank is claimed, a new stream gets the least recently used bank of an idle stream
+// (bnf_slot_for), else the two-kernel path.  (the slots used to be handed out from one
 // process-wide counter, so launches 64 issues apart on two streams could have met on one counter.)  What is NOT covered: two
 // captured graphs holding launches of the same bank replayed CONCURRENTLY on two streams -- include/cnk.h says so.
-constexpr int BNF_BANKS = 16, BNF_PER_BANK = 4, BNF_SLOTS = BNF_BANKS * BNF_PER_BANK, BNF_GROUPS = 64;
+constexpr int BNF_BANKS = 32, BNF_PER_BANK = 4, BNF_SLOTS = BNF_BANKS * BNF_PER_BANK, BNF_GROUPS = 64;
 __device__ unsigned int bn_tickets[BNF_SLOTS * BNF_GROUPS];
 
 struct BnFinalFwd {
@@ -1084,17 +1085,47 @@ static int bn_premerge(const float*& partial, int& slices, int C, float* scratch
 static std::mutex g_bnf_mu;
 static hipStream_t g_bnf_stream[BNF_BANKS];
 static unsigned g_bnf_next[BNF_BANKS];
+static uint64_t g_bnf_used[BNF_BANKS];                 // clock of the bank's last launch (least recently used goes first)
+static bool g_bnf_pinned[BNF_BANKS];                   // a launch of this bank was CAPTURED: a graph may replay it at any time
+static uint64_t g_bnf_clock = 0;
 static int g_bnf_banks = 0;
-static int bnf_slot_for(hipStream_t s) {               // -1: no bank left for this stream
+// A bank belongs to one stream.  When all 16 are taken (a long-lived process that keeps creating streams: every
+// GraphedTrainStep, every test stream), the least recently used bank whose stream is idle -- or no longer exists -- moves to
+// the new stream (they used to be claimed for good, and the 17th stream silently took the two-kernel path for the
+// rest of the process).  Never recycled: a bank with captured launches, and nothing is recycled while the asking stream is
+// capturing (querying another stream is not a capture-safe call).  The fallback is counted (CNK_CNT_BN_FINAL_NOBANK).
+static int bnf_slot_for(hipStream_t s) {               // -1: no bank for this stream right now
     std::lock_guard<std::mutex> lk(g_bnf_mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
     int b = 0;
     while (b < g_bnf_banks && g_bnf_stream[b] != s) ++b;
     if (b == g_bnf_banks) {
-        if (g_bnf_banks == BNF_BANKS) return -1;
+        if (g_bnf_banks < BNF_BANKS) {
+            ++g_bnf_banks;
+        } else {
+            if (capturing) return -1;
+            int victim = -1;
+            for (int k = 0; k < BNF_BANKS; ++k) {
+                if (g_bnf_pinned[k] || (victim >= 0 && g_bnf_used[k] >= g_bnf_used[victim])) continue;
+                hipStreamCaptureStatus vc = hipStreamCaptureStatusNone;
+                hipError_t e = hipStreamIsCapturing(g_bnf_stream[k], &vc);
+                if (e == hipSuccess && vc != hipStreamCaptureStatusNone) continue;           // mid-capture: leave it alone
+                if (e == hipSuccess) e = hipStreamQuery(g_bnf_stream[k]);                    // idle: everything it launched is done
+                if (e == hipErrorNotReady) continue;
+                if (e != hipSuccess) (void)hipGetLastError();                                // the stream is gone: its bank is free
+                victim = k;
+            }
+            if (victim < 0) return -1;
+            b = victim;
+        }
         g_bnf_stream[b] = s;
         g_bnf_next[b] = 0;
-        ++g_bnf_banks;
+        g_bnf_pinned[b] = false;
     }
+    g_bnf_used[b] = ++g_bnf_clock;
+    if (capturing) g_bnf_pinned[b] = true;
     return b * BNF_PER_BANK + (int)(g_bnf_next[b]++ % BNF_PER_BANK);
 }
 template <class FIN>
@@ -1104,7 +1135,10 @@ static int bn_merge_final(const float* partial, int slices, int C, int64_t M, fl
     const int shares = slices >= 2048 ? 64 : 32;          // <= 64: bn_merge_final_kernel reads up to 16 shares per wave, all at once
     if ((int64_t)shares * C * FIN::NV > scratch_floats) return 0;
     const int slot = bnf_slot_for(s);
-    if (slot < 0) return 0;
+    if (slot < 0) {
+        cnk_count(CNK_CNT_BN_FINAL_NOBANK);
+        return 0;
+    }
     hipLaunchKernelGGL((bn_merge_final_kernel<FIN>), dim3(ceil_div(C, 64), shares), dim3(256), 0, s, partial, slices, C, M,
                        scratch, slot, fin);
     hipError_t e = hipGetLastError();

@@ -13,9 +13,8 @@
 // streaming pass (bn_bwd_apply_kernel) and turns the conv data gradient's M * Cout * 2 bytes of reads into M * (Cout + Cin) * 2.
 // The weight gradient forms dy_conv on the fly while it stages its tile (wgrad_mfma_kernel<.., FOLD>, conv_wgrad.hip).
 //
-// Second form (mode 1, for a conv with FEWER output than input channels, e.g. a bottleneck's first block 4f -> f): the BN input y
-// itself is the second K segment -- da = [g | y] x [A W ; -E W] + c, K = 2 Cout, no M matrix -- because reading the f-wide y is
-// cheaper than the 4f-wide conv input.
+// (A second form for convs that NARROW -- the BN input y itself as second K segment, K = 2 Cout, no M matrix -- and the fold of
+// strided 1x1 convs were built and measured in round 4: slower / neutral in the ResNet-50 step; removed in round 5.)
 //
 // This file: the per-step weight image.  One launch, three block roles:
 //   * W' tiles:  wf[j][k] = bf16(A_k * W[k][j])                      from the fp32 master weights (transposed through LDS)
@@ -36,7 +35,6 @@ struct FoldPrepParams {
     float* biasf;          // [Cin]
     int Cout, Cin;
     int nb_w, nb_m;        // blocks of the first two roles (the rest: bias)
-    int mode;              // 0: wf [Cin][Cout + Cin] = [A W ; -M];  1: wf [Cin][2 Cout] = [A W ; -E W]
 };
 
 constexpr int FP_MAXC = 4096;          // Cout bound: one fp32 vector of it lives in LDS
@@ -45,30 +43,25 @@ __global__ __launch_bounds__(256) void bnfold_prep_kernel(const FoldPrepParams p
     __shared__ float vec[FP_MAXC];                 // E_k (M role) or the bias role's per-k factor
     __shared__ float tile[4][32][33];              // W' transpose tile / the four waves' M partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KF = p.mode ? 2 * p.Cout : p.Cout + p.Cin;
+    const int KF = p.Cout + p.Cin;
     const float* cA = p.coef;
     const float* cB1 = p.coef + p.Cout;
     const float* cB2 = p.coef + 2 * (size_t)p.Cout;
     int b = blockIdx.x;
     if (b < p.nb_w) {
-        // ---- W' tile: 32 output channels k x 32 input channels j (mode 1: a second set of tiles scaled by -E_k behind the first)
+        // ---- W' tile: 32 output channels k x 32 input channels j
         const int tj = p.Cin / 32;
-        int kt = b / tj;
-        const int j0 = (b % tj) * 32;
-        const bool second = kt >= p.Cout / 32;
-        if (second) kt -= p.Cout / 32;
-        const int k0 = kt * 32;
+        const int k0 = (b / tj) * 32, j0 = (b % tj) * 32;
         const int c = tid & 31, r0 = tid >> 5;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = r0 + 8 * q, k = k0 + r;
-            const float sc = second ? -(cA[k] * cB2[k] * p.invstd[k]) : cA[k];
-            tile[0][r][c] = sc * p.w[(size_t)k * p.Cin + j0 + c];
+            tile[0][r][c] = cA[k] * p.w[(size_t)k * p.Cin + j0 + c];
         }
         __syncthreads();
         const int j = tid >> 3, k4 = (tid & 7) * 4;
         bf16x4 o = {(bf16)tile[0][k4][j], (bf16)tile[0][k4 + 1][j], (bf16)tile[0][k4 + 2][j], (bf16)tile[0][k4 + 3][j]};
-        *(bf16x4*)(p.wf + (size_t)(j0 + j) * KF + (second ? p.Cout : 0) + k0 + k4) = o;
+        *(bf16x4*)(p.wf + (size_t)(j0 + j) * KF + k0 + k4) = o;
         return;
     }
     b -= p.nb_w;
@@ -154,22 +147,22 @@ __global__ __launch_bounds__(256) void bnfold_prep_kernel(const FoldPrepParams p
 }  // namespace
 
 bool bnfold_supported(const cnk_conv_desc* d) {
-    return d->dtype == CNK_BF16 && conv_groups(d) == 1 && conv_dil(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h >= 1 &&
-           d->stride_w >= 1 && d->stride_h * d->stride_w <= 16 && d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 &&
+    return d->dtype == CNK_BF16 && conv_groups(d) == 1 && conv_dil(d) == 1 && d->kh == 1 && d->kw == 1 && d->stride_h == 1 &&
+           d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && d->Cin % 64 == 0 &&
            d->Cout % 64 == 0 && d->Cout <= FP_MAXC;
 }
 
-size_t bnfold_image_bytes(const cnk_conv_desc* d, int mode) {
-    return (size_t)d->Cin * (mode ? 2 * d->Cout : d->Cout + d->Cin) * sizeof(bf16);
+size_t bnfold_image_bytes(const cnk_conv_desc* d) {
+    return (size_t)d->Cin * (d->Cout + d->Cin) * sizeof(bf16);
 }
 
 int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd,
-                   const float* coef, int mode, void* w_fold, float* bias_fold, hipStream_t s) {
+                   const float* coef, void* w_fold, float* bias_fold, hipStream_t s) {
     FoldPrepParams p = {};
     p.w = w; p.wd = (const bf16*)w_dgrad; p.coef = coef; p.mean = mean; p.invstd = invstd;
-    p.wf = (bf16*)w_fold; p.biasf = bias_fold; p.Cout = d->Cout; p.Cin = d->Cin; p.mode = mode ? 1 : 0;
-    p.nb_w = (d->Cout / 32) * (d->Cin / 32) * (mode ? 2 : 1);
-    p.nb_m = mode ? 0 : (d->Cin / 32) * (d->Cin / 32);
+    p.wf = (bf16*)w_fold; p.biasf = bias_fold; p.Cout = d->Cout; p.Cin = d->Cin;
+    p.nb_w = (d->Cout / 32) * (d->Cin / 32);
+    p.nb_m = (d->Cin / 32) * (d->Cin / 32);
     const int grid = p.nb_w + p.nb_m + d->Cin / 8;
     hipLaunchKernelGGL(bnfold_prep_kernel, dim3(grid), dim3(256), 0, s, p);
     CNK_CHECK_LAUNCH("bnfold_prep");

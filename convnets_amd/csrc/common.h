@@ -69,6 +69,7 @@ enum {
     CNK_CNT_PP_FULL = 9,                                                          // ping-pong launches with the FULL epilogue
     CNK_CNT_BN_FUSED_FINAL = 10, CNK_CNT_BN_FINAL_LAUNCH = 11,
     CNK_CNT_PP_WS = 12,                                                           // weight-stationary 64 -> 64 launches
+    CNK_CNT_BN_FINAL_NOBANK = 13,                                                 // merge + finalise fell back to two launches: no ticket bank
     CNK_CNT_MAX = 32
 };
 void cnk_count(int id);

@@ -41,13 +41,6 @@ struct GatherParams {
     // layer behind the conv (cnk_conv2d_dgrad_bnfold): K = [dy' | conv input].
     const void* src2;
     int C2;
-    int src2_at_src;         // 0: src2 rows are the row's DESTINATION pixel; 1: the row's SOURCE pixel (src2 shaped like src)
-    // FBN kernels (cnk_conv2d_fwd_bn_apply): the training-mode BN of the layer behind the conv applied in the epilogue --
-    // dst = act(round_T(conv) * scale + shift + residual), residual = p.addend (optionally itself round_T(r * rscale + rshift)),
-    // packed ReLU mask out: bit for bit what bn_apply_kernel writes from the stored conv output, which is never stored
-    const float* fbn_coef;   // [2][Nout]: scale | shift
-    const float* fbn_rcoef;  // [2][Nout] or nullptr: the residual's own deferred BN (a projection shortcut)
-    unsigned char* fbn_mask; // packed ReLU mask of dst (one byte per 16-byte vector) or nullptr
     const void* addend;      // optional tensor shaped like dst: dst = conv + addend (fused grad sum)
     const unsigned char* addend_mask;   // optional packed ReLU mask (1 byte per 16-B vector) gating addend
     float* stats;            // optional [tiles_m][Nout][3] BN partials (n, mean, M2) of the OUTPUT
@@ -190,7 +183,7 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 Vec16<T> v;
                 v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
                 const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
-                if (dst) *(decltype(v.v)*)(dst + goff) = v.v;          // (dst == nullptr: statistics only, cnk_conv2d_fwd with y == NULL)
+                *(decltype(v.v)*)(dst + goff) = v.v;
                 if (p.stats) {
 #pragma unroll
                     for (int e = 0; e < PER16; ++e) {
@@ -315,85 +308,9 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
     }
 }
 
-// Epilogue of the FBN kernels: conv -> training-mode BN apply (+ residual) (+ ReLU) (+ packed mask) on the tile, with the
-// arithmetic of bn_apply_row (bn.hip) on the ROUNDED conv value, so the result equals conv-store + BN pass bit for bit while the
-// conv output itself never reaches HBM (it is recomputed for the backward: convnets_amd/ops.py, Y3FreeRecord).
-template <typename T, int BN>
-__device__ __forceinline__ void igemm_epilogue_fbn(const GatherParams& p, unsigned char* smem, const int* row_dst,
-                                                   f32x16 (&acc)[2][BN / 64], int tile_n, int tid, int wm, int wn, int l31, int lh) {
-    constexpr int PER16 = ElemTraits<T>::PER16;
-    constexpr int NJ = BN / 64;
-    constexpr int ES = (int)sizeof(T);
-    constexpr int CS = BN * ES + 16;
-    constexpr int CPR = BN * ES / 16;
-    constexpr int RPP = 256 / CPR;
-    constexpr int NP = BM / RPP;
-    constexpr int GP = NP > 4 ? 4 : NP;
-    unsigned char* Cs = smem + IG_HDR;
-    unsigned char* dst = (unsigned char*)p.dst;
-    const int crow = tid / CPR, cc = tid - crow * CPR;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int row = wm * 64 + i * 32 + l31;
-                const int col = wn * (BN / 2) + j * 32 + 8 * gq + 4 * lh;
-                if constexpr (ES == 2) {
-                    bf16x4 o = {(bf16)acc[i][j][4 * gq], (bf16)acc[i][j][4 * gq + 1], (bf16)acc[i][j][4 * gq + 2], (bf16)acc[i][j][4 * gq + 3]};
-                    *(bf16x4*)(Cs + row * CS + col * 2) = o;
-                } else {
-                    f32x4 o = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
-                    *(f32x4*)(Cs + row * CS + col * 4) = o;
-                }
-            }
-    // this thread's PER16 channels: coefficients in registers, requested back to back
-    const int c0 = tile_n * BN + cc * PER16;
-    const bool raff = p.fbn_rcoef != nullptr;
-    const float* rc = raff ? p.fbn_rcoef : p.fbn_coef;
-    float sc[PER16], sh[PER16], rsc[PER16], rsh[PER16];
-#pragma unroll
-    for (int e = 0; e < PER16; ++e) { sc[e] = p.fbn_coef[c0 + e]; sh[e] = p.fbn_coef[p.Nout + c0 + e]; rsc[e] = rc[c0 + e]; rsh[e] = rc[p.Nout + c0 + e]; }
-#pragma unroll
-    for (int g0 = 0; g0 < NP; g0 += GP) {
-        Vec16<T> rv[GP];
-        int pixs[GP];
-#pragma unroll
-        for (int u = 0; u < GP; ++u) {
-            const int pix = row_dst[(g0 + u) * RPP + crow];
-            pixs[u] = pix;
-            if (pix >= 0 && p.addend)
-                rv[u].v = *(const decltype(rv[u].v)*)((const unsigned char*)p.addend + ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16);
-        }
-        if (g0 == 0) __syncthreads();               // staged tile complete (residual loads already in flight)
-#pragma unroll
-        for (int u = 0; u < GP; ++u) {
-            const int row = (g0 + u) * RPP + crow;
-            const int pix = pixs[u];
-            if (pix >= 0) {
-                Vec16<T> v, o;
-                v.v = *(const decltype(v.v)*)(Cs + row * CS + cc * 16);
-                const size_t goff = ((size_t)pix * p.Nout + tile_n * BN) * ES + cc * 16;
-                unsigned bits = 0;
-#pragma unroll
-                for (int e = 0; e < PER16; ++e) {
-                    float a = v.get(e) * sc[e] + sh[e];
-                    if (p.addend) a += raff ? to_f32(from_f32<T>(rv[u].get(e) * rsc[e] + rsh[e])) : rv[u].get(e);
-                    if (p.relu) a = a > 0.f ? a : 0.f;
-                    bits |= (a > 0.f ? 1u : 0u) << e;
-                    o.set(e, a);
-                }
-                *(decltype(o.v)*)(dst + goff) = o.v;
-                if (p.fbn_mask) p.fbn_mask[goff >> 4] = (unsigned char)bits;
-            }
-        }
-    }
-}
-
 // EDGE: channel counts that are multiples of one 16-byte vector but not of the K step / BN: chunks past C fetch
 // zeros, the weight image is zero-padded to [tiles_n*BN][taps][Cpad], the epilogue skips the missing columns.
-template <typename T, int BN, bool EDGE = false, bool CAT = false, bool FBN = false>
+template <typename T, int BN, bool EDGE = false, bool CAT = false>
 __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams p) {
     constexpr int PER16 = ElemTraits<T>::PER16;      // elements per 16-B chunk
     constexpr int KSTEP = 8 * PER16;                 // channels per K step (128 B)
@@ -534,15 +451,10 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
                              : (const T*)cnk_zero16;
             if constexpr (CAT) {
                 // second segment: the row of src2 is the DESTINATION pixel of this tile row (the conv input at the pixel whose
-                // gradient the row computes; row_dst also carries the stride-parity class of a strided 1x1 conv)
+                // gradient the row computes)
                 if (seg2) {
-                    if (p.src2_at_src) {
-                        gp = ok ? (const T*)p.src2 + ((size_t)(a_base[i] + ih) * p.IW + iw) * p.C2 + cb + c * PER16
-                                : (const T*)cnk_zero16;
-                    } else {
-                        const int pix = row_dst[r];
-                        gp = pix >= 0 ? (const T*)p.src2 + (size_t)pix * p.C2 + cb + c * PER16 : (const T*)cnk_zero16;
-                    }
+                    const int pix = row_dst[r];
+                    gp = pix >= 0 ? (const T*)p.src2 + (size_t)pix * p.C2 + cb + c * PER16 : (const T*)cnk_zero16;
                 }
             }
             __builtin_amdgcn_global_load_lds((gptr_t)gp, (__attribute__((address_space(3))) void*)(As3 + (wave * 8 + 32 * i) * 128), 16, 0, 0);
@@ -568,8 +480,7 @@ __global__ __launch_bounds__(256, 4) void igemm_gather_kernel(const GatherParams
     }
     if (nk == 0) __syncthreads();
 
-    if constexpr (FBN) igemm_epilogue_fbn<T, BN>(p, smem, row_dst, acc, tile_n, tid, wm, wn, l31, lh);
-    else igemm_epilogue<T, BN, EDGE, CAT>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
+    igemm_epilogue<T, BN, EDGE, CAT>(p, smem, row_dst, acc, tile_m, tile_n, tid, wm, wn, l31, lh);
 }
 
 // 3x3 / stride 1 / "same" convolutions (forward, and the data gradient of such a conv): halo reuse.
@@ -875,7 +786,7 @@ static double gather_bytes(const GatherParams& p, size_t esz) {
     return e * esz;
 }
 
-template <typename T, int BN, bool EDGE = false, bool CAT = false, bool FBN = false> int launch_gather(const GatherParams& p, hipStream_t s) {
+template <typename T, int BN, bool EDGE = false, bool CAT = false> int launch_gather(const GatherParams& p, hipStream_t s) {
     size_t pipe = BM * 128 + BN * 128;
     size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
     size_t red = 2 * (256 / (BN * sizeof(T) / 16)) * BN * sizeof(float);     // aliases the staged tile
@@ -883,7 +794,7 @@ template <typename T, int BN, bool EDGE = false, bool CAT = false, bool FBN = fa
     size_t lds = IG_HDR + (pipe > epi ? pipe : epi);
     ProfScope kscope(CNK_KF_GATHER, s, gather_flops(p), gather_bytes(p, sizeof(T)));
     cnk_count(CNK_CNT_GATHER);
-    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE, CAT, FBN>), dim3(p.tiles_total), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((igemm_gather_kernel<T, BN, EDGE, CAT>), dim3(p.tiles_total), dim3(256), lds, s, p);
     CNK_CHECK_LAUNCH("igemm_gather");
     return 0;
 }
@@ -969,7 +880,7 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     if (p.src2) CNK_CHECK_ARG(sizeof(T) == 2 && !p.chunked && p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.sm_h == 1 && p.sm_w == 1 &&
                                   (p.Cpad == 0 || p.Cpad == p.C) && p.C2 % KS == 0 && !p.relu && !p.stats && p.bias,
                               "igemm: a second K segment needs a bf16 one-tap launch with C2 on the K-step grid and a bias");
-    if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.relu && p.dst && !(p.stats && (p.addend || p.bnf_x)))
+    if (sizeof(T) == 2 && !p.chunked && dense_1x1(p) && !p.relu && !(p.stats && (p.addend || p.bnf_x)))
         if (const int nj = gemm1x1_pick(p.M, p.C + (p.src2 ? p.C2 : 0), p.Nout, p.addend || p.bnf_x)) {
             G1Args a = {};
             a.a = p.src; a.b = p.wpk; a.c = p.dst; a.bias = p.bias; a.stats = p.stats;
@@ -1058,13 +969,6 @@ int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
     return ceil_div(d->N * Ho * Wo, BM);
 }
 
-// y == NULL (statistics only) always runs the gather kernel: one slice per BM-row tile
-int64_t igemm_fwd_stats_only_slices(const cnk_conv_desc* d) {
-    int Ho, Wo;
-    cnk_conv2d_out_hw(d, &Ho, &Wo);
-    return ceil_div(d->N * Ho * Wo, BM);
-}
-
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
               float* stats, const void* residual, int relu, hipStream_t s) {
     int Ho, Wo;
@@ -1086,27 +990,6 @@ int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const fl
     p.fd_ohw = make_fastdiv(Ho * Wo);
     p.fd_ow = make_fastdiv(Wo);
     return d->dtype == CNK_BF16 ? launch_gather_bn<bf16>(p, s) : launch_gather_bn<float>(p, s);
-}
-
-// conv (1x1 / stride 1, on the tile grid) + the training-mode BN apply of the layer behind it in one launch (FBN kernels)
-int igemm_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* coef, const void* residual,
-                       const float* rcoef, int relu, void* y, unsigned char* mask, hipStream_t s) {
-    GatherParams p = {};
-    p.src = x; p.wpk = w_fwd; p.dst = y; p.addend = residual; p.relu = relu;
-    p.fbn_coef = coef; p.fbn_rcoef = rcoef; p.fbn_mask = mask;
-    p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cin; p.Cpad = d->Cin;
-    p.OH = d->H; p.OW = d->W; p.FH = d->H; p.FW = d->W; p.Nout = d->Cout;
-    p.sm_h = 1; p.sm_w = 1; p.dm_h = 1; p.dm_w = 1;
-    p.ntaps = 1; p.dh[0] = 0; p.dw[0] = 0;
-    p.M = d->N * d->H * d->W;
-    if (p.M == 0) return 0;
-    p.fd_ohw = make_fastdiv(d->H * d->W);
-    p.fd_ow = make_fastdiv(d->W);
-    const bool use128 = pick_bn128(p.M, p.Nout);
-    p.tiles_n = p.Nout / (use128 ? 128 : 64);
-    p.tiles_total = ceil_div(p.M, BM) * p.tiles_n;
-    if (d->dtype == CNK_BF16) return use128 ? launch_gather<bf16, 128, false, false, true>(p, s) : launch_gather<bf16, 64, false, false, true>(p, s);
-    return use128 ? launch_gather<float, 128, false, false, true>(p, s) : launch_gather<float, 64, false, false, true>(p, s);
 }
 
 // Enumerates the stride-parity classes of the data gradient in the order the packed dgrad
@@ -1153,46 +1036,30 @@ int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     return n;
 }
 
-// Data gradient of a 1x1 conv (no padding, any stride) with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
-// K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c -- for the stride-parity class that
-// holds the conv's one tap; the other classes of a strided conv see no output pixel: zeros (+ addend, + fused BN backward).
-// mode 1: the second segment is the conv OUTPUT y (Cout channels, at the source pixel of the row) instead of the conv input.
-int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, int mode, const void* w_fold, const float* bias_fold,
+// Data gradient of a 1x1 / stride-1 conv (no padding) with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
+// K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c (+ addend, + fused BN backward of the
+// layer in front).
+int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold,
                        void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s) {
-    int Ho, Wo;
-    cnk_conv2d_out_hw(d, &Ho, &Wo);
-    DgradClass cls[16];
-    CNK_CHECK_ARG(d->stride_h * d->stride_w <= 16, "igemm_dgrad_bnfold: stride too large");
-    const int nc = dgrad_classes(d, cls);
-    int tile0 = 0;
-    for (int c = 0; c < nc; ++c) {
-        const DgradClass& k = cls[c];
-        GatherParams p = {};
-        p.src = g; p.wpk = w_fold; p.dst = dx; p.is_dgrad = 1;
-        p.addend = addend; p.addend_mask = addend_mask;
-        p.N = d->N; p.IH = Ho; p.IW = Wo; p.C = d->Cout;
-        p.OH = k.OH; p.OW = k.OW; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
-        p.sm_h = 1; p.sm_w = 1;
-        p.dm_h = d->stride_h; p.dm_w = d->stride_w; p.d_h0 = k.ph; p.d_w0 = k.pw;
-        p.ntaps = k.ntaps;
-        for (int t = 0; t < k.ntaps; ++t) { p.dh[t] = k.dh[t]; p.dw[t] = k.dw[t]; }
-        if (k.ntaps) {                               // the class of the tap: the folded GEMM
-            CNK_CHECK_ARG(k.ntaps == 1 && k.dh[0] == 0 && k.dw[0] == 0, "igemm_dgrad_bnfold: not a 1x1 conv");
-            p.src2 = x; p.C2 = mode ? d->Cout : d->Cin; p.src2_at_src = mode; p.bias = bias_fold;
-        }
-        p.M = d->N * k.OH * k.OW;
-        if (p.M == 0) continue;
-        if (bn) {
-            p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;
-            p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
-            p.bnf_relu = bn->relu; p.bnf_tile0 = tile0;
-            tile0 += ceil_div(p.M, BM);
-        }
-        p.fd_ohw = make_fastdiv(k.OH * k.OW);
-        p.fd_ow = make_fastdiv(k.OW);
-        if (int rc = launch_gather_bn<bf16>(p, s)) return rc;
+    CNK_CHECK_ARG(d->stride_h == 1 && d->stride_w == 1 && d->kh == 1 && d->kw == 1, "igemm_dgrad_bnfold: a 1x1 / stride-1 conv");
+    GatherParams p = {};
+    p.src = g; p.wpk = w_fold; p.dst = dx; p.is_dgrad = 1;
+    p.addend = addend; p.addend_mask = addend_mask;
+    p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cout;
+    p.OH = d->H; p.OW = d->W; p.FH = d->H; p.FW = d->W; p.Nout = d->Cin;
+    p.sm_h = 1; p.sm_w = 1; p.dm_h = 1; p.dm_w = 1;
+    p.ntaps = 1; p.dh[0] = 0; p.dw[0] = 0;
+    p.src2 = x; p.C2 = d->Cin; p.bias = bias_fold;
+    p.M = d->N * d->H * d->W;
+    if (p.M == 0) return 0;
+    if (bn) {
+        p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;
+        p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
+        p.bnf_relu = bn->relu; p.bnf_tile0 = 0;
     }
-    return 0;
+    p.fd_ohw = make_fastdiv(d->H * d->W);
+    p.fd_ow = make_fastdiv(d->W);
+    return launch_gather_bn<bf16>(p, s);
 }
 
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,

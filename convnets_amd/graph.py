@@ -71,6 +71,34 @@ class GraphedTrainStep:
             ops.WGRAD_SHARE[0] = float(wgrad_share)
         self._capture()
 
+    @classmethod
+    def build_collective(cls, model, example_batch, group=None, **kwargs):
+        """The constructor as the COLLECTIVE operation it is under data parallelism: every rank of `group` calls this at the
+        same point of its training loop (the first batch).  Warm-up steps, the split-K probe (its timings are all-reduced, so
+        every rank picks the same share) and the captured step issue the same bucket all-reduces on every rank; afterwards
+        the ranks agree on the outcome -- if the capture was refused on ANY rank, every rank drops its graph and trains
+        eagerly (returns None), so no rank is left replaying collectives its peers issue eagerly in a different order.
+        A rank that dies inside its warm-up leaves the others blocked in a collective, as with any data-parallel step."""
+        import warnings
+        import torch.distributed as dist
+        step, err = None, None
+        try:
+            step = cls(model, example_batch, **kwargs)
+        except (RuntimeError, NotImplementedError, ValueError) as e:      # a refused capture, not a dead process
+            err = e
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if multi:
+            dev = example_batch[0].device
+            ok = torch.tensor([0 if step is None else 1], dtype=torch.int32,
+                              device=dev if dist.get_backend(group) == 'nccl' else 'cpu')
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                step = None
+        if step is None:
+            warnings.warn('GraphedTrainStep: the hipGraph capture was refused%s; every rank trains with the eager step'
+                          % ('' if err is None else ' on this rank (%s: %s)' % (type(err).__name__, err)))
+        return step
+
     # ---- state that a throw-away step must not leave behind ----------------------------------------------
     def _snapshot(self):
         opt = self.model.optimizer

@@ -59,7 +59,7 @@ class Conv2d(nn.Conv2d):
             new.__dict__[k] = ops.PackedWeights() if k == '_packed' else copy.deepcopy(v, memo)
         return new
 
-    def forward(self, x, want_bn_partial=False, link=None, fold=None, lazy=None):
+    def forward(self, x, want_bn_partial=False, link=None, fold=None):
         if self._depthwise:                      # conv2d_depthwise (basemodel.py:981-997)
             y = ops.DepthwiseConv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
             return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
@@ -76,7 +76,7 @@ class Conv2d(nn.Conv2d):
                                       self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), 1)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
                                   self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups,
-                                  self._dil, fold, lazy)
+                                  self._dil, fold)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -87,7 +87,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     # model then bumps every layer's num_batches_tracked with ONE kernel per step, not one per layer
     _deferred_counter = None
 
-    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None, fold=None, defer=False, lazy=None):
+    def forward(self, x, residual=None, relu=False, partial=None, link=None, pool=None, fold=None, defer=False):
         """pool: the MaxPool2d module that consumes this layer's output (ConvBlock passes it for the stems, training
         mode only): BN, ReLU and the pooling then run as one autograd node and the POOLED tensor is returned."""
         if not (self.affine and self.track_running_stats):
@@ -108,7 +108,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                 holder = [] if defer else None
                 y = ops.BatchNormActFn.apply(x, self.weight, self.bias, residual, self.running_mean,
                                              self.running_var, float(self.eps), float(self.momentum),
-                                             bool(relu), partial, link, rec, fold, holder, res_affine, lazy)
+                                             bool(relu), partial, link, rec, fold, holder, res_affine)
                 if rec is not None and rec.x is not None:
                     y._cnk_bn = rec
                 if defer:
@@ -120,6 +120,12 @@ class BatchNorm2d(nn.BatchNorm2d):
             else:
                 self.num_batches_tracked += 1
             return y
+        if residual is not None and getattr(residual, '_cnk_defer', None) is not None:
+            #  the residual is a projection shortcut's UN-normalised conv output whose BN apply pass was left to
+            # this layer's training-mode pass; an eval-mode layer has no such pass -- adding it as it is would be silently wrong
+            raise RuntimeError('convnets_amd.BatchNorm2d: the residual operand carries a deferred BN apply pass (a projection '
+                               'shortcut in training mode) but this layer is in eval mode; put both in the same mode, or call '
+                               'the shortcut block without defer_apply')
         return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var,
                                    float(self.eps), residual, relu)
 
@@ -291,17 +297,15 @@ class ConvBlock(nn.Sequential):
         conv = mods[0]
         bn = mods[1] if len(mods) > 1 and isinstance(mods[1], BatchNorm2d) else None
         act = isinstance(mods[-1], ReLU)
+        if residual is not None and getattr(residual, '_cnk_defer', None) is not None and not (bn is not None and bn.training):
+            raise RuntimeError('ConvBlock: a residual operand with a deferred BN apply pass needs a training-mode BatchNorm in this '
+                               'block (the shortcut block asks its consumer first: ConvBlock.applies_deferred_residual)')
         if bn is not None:
             if bn.training:      # the conv epilogue also emits the BN statistics partials
                 # (fold: the BN backward's apply pass runs inside this conv's backward where the shape allows, ops.FoldRecord)
                 fold = ops.FoldRecord() if (ops.BN_FOLD and torch.is_grad_enabled()
                                             and isinstance(conv, Conv2d) and conv.kernel_size == (1, 1)) else None
-                # (lazy: a widening 1x1 conv in front of a BN with a residual operand -- a bottleneck's last block -- may leave
-                # its output out of the forward, ops.LazyConvOut)
-                lazy = ops.LazyConvOut() if (ops.LAZY_CONV_OUT and residual is not None and not defer_apply
-                                             and torch.is_grad_enabled() and isinstance(conv, Conv2d)
-                                             and conv.kernel_size == (1, 1) and conv.stride == (1, 1)) else None
-                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold, lazy=lazy)
+                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold)
                 pool = self._linked_pool()
                 if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
@@ -309,8 +313,7 @@ class ConvBlock(nn.Sequential):
                 if defer_apply and not act and residual is None and torch.is_grad_enabled() and DEFER_SHORTCUT_BN:
                     return bn(y, partial=partial, defer=True, fold=fold if (fold is not None and fold.ok) else None)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
-                          link=res_link, fold=fold if (fold is not None and fold.ok) else None,
-                          lazy=lazy if (lazy is not None and lazy.ok) else None)
+                          link=res_link, fold=fold if (fold is not None and fold.ok) else None)
             if not torch.is_grad_enabled():
                 # inference: BN folded into the conv, ReLU / residual add in its epilogue (one kernel)
                 fold = self.__dict__.setdefault('_fold', ops.FoldedConv())
@@ -321,14 +324,24 @@ class ConvBlock(nn.Sequential):
                 if y is not None:
                     return y
             return bn(conv(x), residual=residual, relu=act or relu_after_add)
-        if residual is not None and getattr(residual, '_cnk_defer', None) is not None:
-            raise RuntimeError('ConvBlock: a residual operand with a deferred BN apply pass needs a BatchNorm in this block')
         y = conv(x, link=in_link)
         if residual is not None:
             if act:
                 y = ops.ReLUFn.apply(y)
             return ops.AddReLUFn.apply(y, residual) if relu_after_add else y + residual
         return ops.ReLUFn.apply(y) if act else y
+
+
+def _applies_deferred_residual(self):
+    """True when this block's forward will run a training-mode BN apply pass that can normalise a residual operand on the fly
+    (cnk_bn_fwd_train_res_affine): what a projection shortcut asks its consumer before it defers its own apply pass -- with
+    BN frozen per submodule the two layers may be in different modes."""
+    mods = list(self)
+    bn = mods[1] if len(mods) > 1 and isinstance(mods[1], BatchNorm2d) else None
+    return bn is not None and bn.training and torch.is_grad_enabled() and DEFER_SHORTCUT_BN
+
+
+ConvBlock.applies_deferred_residual = _applies_deferred_residual
 
 
 def _conv_block_linked_pool(self):

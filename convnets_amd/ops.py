@@ -6,7 +6,6 @@ reference's semantics -- flatten order, state_dict shapes [Cout,Cin,kh,kw] -- ar
 PyTorch is used for device memory, streams and autograd bookkeeping only; every kernel that
 touches an activation is in libcnk.so.  Nothing here falls back to ATen/MIOpen.
 """
-import contextlib
 import ctypes
 import os
 import weakref
@@ -178,7 +177,7 @@ def join_side_streams(device=None):
 # ~1,900 launches from Python).  _lib.reload_switches() (tests, A/B tools) moves the epoch and drops them.
 class ConvPlan:
     __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'wgrad_min_ws', 'wgrad_min_ws_bias', 'accepts_mask',
-                 'bnfold', 'fold_bytes', 'stats_only_slices')
+                 'bnfold', 'fold_bytes')
 
 
 _conv_plans = {}
@@ -202,8 +201,7 @@ def conv_plan(x_shape, weight_shape, stride, padding, dtype_code, groups, dilati
         pl.wgrad_min_ws_bias = lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(d), 1)
         pl.accepts_mask = bool(lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(d)))
         pl.bnfold = bool(lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)))
-        pl.fold_bytes = tuple(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), m) for m in (0, 1)) if pl.bnfold else (0, 0)
-        pl.stats_only_slices = lib.cnk_conv2d_fwd_stats_only_slices(ctypes.byref(d))
+        pl.fold_bytes = lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)) if pl.bnfold else 0
         if len(_conv_plans) > 4096:
             _conv_plans.clear()
         _conv_plans[key] = pl
@@ -245,10 +243,10 @@ class BnRecord:
     `fused = (dx, partial)`, and BatchNormActFn.backward uses it only if the gradient autograd then
     delivers is that very tensor (any other consumer of y makes autograd sum into a new tensor, and
     the regular two-pass backward runs: masking twice is idempotent, so that path stays exact)."""
-    __slots__ = ('x', 'mean', 'invstd', 'gamma', 'beta', 'mask', 'relu', 'fused', 'lazy')
+    __slots__ = ('x', 'mean', 'invstd', 'gamma', 'beta', 'mask', 'relu', 'fused')
 
     def __init__(self):
-        self.x = self.mean = self.invstd = self.gamma = self.beta = self.mask = self.fused = self.lazy = None
+        self.x = self.mean = self.invstd = self.gamma = self.beta = self.mask = self.fused = None
         self.relu = False
 
 
@@ -259,11 +257,10 @@ class FoldRecord:
     (dgamma, dbeta, the three coefficient vectors), parks them here together with the gradient w.r.t. the BN OUTPUT, and hands
     that very tensor to autograd as the "gradient" of the conv output; Conv2dFn.backward recognises it (same storage) and runs
     cnk_conv2d_dgrad_bnfold / cnk_conv2d_wgrad_bnfold.  The [M][Cout] gradient w.r.t. the conv output is never written."""
-    __slots__ = ('ok', 'mode', 'g', 'y', 'mean', 'invstd', 'coef')
+    __slots__ = ('ok', 'g', 'y', 'mean', 'invstd', 'coef')
 
     def __init__(self):
         self.ok = False                   # set by Conv2dFn.forward when the conv shape can fold
-        self.mode = 0                     # 0: K = [g | conv input] (widening convs); 1: K = [g | conv output] (narrowing convs)
         self.g = self.y = self.mean = self.invstd = self.coef = None
 
 
@@ -273,101 +270,15 @@ BN_FOLD = os.environ.get('CNK_BN_FOLD', '1') != '0'
 # BN input read beside the gradient): measured per ResNet-50 stage at batch 256 (tools/bench_fold.py) 366 -> 163 / 203 -> 110 /
 # 119 -> 83 / 87 -> 91 us on the compute stream, i.e. not at 7x7; the rule below is M * Cout elements of the BN tensor.
 BN_FOLD_MIN_ELEMS = float(os.environ.get('CNK_BN_FOLD_MIN', '4e7'))
-# mode 1 (a conv that narrows, Cout <= Cin: a bottleneck's first block): second segment = the BN input, K = 2 Cout, no M matrix.
-# Correct (tests/test_gpu_round4.py: 2.5e-3 against fp64) and measured SLOWER in the ResNet-50 step (19.80 -> 19.95 ms with
-# stages 1-2 folded, 19.87 with stage 1 only, three alternating pairs): the pass it removes is f channels wide, the data gradient
-# it lengthens is the step's largest launch.  Off by default.
-BN_FOLD_Y = os.environ.get('CNK_BN_FOLD_Y', '0') != '0'
-BN_FOLD_MIN_ELEMS_Y = float(os.environ.get('CNK_BN_FOLD_MIN_Y', '2e7'))
-# strided projection shortcuts too?  The library folds them (the stride-parity class of the tap; tests/test_gpu_round4.py), but
-# in the ResNet-50 step it measured neutral (19.23 vs 19.26 ms, four alternating pairs): the removed apply pass is a quarter of
-# the stride-1 one's size and the data gradient's K grows by a half.  Off by default.
-BN_FOLD_STRIDED = os.environ.get('CNK_BN_FOLD_STRIDED', '0') != '0'
+# (Round 4 also had: the fold's second form for convs that narrow (the BN input as second K segment), the fold of strided
+# projection shortcuts, and LazyConvOut (the conv output of a bottleneck's last block left out of the forward and replayed in
+# the backward).  Each measured slower or neutral in the ResNet-50 step -- 19.80 -> 19.95, 19.23 vs 19.26, 19.65 -> 19.88 ms,
+# DESIGN.md 7b / 9 -- and was removed in round 5: one folded path in Conv2dFn.backward.)
 FOLD_COUNTS = {'folded': 0}               # folded conv backward passes (tests read this)
 BN_BWD_FUSE = os.environ.get('CNK_BN_BWD_FUSE', '1') != '0'
 # the same fusion for the stride-1 3x3 convs only (A/B switch, DESIGN.md: break-even per layer, see there)
 BN_BWD_FUSE_3X3 = os.environ.get('CNK_BN_BWD_FUSE_3X3', '1') != '0'
 FUSE_COUNTS = {'bn_bwd_fused': 0, 'bn_bwd_unfused': 0}      # which backward path ran (tests read this)
-
-
-class LazyConvOut:
-    """Shared by the Conv2dFn and the BatchNormActFn of one conv(1x1, stride 1) -> BN pair (layers.ConvBlock.forward) whose
-    conv output is NOT kept between the forward and the backward: the forward runs the conv twice (statistics only, then
-    conv + BN apply in the epilogue: cnk_conv2d_fwd with y == NULL, cnk_conv2d_fwd_bn_apply) and the tensor autograd sees as
-    the conv output has an EMPTY storage.  The backward needs that tensor (the BN backward's x-hat; the folded weight
-    gradient): when the first backward node of this package runs, every pending record's storage is given back its size and
-    the plain conv is replayed into it on the weight-gradient stream (prefetch_lazy), concurrent with the backward of the
-    network's last stages; a reader calls wait() first.  The values are the ones the stored path keeps (same kernel
-    arithmetic), so the backward is bit-identical."""
-    __slots__ = ('ok', 'desc', 'x', 'w_fwd', 'y', 'nbytes', 'ready', 'state', '__weakref__')
-
-    def __init__(self):
-        self.ok = False                   # set by Conv2dFn.forward when the conv output is left out
-        self.desc = self.x = self.w_fwd = self.y = self.ready = None
-        self.nbytes = 0
-        self.state = 0                    # 0: no storage (after the forward), 1: recomputed, 2: released
-
-    def wait(self):
-        """Before the first read of y on the current stream."""
-        if self.state == 0:
-            prefetch_lazy()
-        if self.state != 1:
-            raise RuntimeError('convnets_amd: a conv output that was left out of the forward (ops.LazyConvOut) is needed a second '
-                               'time; backward(retain_graph=True) twice over such a graph needs CNK_LAZY_CONV_OUT=0')
-        if self.ready is not None:
-            torch.cuda.current_stream(self.y.device).wait_event(self.ready)
-            self.ready = None
-
-    def release(self):
-        if self.state == 1:
-            self.y.untyped_storage().resize_(0)
-        self.state = 2
-        self.x = self.w_fwd = self.ready = None
-
-
-# Leave the conv output of a bottleneck's last block out of the forward?  Per block the forward moves 10 instead of 17 element
-# transfers per pixel and narrow channel and the conv runs three times instead of once (tools/bench_y3free.py, forward at batch
-# 256: 386 -> 316 us at 56x56, 219 -> 195 at 28x28, 115 -> 139 at 14x14): the rule below is M * Cout elements of that tensor.
-# In the ResNet-50 step the backward gives the forward's gain back and more (19.65 -> 19.88 ms, three alternating pairs): the
-# weight-gradient stream already carries ~9.7 ms of kernels inside a ~12 ms backward, so the seven replayed convs (0.6 ms) land
-# on its critical path, and each replay re-writes the tensor the forward saved (net traffic saved per step: ~1 GB of ~65).
-# What it does buy is memory: 2.1 GB of activations less at batch 256.  Off by default; bit-identical when on.
-LAZY_CONV_OUT = os.environ.get('CNK_LAZY_CONV_OUT', '0') != '0'
-LAZY_MIN_ELEMS = float(os.environ.get('CNK_LAZY_CONV_OUT_MIN', '8e7'))
-LAZY_COUNTS = {'left_out': 0, 'recomputed': 0}
-_lazy_pending = []                        # weak references, in forward order
-
-
-def prefetch_lazy():
-    """Replays the convs of all pending LazyConvOut records (latest first: the backward needs them in that order)."""
-    if not _lazy_pending:
-        return
-    recs = [r for r in (w() for w in reversed(_lazy_pending)) if r is not None and r.state == 0]
-    del _lazy_pending[:]
-    if not recs:
-        return
-    lib = _lib.load()
-    dev = recs[0].y.device
-    for r in recs:
-        r.y.untyped_storage().resize_(r.nbytes)          # on the compute stream's allocator pool
-    main = torch.cuda.current_stream(dev)
-    side = wgrad_stream(dev) if WGRAD_STREAM else None
-    if side is not None:
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)                              # whatever used that memory before is done
-    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-        for r in recs:
-            check(lib.cnk_conv2d_fwd(ctypes.byref(r.desc), _p(r.x), _p(r.w_fwd), None, _p(r.y), None, None, 0, _stream()))
-            r.state = 1
-            LAZY_COUNTS['recomputed'] += 1
-            if side is not None:
-                r.ready = torch.cuda.Event()
-                r.ready.record(side)
-                r.y.record_stream(side)
-                r.x.record_stream(side)
-    if side is not None:
-        _join_at_end_of_backward()
 
 
 class GradLink:
@@ -543,12 +454,10 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None,
-                bn_rec=None, groups=1, dilation=1, fold=None, lazy=None):
+                bn_rec=None, groups=1, dilation=1, fold=None):
         """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
         of y emitted by the conv epilogue (None when this conv shape cannot produce them).
-        link: optional GradLink shared with the other consumer of x (residual blocks).
-        lazy: LazyConvOut shared with the BatchNormActFn that is y's only consumer; when this call sets lazy.ok the returned
-        y has NO storage (statistics only) and that BN call must produce its output with cnk_conv2d_fwd_bn_apply."""
+        link: optional GradLink shared with the other consumer of x (residual blocks)."""
         _require_gpu(x)
         lib = _lib.load()
         ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) bn_partial
@@ -562,25 +471,12 @@ class Conv2dFn(torch.autograd.Function):
         y = torch.empty((desc.N, desc.Cout, plan.Ho, plan.Wo), dtype=x.dtype, device=x.device,
                         memory_format=CL)
         partial = None
-        left_out = lazy is not None and LAZY_CONV_OUT and want_bn_partial and plan.stats_only_slices > 0 and bias is None \
-            and x_needs_grad and x.dtype == torch.bfloat16 and y.numel() >= LAZY_MIN_ELEMS and desc.Cout >= 2 * desc.Cin
-        if left_out:
-            # statistics only; y keeps its shape and loses its storage until the backward (LazyConvOut)
-            partial = torch.empty((plan.stats_only_slices, desc.Cout, 3), dtype=torch.float32, device=x.device)
-            check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), None, None, _p(partial), None, 0, _stream()))
-            # (an alias without autograd history: the returned y's grad_fn is this node, whose ctx holds the record)
-            lazy.ok, lazy.desc, lazy.x, lazy.w_fwd, lazy.y = True, desc, x, w_fwd, y.detach()
-            lazy.nbytes = y.untyped_storage().nbytes()
-            y.untyped_storage().resize_(0)
-            LAZY_COUNTS['left_out'] += 1
-        else:
-            if want_bn_partial:
-                slices = plan.fwd_slices
-                if slices > 0:
-                    partial = torch.empty((slices, desc.Cout, 3), dtype=torch.float32, device=x.device)
-            check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial),
-                                     None, 0, _stream()))
-        ctx.lazy = lazy if left_out else None
+        if want_bn_partial:
+            slices = plan.fwd_slices
+            if slices > 0:
+                partial = torch.empty((slices, desc.Cout, 3), dtype=torch.float32, device=x.device)
+        check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial),
+                                 None, 0, _stream()))
         ctx.save_for_backward(x, w)
         ctx.desc, ctx.w_dgrad, ctx.has_bias, ctx.plan = desc, w_dgrad, bias is not None, plan
         ctx.params = (weight, bias)
@@ -589,13 +485,10 @@ class Conv2dFn(torch.autograd.Function):
         # conv -> BN with the BN backward folded into this conv's backward (FoldRecord): dense 1x1 bf16, no bias
         ctx.fold = None
         if fold is not None and BN_FOLD and plan.bnfold and bias is None and w.dtype == torch.float32 \
-                and x_needs_grad and w_dgrad is not None and (desc.stride_h == 1 or BN_FOLD_STRIDED):
+                and x_needs_grad and w_dgrad is not None:
             elems = desc.N * plan.Ho * plan.Wo * desc.Cout
             if desc.Cout >= 2 * desc.Cin and elems >= BN_FOLD_MIN_ELEMS:
-                fold.ok, fold.mode = True, 0          # K grows by Cin / Cout
-                ctx.fold = fold
-            elif desc.Cout <= desc.Cin and BN_FOLD_Y and desc.stride_h == 1 and elems >= BN_FOLD_MIN_ELEMS_Y:
-                fold.ok, fold.mode = True, 1          # K doubles, but the narrow BN input is read instead of the wide conv input
+                fold.ok = True                        # K grows by Cin / Cout
                 ctx.fold = fold
         if want_bn_partial:
             if partial is None:
@@ -608,26 +501,33 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
         if dy is None:                        # y took no part in the loss
-            return (None,) * 13
-        if _lazy_pending:
-            prefetch_lazy()
+            return (None,) * 12
         x, w = ctx.saved_tensors
         desc = ctx.desc
         # folded BN backward: dy is the gradient w.r.t. the BN OUTPUT, parked by BatchNormActFn.backward
         fold, ctx.fold = ctx.fold, None
         if fold is not None:
             fold.ok = False
-            if fold.g is None or fold.g.data_ptr() != dy.data_ptr() or fold.g.shape != dy.shape:
-                fold = None
+            if fold.g is None:
+                fold = None                   # the BN backward in front of this node took the unfolded path: dy is dy_conv
+            elif fold.g.data_ptr() != dy.data_ptr() or fold.g.shape != dy.shape:
+                # BatchNormActFn.backward DID fold (it skipped its apply pass and returned the gradient w.r.t. the BN output
+                # as this conv's "gradient"), but autograd delivers a different tensor -- a hook cloned or rescaled it, or a
+                # second consumer's gradient was accumulated on top: the plain backward on it would be silently wrong
+                # 
+                fold.g = fold.y = fold.mean = fold.invstd = fold.coef = None
+                raise RuntimeError('convnets_amd: the gradient of a conv output whose BN backward was folded into the conv '
+                                   '(ops.FoldRecord) reached Conv2dFn.backward as a different tensor (a tensor hook or a second '
+                                   'consumer of the conv output?); run with CNK_BN_FOLD=0')
         dy = _nhwc(dy)
         dx = dw = db = None
         w_fold = bias_fold = None
         if fold is not None:
             FOLD_COUNTS['folded'] += 1
-            w_fold = torch.empty(ctx.plan.fold_bytes[fold.mode], dtype=torch.uint8, device=x.device)
+            w_fold = torch.empty(ctx.plan.fold_bytes, dtype=torch.uint8, device=x.device)
             bias_fold = torch.empty(desc.Cin, dtype=torch.float32, device=x.device)
             check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(desc), _p(w), _p(ctx.w_dgrad), _p(fold.mean), _p(fold.invstd),
-                                                _p(fold.coef), fold.mode, _p(w_fold), _p(bias_fold), _stream()))
+                                                _p(fold.coef), _p(w_fold), _p(bias_fold), _stream()))
         # dy is complete on the compute stream HERE: the weight gradient (issued below on the second
         # stream) waits for this point only, so it also overlaps this conv's own data gradient
         dy_ready = None
@@ -654,15 +554,13 @@ class Conv2dFn(torch.autograd.Function):
                         and (BN_BWD_FUSE_3X3 or desc.kh != 3 or desc.stride_h != 1):
                     slices = ctx.plan.dgrad_slices
                     if slices > 0:
-                        if rec.lazy is not None:
-                            rec.lazy.wait()               # the BN input is being recomputed on the side stream
                         partial = torch.empty((slices, desc.Cin, 2), dtype=torch.float32, device=x.device)
                         fuse = _lib.BnBwdFuse(rec.x.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr(),
                                               rec.gamma.data_ptr(), rec.beta.data_ptr(),
                                               rec.mask.data_ptr() if rec.mask is not None else None,
                                               partial.data_ptr(), int(rec.relu))
                 if fold is not None:
-                    check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fold.y if fold.mode else x), fold.mode,
+                    check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(desc), _p(dy), _p(x),
                                                       _p(w_fold), _p(bias_fold), _p(out), _p(addend), _p(amask),
                                                       ctypes.byref(fuse) if fuse else None, _stream()))
                 else:
@@ -730,10 +628,7 @@ class Conv2dFn(torch.autograd.Function):
                 run_wgrad()
         if fold is not None:
             fold.g = fold.y = fold.mean = fold.invstd = fold.coef = None
-        if ctx.lazy is not None:
-            ctx.lazy.release()                # the BN backward in front of this node was its last reader
-            ctx.lazy = None
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -742,10 +637,8 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu,
-                partial=None, link=None, rec=None, fold=None, defer=None, res_affine=None, lazy=None):
-        """lazy (LazyConvOut with .ok set by the conv that produced x): x has no storage; the output comes from the conv
-        replayed with this layer's apply pass in its epilogue (bit-identical to the stored sequence).
-        defer (a list, or None): statistics only -- the apply pass of this layer (no activation, no residual: a projection
+                partial=None, link=None, rec=None, fold=None, defer=None, res_affine=None):
+        """defer (a list, or None): statistics only -- the apply pass of this layer (no activation, no residual: a projection
         shortcut, resnet.py:90-91) is left to the ONE consumer of its output, the `output += identity` of the block's last
         BN; the returned tensor aliases x (un-normalised) and the layer's scale | shift [2][C] are appended to the list
         (layers.BatchNorm2d.forward attaches them to the output as `_cnk_defer`).  res_affine: such a deferred layer's
@@ -776,20 +669,7 @@ class BatchNormActFn(torch.autograd.Function):
         mask = None
         if relu and residual is not None and x_needs_grad:
             mask = torch.empty(mask_bytes, dtype=torch.uint8, device=x.device)
-        if lazy is not None and not lazy.ok:
-            lazy = None
-        if lazy is not None:
-            if defer is not None or partial is None or lazy.y.shape != x.shape:
-                raise ValueError('batch_norm: a conv output that was left out needs the conv\'s statistics partials and an apply pass')
-            check(lib.cnk_bn_fwd_train(None, _p(gamma), _p(beta), None, None, None,
-                                       _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
-                                       M, C, eps, momentum, 0, _dtype_code(x), _p(ws), ws.numel(), _stream()))
-            coef = ws[:8 * C].view(torch.float32).clone()         # scale | shift (the workspace is shared)
-            y = torch.empty_like(x, memory_format=CL)
-            check(lib.cnk_conv2d_fwd_bn_apply(ctypes.byref(lazy.desc), _p(lazy.x), _p(lazy.w_fwd), _p(coef), _p(residual),
-                                              _p(res_affine), int(relu), _p(y), _p(mask), _stream()))
-            _lazy_pending.append(weakref.ref(lazy))
-        elif defer is not None:
+        if defer is not None:
             # statistics only; scale | shift are left at the start of the (shared) workspace: keep a copy for the consumer
             check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), None, None, None,
                                        _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
@@ -818,28 +698,23 @@ class BatchNormActFn(torch.autograd.Function):
         ctx.link = link if res_needs_grad else None
         ctx.rec = None
         ctx.fold = fold if (fold is not None and fold.ok and x_needs_grad and x.dtype == torch.bfloat16) else None
-        ctx.lazy = lazy
         if rec is not None and x_needs_grad and (mask is not None or residual is None):
             # what a consumer conv needs to run this layer's backward reduction in its dgrad epilogue
             rec.x, rec.mean, rec.invstd, rec.gamma, rec.beta = x, save_mean, save_invstd, gamma.detach(), beta.detach()
-            rec.mask, rec.relu, rec.lazy = mask, bool(relu), lazy
+            rec.mask, rec.relu = mask, bool(relu)
             ctx.rec = rec
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        if _lazy_pending:
-            prefetch_lazy()
         x, y, mask, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
-        if ctx.lazy is not None:
-            ctx.lazy.wait()                   # x is the conv output the forward left out: recomputed by now (or right here)
         # first pass already done by the consumer conv's dgrad epilogue?  Only if autograd hands back
         # exactly the tensor that conv wrote (no other gradient was accumulated on top of it)
         fused, ext_partial = None, None
         if ctx.rec is not None:
             fused, ctx.rec.fused = ctx.rec.fused, None
-            ctx.rec.x = ctx.rec.lazy = None
+            ctx.rec.x = None
         if fused is not None and fused[0].data_ptr() == dy.data_ptr() and fused[0].shape == dy.shape \
                 and dy.is_contiguous(memory_format=CL):
             ext_partial = fused[1]
@@ -896,7 +771,7 @@ class BatchNormActFn(torch.autograd.Function):
             # identity shortcut: park the residual gradient for the block's first conv, whose
             # dgrad epilogue adds it (falls back to a plain add if this backward is the last one)
             dres = ctx.link.contribute(lambda parked: dres if parked is None else dres + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx, want_res, ext_partial, M, C):
@@ -935,7 +810,7 @@ class BatchNormActFn(torch.autograd.Function):
             dres = dy
             if ctx.link is not None:
                 dres = ctx.link.contribute(lambda parked: dy if parked is None else dy + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):

@@ -37,7 +37,8 @@ class ResBlock(nn.Module):                                   # src/resnet.py:119
         if self.dim_synch is None:
             output = self.res_block[0](x, in_link=link)
             return self.res_block[1](output, residual=x, relu_after_add=True, res_link=link)
-        identity = self.dim_synch(x, in_link=link, defer_apply=True)      # its BN is applied inside the last block's BN pass
+        # (its BN is applied inside the last block's BN pass -- when that block runs one)
+        identity = self.dim_synch(x, in_link=link, defer_apply=self.res_block[1].applies_deferred_residual())
         output = self.res_block[0](x, in_link=link)
         return self.res_block[1](output, residual=identity, relu_after_add=True)
 
@@ -58,7 +59,8 @@ class ResBottleneck(nn.Module):                              # src/resnet.py:158
             output = self.res_bottleneck[0](x, in_link=link)
             output = self.res_bottleneck[1](output)
             return self.res_bottleneck[2](output, residual=x, relu_after_add=True, res_link=link)
-        identity = self.dim_synch(x, in_link=link, defer_apply=True)      # its BN is applied inside the last block's BN pass
+        # (its BN is applied inside the last block's BN pass -- when that block runs one)
+        identity = self.dim_synch(x, in_link=link, defer_apply=self.res_bottleneck[2].applies_deferred_residual())
         output = self.res_bottleneck[0](x, in_link=link)
         output = self.res_bottleneck[1](output)
         return self.res_bottleneck[2](output, residual=identity, relu_after_add=True)

@@ -31,7 +31,12 @@ class Settings:
                grad_clip_norm=False, gc_max_norm=1, grad_clip_value=False, gc_value=1,
                init_params=True, sanity_check=False, debug=False, mixed_precision=True, seed=21,
                test_sample_size=90,
-               hipgraph=False)     # (not a reference field) train_model replays a captured hipGraph per batch shape
+               hipgraph=False,     # (not a reference field) train_model replays a captured hipGraph per batch shape
+               # (not a reference field) the same under data parallelism (BASELINE config 5: "comm/compute overlap + hipGraph-captured
+               # step"): the capture -- warm-up, split-K probe and the captured step all issue the bucket all-reduces -- is then a
+               # COLLECTIVE operation entered by every rank at its first training batch (basemodel._graphed_batch).  None: the
+               # environment decides (CNK_GRAPH_DP=1), default off: replays of captured RCCL nodes are verified on one rank only
+               hipgraph_dp=None)
 
     def __init__(self, kind, input_size, num_classes, device=None, **kwargs):
         self.kind = kind
@@ -44,6 +49,9 @@ class Settings:
             val = kwargs.get(k)
             setattr(self, k, v if val is None else val)     # None -> default, as settings.py:294-300
         self.device = device if isinstance(device, DeviceMngr) else DeviceMngr(device)
+        if self.hipgraph_dp is None:
+            import os
+            self.hipgraph_dp = os.environ.get('CNK_GRAPH_DP', '0') == '1'
 
     @property
     def compute_dtype(self):

@@ -157,22 +157,6 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
  * scratch) for the split-K kernels, cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD) for every other kernel. */
 size_t cnk_conv2d_wgrad_min_workspace_bytes(const cnk_conv_desc* d, int has_bias);
 
-/* conv2d_block without ever storing the conv output (round 4; the last block of a bottleneck: conv 1x1 -> BN -> += identity ->
- * ReLU, resnet.py:172-176,191-194).  Training-mode BN needs the batch statistics of the conv output before it can be applied, so
- * the conv runs TWICE: cnk_conv2d_fwd with y == NULL leaves only the statistics partials; cnk_bn_fwd_train with y == NULL turns
- * them into scale | shift (start of its workspace; copy them out); cnk_conv2d_fwd_bn_apply recomputes the conv and writes
- *     y = act( round_dtype(conv) * scale + shift + residual ),  residual optionally round_dtype(r * rscale + rshift)
- * plus the packed ReLU mask -- bit for bit what cnk_conv2d_fwd + cnk_bn_fwd_train store (the second pass reproduces the
- * accumulators), with 10 instead of 17 element transfers per pixel and channel of the narrow width.  A backward that needs
- * the conv output recomputes it (cnk_conv2d_fwd).  _supported: 1x1 / stride 1 / no padding, dense, on the 64-channel grid. */
-int cnk_conv2d_fwd_bn_apply_supported(const cnk_conv_desc* d);
-/* slices of the partials a y == NULL call of cnk_conv2d_fwd writes (it may differ from cnk_conv2d_fwd_bn_partial_slices, which
- * describes the storing call's kernel); 0 when the shape is not _supported */
-int64_t cnk_conv2d_fwd_stats_only_slices(const cnk_conv_desc* d);
-int cnk_conv2d_fwd_bn_apply(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* scale_shift,
-                            const void* residual, const float* residual_scale_shift, int relu, void* y,
-                            uint8_t* relu_mask, void* stream);
-
 /* nn.BatchNorm2d in training mode (basemodel.py:1008,1061), optionally fused with the ReLU that
  * follows it in conv2d_block (:1012) and with the residual add + F.relu of the ResNet blocks
  * (resnet.py:151-154,191-194):   y = act( (x-mean)*invstd*gamma + beta [+ residual] ).
@@ -245,20 +229,17 @@ int cnk_bn_bwd(const void* dy, const void* x, const void* y, const uint8_t* relu
  *   4. cnk_conv2d_dgrad_bnfold(g, x = the conv input, ...) -> dx, with the same optional gradient addend (+ packed mask) and
  *      fused BN backward of the layer that produced x as cnk_conv2d_dgrad;  cnk_conv2d_wgrad_bnfold(g, y = the conv output, x, ...) -> dw, which forms dy_conv
  *      while staging its tiles, bit for bit the tensor cnk_bn_bwd would have written (workspace as cnk_conv2d_wgrad).
- * mode (prepare / image_bytes / dgrad_bnfold): 0 = the second K segment is the conv INPUT (K = Cout + Cin, image
- * [A W ; -W^T diag(E) W]: for convs that widen, Cout > Cin); 1 = it is the conv OUTPUT y, the BN input (K = 2 Cout, image
- * [A W ; -diag(E) W]: for convs that narrow, e.g. a bottleneck's first block 4f -> f) -- pass that tensor as `x`.
- * cnk_conv2d_bnfold_supported: bf16, 1x1, no padding, any stride (a strided conv's data gradient folds in the stride-parity
- * class that holds its tap), dense, both channel counts multiples of 64. */
+ * cnk_conv2d_bnfold_supported: bf16, 1x1, stride 1, no padding, dense, both channel counts multiples of 64.  (Round 4 also had a
+ * second form for convs that narrow -- the BN input as second K segment -- and the fold of strided 1x1 convs; both measured
+ * slower / neutral in the training step, DESIGN.md 7b, and were removed in round 5.) */
 int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d);
-size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d, int mode);
+size_t cnk_conv2d_bnfold_image_bytes(const cnk_conv_desc* d);
 int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int accumulate,
                     float* coef, int64_t M, int32_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean,
-                              const float* save_invstd, const float* coef, int mode, void* w_fold, float* bias_fold,
-                              void* stream);
-int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, int mode, const void* w_fold,
+                              const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream);
+int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold,
                             const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask,
                             const cnk_bn_bwd_fuse* bn, void* stream);
 int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean,

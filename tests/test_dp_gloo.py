@@ -105,3 +105,40 @@ def test_bucket_layout_covers_arena_once():
     assert red._pending == before
     red.finish_step()
     red.remove()
+
+
+def _collective_build_worker(rank, world, port, out):
+    """GraphedTrainStep.build_collective on two ranks: a capture refused on ONE rank makes EVERY rank train eagerly (no rank
+    is left replaying collectives its peer issues in another order); when both succeed both keep their graph."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import warnings
+    from convnets_amd import graph
+    results = []
+    for fail_on in (1, None):
+        def fake_init(self, model, batch, **kw):
+            if fail_on is not None and dist.get_rank() == fail_on:
+                raise RuntimeError('capture refused (test)')
+            self.model = model
+        orig = graph.GraphedTrainStep.__init__
+        graph.GraphedTrainStep.__init__ = fake_init
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter('always')
+                step = graph.GraphedTrainStep.build_collective('model', (torch.zeros(1), torch.zeros(1)))
+            results.append((step is not None, len(w)))
+        finally:
+            graph.GraphedTrainStep.__init__ = orig
+    dist.barrier()
+    torch.save(results, out % rank)
+    dist.destroy_process_group()
+
+
+def test_collective_graph_construction_agrees_across_ranks(tmp_path):
+    out = str(tmp_path / 'c%d.pt')
+    mp.start_processes(_collective_build_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method='spawn')
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert r0[0] == (False, 1) and r1[0] == (False, 1), 'rank 1 refused: both ranks must drop the graph (and say so)'
+    assert r0[1] == (True, 0) and r1[1] == (True, 0)

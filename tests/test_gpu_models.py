@@ -288,8 +288,15 @@ def test_fullsize_resnet50_step_properties():
     x = torch.randn(256, 3, 224, 224, generator=gen, device='cuda')
     y = torch.randint(0, 1000, (256,), generator=gen, device='cuda')
     before = model.optimizer.flat_p.clone()
+    from convnets_amd import ops
+    ops.FOLD_COUNTS['folded'] = 0
+    ops.FUSE_COUNTS.update(bn_bwd_fused=0, bn_bwd_unfused=0)
     loss1, correct = model.train_batch((x, y))
     torch.cuda.synchronize()
+    # the path bench.py times: the BN backward of the 13 last-block convs at 56x56 / 28x28 / 14x14 and of the stride-1 projection
+    # shortcut is folded into the conv's backward (csrc/bnfold.hip), and the consumers' epilogues carried the reductions
+    assert ops.FOLD_COUNTS['folded'] >= 14, ops.FOLD_COUNTS
+    assert ops.FUSE_COUNTS['bn_bwd_fused'] >= 40, ops.FUSE_COUNTS
     assert abs(float(loss1) - 256 * math.log(1000)) < 0.06 * 256 * math.log(1000)   # dropout 0.5 on the head inflates it a few %
     assert 0 <= int(correct) <= 256
     gflat = model.optimizer.flat_g

@@ -130,10 +130,7 @@ FOLD_CASES = {
     'ring2_n64_256_1024_14': (64, 256, 1024, 14, 14, '1', CNT_G1_2),         # the rule's choice at this size: 256 x 128 tiles
     'ring4_n64_256_1024_14': (64, 256, 1024, 14, 14, '4', CNT_G1_4),         # 256 x 256 tiles forced
     'ring2_n40_512_2048_7': (40, 512, 2048, 7, 7, '2', CNT_G1_2),            # 7x7, K = 2048 + 512, M = 1960 (ragged)
-    'strided_n8_128_256_14': (8, 128, 256, 14, 14, '1', CNT_GATHER),         # stride 2 (a projection shortcut): 4 parity classes
-    'strided_n6_64_128_9x13': (6, 64, 128, 9, 13, '1', CNT_GATHER),          # stride 2 on an odd image: ragged classes
 }
-FOLD_STRIDE = {'strided_n8_128_256_14': 2, 'strided_n6_64_128_9x13': 2}
 
 
 @pytest.mark.parametrize('case', sorted(FOLD_CASES))
@@ -141,7 +138,7 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
     from convnets_amd import ops
     _lib, lib, cnt = _lib_and_counter()
     N, Cin, Cout, H, W, g1, counter = FOLD_CASES[case]
-    fc = FoldCase(N, Cin, Cout, H, W, seed=4 + len(case), stride=FOLD_STRIDE.get(case, 1))
+    fc = FoldCase(N, Cin, Cout, H, W, seed=4 + len(case))
     d, dev = fc.desc, 'cuda'
     assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)) == 1
     coef, dgamma, dbeta = fc.coef(lib, _lib)
@@ -173,9 +170,9 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
     assert torch.equal(dw_acc, dw_one + 1.0)
 
     # ---- data gradient
-    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device=dev)
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
     bias_fold = torch.empty(Cin, device=dev)
-    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), 0, P(w_fold),
+    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), P(w_fold),
                                              P(bias_fold), _stream()))
     # the image against its definition (fp64): [A W ; -W^T diag(E) W], bias
     C = Cout
@@ -194,18 +191,14 @@ def test_bnfold_dgrad_wgrad_vs_fp64_and_unfolded(case):
     with _lib.switches(CNK_GEMM1X1=g1):
         c0 = cnt(counter)
         da_f = torch.empty_like(fc.a, memory_format=CL)
-        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), 0, P(w_fold), P(bias_fold), P(da_f), None, None, None, _stream()))
-        assert cnt(counter) == c0 + (1 if fc.stride == 1 else fc.stride ** 2), 'the folded data gradient did not run on the expected kernel'
+        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da_f), None, None, None, _stream()))
+        assert cnt(counter) == c0 + 1, 'the folded data gradient did not run on the expected kernel'
         da_u = torch.empty_like(fc.a, memory_format=CL)
         _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da_u), None, None, None, None, 0, _stream()))
     torch.cuda.synchronize()
     ref = da64.numpy()
     e_f = rel_l2(da_f.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), ref)
     e_u = rel_l2(da_u.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), ref)
-    if fc.stride > 1:                                # pixels the conv never read: exact zeros
-        zmask = torch.ones(fc.N, fc.H, fc.W, dtype=torch.bool)
-        zmask[:, ::fc.stride, ::fc.stride] = False
-        assert torch.all(da_f.permute(0, 2, 3, 1).cpu()[zmask] == 0)
     print('%s: folded %.2e unfolded %.2e (vs fp64)' % (case, e_f, e_u))
     assert e_f < 4e-3 and e_u < 4e-3
 
@@ -220,9 +213,9 @@ def test_bnfold_dgrad_with_fused_bn_backward_in_front(case):
     d, dev = fc.desc, 'cuda'
     coef, _, _ = fc.coef(lib, _lib)
     dxc, _, _ = fc.unfolded_dxconv(lib, _lib)
-    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), 0), dtype=torch.uint8, device=dev)
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
     bias_fold = torch.empty(Cin, device=dev)
-    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), 0, P(w_fold),
+    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), P(w_fold),
                                              P(bias_fold), _stream()))
     # the BN layer in front: a = relu(bn(u)); mask re-derived from u (no residual)
     gen = torch.Generator().manual_seed(5)
@@ -241,7 +234,7 @@ def test_bnfold_dgrad_with_fused_bn_backward_in_front(case):
                                   part.data_ptr(), 1)
             da = torch.empty_like(fc.a, memory_format=CL)
             if folded:
-                _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), 0, P(w_fold), P(bias_fold), P(da), None, None,
+                _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da), None, None,
                                                        ctypes.byref(fuse), _stream()))
             else:
                 _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da), None, None, ctypes.byref(fuse), None, 0,
@@ -305,11 +298,11 @@ def test_bottleneck_resnet_step_with_and_without_the_fold():
     den = sum(float((g0[k] ** 2).sum()) for k in g0)
     err = math.sqrt(num / den)
     print('fold on vs off: whole-gradient L2-rel %.3e' % err)
-    assert err < 3e-2
+    assert err < 1e-2                                # measured 3.3e-3 (round 4): three times that
     worst = max((math.sqrt(float(((g1[k] - g0[k]) ** 2).sum()) / max(float((g0[k] ** 2).sum()), 1e-30)), k) for k in g0
                 if float((g0[k] ** 2).sum()) > 1e-12)
     print('worst tensor', worst)
-    assert worst[0] < 1.5e-1
+    assert worst[0] < 5e-2
 
 
 def test_graphed_step_captured_at_zero_learning_rate():
@@ -430,56 +423,8 @@ def test_fold_of_a_projection_shortcut_bn_with_gradient_handover():
     assert math.sqrt(num / den) < 3e-2
 
 
-# narrowing convs (a bottleneck's first block, 4f -> f): the second K segment is the BN INPUT y (mode 1), K = 2 Cout
-FOLD_Y_CASES = {
-    'y_gather_n8_256_64_14': (8, 256, 64, 14, 14, '1', CNT_GATHER),          # Nout = 256, K = 64 + 64
-    'y_gather_n16_128_128_9x13': (16, 128, 128, 9, 13, '1', CNT_GATHER),     # Cout == Cin, odd image
-    'y_gather128_n96_512_128_28': (96, 512, 128, 28, 28, '0', CNT_GATHER),   # 588 x 4 tiles of 128 x 128, K = 128 + 128
-    'y_ring_n64_1024_512_14': (64, 1024, 512, 14, 14, '2', CNT_G1_2),        # ring GEMM, K = 512 + 512, Nout = 1024
-}
-
-
-@pytest.mark.parametrize('case', sorted(FOLD_Y_CASES))
-def test_bnfold_mode1_second_segment_is_the_bn_input(case):
-    _lib, lib, cnt = _lib_and_counter()
-    N, Cin, Cout, H, W, g1, counter = FOLD_Y_CASES[case]
-    fc = FoldCase(N, Cin, Cout, H, W, seed=9 + len(case))
-    d, dev = fc.desc, 'cuda'
-    coef, _, _ = fc.coef(lib, _lib)
-    dxc, _, _ = fc.unfolded_dxconv(lib, _lib)
-    _, da64 = fc.fp64_da(coef)
-    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), 1), dtype=torch.uint8, device=dev)
-    assert w_fold.numel() == Cin * 2 * Cout * 2
-    bias_fold = torch.empty(Cin, device=dev)
-    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), 1, P(w_fold),
-                                             P(bias_fold), _stream()))
-    C = Cout
-    c64 = coef.double().cpu()
-    A, B1, B2 = c64[:C], c64[C:2 * C], c64[2 * C:]
-    m64, i64 = fc.mean.double().cpu(), fc.invstd.double().cpu()
-    w64 = fc.w.double().cpu().reshape(C, Cin)
-    E = A * i64 * B2
-    img = w_fold.view(torch.bfloat16).reshape(Cin, 2 * C).double().cpu()
-    assert rel_l2(img[:, :C].numpy(), (w64 * A[:, None]).t().numpy()) < 3e-3
-    assert rel_l2(img[:, C:].numpy(), (-(w64 * E[:, None])).t().numpy()) < 3e-3
-    assert rel_l2(bias_fold.double().cpu().numpy(), (w64 * (E * m64 - A * B1)[:, None]).sum(0).numpy()) < 1e-5
-    with _lib.switches(CNK_GEMM1X1=g1):
-        c0 = cnt(counter)
-        da_f = torch.empty_like(fc.a, memory_format=CL)
-        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.y), 1, P(w_fold), P(bias_fold), P(da_f), None, None, None,
-                                               _stream()))
-        assert cnt(counter) == c0 + 1
-        da_u = torch.empty_like(fc.a, memory_format=CL)
-        _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(fc.w_dgrad), P(da_u), None, None, None, None, 0, _stream()))
-    torch.cuda.synchronize()
-    e_f = rel_l2(da_f.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), da64.numpy())
-    e_u = rel_l2(da_u.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), da64.numpy())
-    print('%s: folded %.2e unfolded %.2e (vs fp64)' % (case, e_f, e_u))
-    assert e_f < 4e-3 and e_u < 4e-3
-
-
 def test_bnfold_random_geometries():
-    """Twelve random (N, H, W, Cin, Cout, stride, form) draws, small and ragged (M below one tile, odd images, one K step): the
+    """Twelve random (N, H, W, Cin, Cout) draws, small and ragged (M below one tile, odd images, one K step): the
     folded data gradient against the fp64 restatement, the folded weight gradient bit-identical to bn_bwd + wgrad."""
     _lib, lib, cnt = _lib_and_counter()
     rng = np.random.RandomState(4)
@@ -489,19 +434,17 @@ def test_bnfold_random_geometries():
         N = int(rng.randint(1, 9))
         H, W = int(rng.randint(3, 20)), int(rng.randint(3, 20))
         Cin, Cout = 64 * int(rng.randint(1, 5)), 64 * int(rng.randint(1, 9))
-        stride = int(rng.choice([1, 1, 2]))
-        mode = int(rng.randint(0, 2)) if stride == 1 else 0
-        fc = FoldCase(N, Cin, Cout, H, W, seed=100 + it, stride=stride)
+        fc = FoldCase(N, Cin, Cout, H, W, seed=100 + it)
         d = fc.desc
         coef, _, _ = fc.coef(lib, _lib)
         dxc, _, _ = fc.unfolded_dxconv(lib, _lib)
         _, da64 = fc.fp64_da(coef)
-        w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d), mode), dtype=torch.uint8, device=dev)
+        w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
         bias_fold = torch.empty(Cin, device=dev)
-        _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), mode, P(w_fold),
+        _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(fc.w), P(fc.w_dgrad), P(fc.mean), P(fc.invstd), P(coef), P(w_fold),
                                                  P(bias_fold), _stream()))
         da = torch.empty_like(fc.a, memory_format=CL)
-        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.y if mode else fc.a), mode, P(w_fold), P(bias_fold), P(da), None,
+        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(fc.g), P(fc.a), P(w_fold), P(bias_fold), P(da), None,
                                                None, None, _stream()))
         nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), _lib.PASS_WGRAD)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
@@ -512,188 +455,6 @@ def test_bnfold_random_geometries():
         torch.cuda.synchronize()
         e = rel_l2(da.permute(0, 2, 3, 1).reshape(-1, Cin).double().cpu().numpy(), da64.numpy())
         worst = max(worst, e)
-        assert e < 5e-3, (it, N, H, W, Cin, Cout, stride, mode, e)
-        assert torch.equal(dw_u, dw_f), (it, N, H, W, Cin, Cout, stride, mode)
+        assert e < 5e-3, (it, N, H, W, Cin, Cout, e)
+        assert torch.equal(dw_u, dw_f), (it, N, H, W, Cin, Cout)
     print('worst folded data gradient vs fp64 over 12 draws: %.2e' % worst)
-
-
-@pytest.mark.parametrize('case', ['n8_64_256_14', 'n96_128_512_28', 'n5_64_128_9x13_raff', 'n4_64_64_14_f32', 'n8_64_256_14_nores'])
-def test_conv_bn_apply_without_storing_the_conv_output(case):
-    """conv(1x1) -> BN -> += residual -> ReLU as two conv passes (statistics only; conv + BN apply in the epilogue,
-    cnk_conv2d_fwd_bn_apply) against the stored-output sequence cnk_conv2d_fwd + cnk_bn_fwd_train: output, packed mask, saved
-    statistics and running statistics bit for bit (reference: /root/reference/src/resnet.py:172-176,191-194)."""
-    from convnets_amd import ops
-    _lib, lib, cnt = _lib_and_counter()
-    cfg = {'n8_64_256_14': (8, 64, 256, 14, 14, torch.bfloat16, True, False),
-           'n96_128_512_28': (96, 128, 512, 28, 28, torch.bfloat16, True, False),      # 128-wide tiles
-           'n5_64_128_9x13_raff': (5, 64, 128, 9, 13, torch.bfloat16, True, True),     # residual with its own deferred BN
-           'n4_64_64_14_f32': (4, 64, 64, 14, 14, torch.float32, True, False),
-           'n8_64_256_14_nores': (8, 64, 256, 14, 14, torch.bfloat16, False, False)}[case]
-    N, Cin, Cout, H, W, dt, has_res, raff = cfg
-    dev = 'cuda'
-    gen = torch.Generator().manual_seed(len(case))
-    code = _lib.CNK_BF16 if dt == torch.bfloat16 else _lib.CNK_F32
-    M = N * H * W
-    x = torch.relu(torch.randn(N, Cin, H, W, generator=gen)).to(dt).to(dev).contiguous(memory_format=CL)
-    w = (torch.randn(Cout, Cin, 1, 1, generator=gen) / math.sqrt(Cin)).to(dev)
-    res = torch.randn(N, Cout, H, W, generator=gen).to(dt).to(dev).contiguous(memory_format=CL) if has_res else None
-    rcoef = torch.cat([0.5 + torch.rand(Cout, generator=gen), 0.1 * torch.randn(Cout, generator=gen)]).to(dev) if raff else None
-    gamma, beta = (0.5 + torch.rand(Cout, generator=gen)).to(dev), (0.1 * torch.randn(Cout, generator=gen)).to(dev)
-    d = ops.make_desc(x.shape, w.shape, (1, 1), (0, 0), code)
-    assert lib.cnk_conv2d_fwd_bn_apply_supported(ctypes.byref(d)) == 1
-    w_fwd = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_FWD), dtype=torch.uint8, device=dev)
-    _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(w), P(w_fwd), None, _stream()))
-    nws = lib.cnk_bn_workspace_bytes(M, Cout)
-    nmask = lib.cnk_bn_mask_bytes(M, Cout, code)
-
-    def bn_state():
-        return dict(rm=torch.zeros(Cout, device=dev), rv=torch.ones(Cout, device=dev), sm=torch.empty(Cout, device=dev),
-                    si=torch.empty(Cout, device=dev), ws=torch.empty(nws, dtype=torch.uint8, device=dev),
-                    mask=torch.zeros(nmask, dtype=torch.uint8, device=dev))
-    # ---- stored-output sequence
-    a = bn_state()
-    with _lib.switches(CNK_GEMM1X1='0'):
-        nsl = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d))
-        part_a = torch.zeros(nsl, Cout, 3, device=dev)
-        y3 = torch.empty(N, Cout, H, W, dtype=dt, device=dev).contiguous(memory_format=CL)
-        _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(x), P(w_fwd), None, P(y3), P(part_a), None, 0, _stream()))
-    ya = torch.empty_like(y3, memory_format=CL)
-    if raff:
-        _lib.check(lib.cnk_bn_fwd_train_res_affine(P(y3), P(gamma), P(beta), P(res), P(rcoef), P(ya), P(a['mask']), P(a['rm']), P(a['rv']),
-                                                   P(a['sm']), P(a['si']), P(part_a), nsl, M, Cout, 1e-5, 0.1, 1, code, P(a['ws']), nws, _stream()))
-    else:
-        _lib.check(lib.cnk_bn_fwd_train(P(y3), P(gamma), P(beta), P(res), P(ya), P(a['mask']) if has_res else None, P(a['rm']), P(a['rv']),
-                                        P(a['sm']), P(a['si']), P(part_a), nsl, M, Cout, 1e-5, 0.1, 1, code, P(a['ws']), nws, _stream()))
-    # ---- two conv passes, the conv output never stored
-    b = bn_state()
-    nsl_b = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d))
-    part_b = torch.zeros(nsl_b, Cout, 3, device=dev)
-    _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(x), P(w_fwd), None, None, P(part_b), None, 0, _stream()))
-    _lib.check(lib.cnk_bn_fwd_train(P(x), P(gamma), P(beta), None, None, None, P(b['rm']), P(b['rv']), P(b['sm']), P(b['si']), P(part_b), nsl_b,
-                                    M, Cout, 1e-5, 0.1, 1, code, P(b['ws']), nws, _stream()))
-    coef = b['ws'][:8 * Cout].view(torch.float32).clone()
-    yb = torch.empty_like(y3, memory_format=CL)
-    _lib.check(lib.cnk_conv2d_fwd_bn_apply(ctypes.byref(d), P(x), P(w_fwd), P(coef), P(res), P(rcoef), 1, P(yb), P(b['mask']) if has_res else None,
-                                           _stream()))
-    torch.cuda.synchronize()
-    assert torch.equal(a['sm'], b['sm']) and torch.equal(a['si'], b['si']), 'saved statistics differ'
-    assert torch.equal(a['rm'], b['rm']) and torch.equal(a['rv'], b['rv'])
-    assert torch.equal(ya, yb), 'conv + BN apply in one launch differs from the stored-output sequence'
-    if has_res:
-        assert torch.equal(a['mask'], b['mask'])
-
-
-def _lazy_model(kind=26, size=64, bs=32):
-    import convnets_amd as ca
-    from oracle import torch_ref as tr
-    torch.manual_seed(33)
-    s = ca.Settings(kind=kind, input_size=(3, size, size), num_classes=10, batch_size=bs, dropout_rate=0, mixed_precision=True,
-                    device='cuda:0')
-    m = ca.ResNet(s)
-    tr.damp_residual_branches(m, 0.1)
-    m = m.cuda()
-    m.init_optimizer()
-    m.train()
-    return m
-
-
-@pytest.mark.parametrize('fold', [True, False])
-def test_conv_output_left_out_of_the_forward_is_bit_identical(fold):
-    """ops.LazyConvOut: a bottleneck's last conv output is never stored in the forward (two conv passes) and recomputed on the
-    weight-gradient stream for the backward.  Same kernels, same arithmetic: loss, every gradient and the parameters after
-    two steps carry the same bits as the stored path -- with the folded BN backward behind it and without."""
-    from convnets_amd import ops
-    from oracle import torch_ref as tr
-    saved = (ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS, ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS)
-    ops.LAZY_MIN_ELEMS, ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS = 0, fold, 0
-    try:
-        res = {}
-        for lazy in (True, False):
-            ops.LAZY_CONV_OUT = lazy
-            ops.LAZY_COUNTS.update(left_out=0, recomputed=0)
-            model = _lazy_model()
-            x, y = tr.synthetic_batch(32, (3, 64, 64), 10, seed=33)
-            losses = []
-            for _ in range(2):
-                loss, _c = model.train_batch((x, y))
-                losses.append(float(loss))
-            torch.cuda.synchronize()
-            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-            params = {n: p.detach().clone() for n, p in model.named_parameters()}
-            stats = {n: b.detach().clone() for n, b in model.named_buffers()}
-            res[lazy] = (losses, grads, params, stats, dict(ops.LAZY_COUNTS))
-    finally:
-        ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS, ops.BN_FOLD, ops.BN_FOLD_MIN_ELEMS = saved
-    (l1, g1, p1, s1, c1), (l0, g0, p0, s0, c0) = res[True], res[False]
-    assert c0 == {'left_out': 0, 'recomputed': 0}
-    assert c1['left_out'] == 16 and c1['recomputed'] == 16, c1            # 8 bottlenecks x 2 steps
-    assert l1 == l0
-    for k in g0:
-        assert torch.equal(g1[k], g0[k]), 'gradient of %s differs' % k
-    for k in p0:
-        assert torch.equal(p1[k], p0[k]), 'parameter %s differs' % k
-    for k in s0:
-        assert torch.equal(s1[k], s0[k]), 'buffer %s differs' % k
-
-
-def test_conv_output_left_out_in_a_captured_step():
-    """The same inside a hipGraph: the recomputation is captured on the side stream; three replays equal three eager steps of
-    a twin model that stores the conv outputs."""
-    from convnets_amd import ops
-    from convnets_amd.graph import GraphedTrainStep
-    from oracle import torch_ref as tr
-    saved = (ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS)
-    ops.LAZY_MIN_ELEMS = 0
-    try:
-        x, y = tr.synthetic_batch(32, (3, 64, 64), 10, seed=33)
-        x, y = x.cuda(), y.cuda()
-        ops.LAZY_CONV_OUT = False
-        eager = _lazy_model()
-        for _ in range(3):
-            le, _c = eager.train_batch((x, y))
-        ops.LAZY_CONV_OUT = True
-        ops.LAZY_COUNTS.update(left_out=0, recomputed=0)
-        graphed = _lazy_model()
-        step = GraphedTrainStep(graphed, (x, y))
-        assert ops.LAZY_COUNTS['left_out'] >= 8 and ops.LAZY_COUNTS['recomputed'] == ops.LAZY_COUNTS['left_out']
-        for _ in range(3):
-            lg, _c = step.replay()
-        torch.cuda.synchronize()
-    finally:
-        ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS = saved
-    assert float(lg) == float(le)
-    for (n, a), (_, b) in zip(eager.named_parameters(), graphed.named_parameters()):
-        assert torch.equal(a, b), n
-
-
-def test_conv_output_left_out_without_a_backward_and_twice():
-    """A training-mode forward that is never followed by a backward leaves nothing behind (weak references); two forwards
-    before the first backward (gradient accumulation) recompute both graphs' tensors; a second backward over a retained
-    graph is refused loudly instead of reading freed memory."""
-    import gc
-    from convnets_amd import ops
-    saved = (ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS)
-    ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS = True, 0
-    try:
-        model = _lazy_model()
-        x = torch.randn(32, 3, 64, 64, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
-        out = model(x)
-        assert len(ops._lazy_pending) == 8
-        del out
-        gc.collect()
-        assert all(w() is None for w in ops._lazy_pending)
-        ops.LAZY_COUNTS.update(left_out=0, recomputed=0)
-        o1 = model(x).float().sum()
-        o2 = model(x * 0.5).float().sum()
-        o1.backward(retain_graph=True)
-        assert ops.LAZY_COUNTS['recomputed'] == 16 and not ops._lazy_pending
-        o2.backward()
-        ops.join_side_streams()
-        torch.cuda.synchronize()
-        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
-        with pytest.raises(RuntimeError, match='LazyConvOut'):
-            o1.backward()
-    finally:
-        ops.LAZY_CONV_OUT, ops.LAZY_MIN_ELEMS = saved
-        ops.join_side_streams()
-        torch.cuda.synchronize()

@@ -1,0 +1,404 @@
+"""GPU parity (-m gpu), round-5 additions.
+
+  * the folded BN backward (csrc/bnfold.hip; reference sites /root/reference/src/resnet.py:170-172, built by conv2d_block
+    /root/reference/src/basemodel.py:999-1015, BN at :1008) under the oracle AT THE SIZE AND LOAD THE BENCHMARK RUNS IT: batch
+    256, the three ResNet-50 shapes the fold takes, unforced dispatch with launch counters, a weight-gradient stream busy beside
+    it; folded weight gradient bit-identical to cnk_bn_bwd + cnk_conv2d_wgrad, folded data gradient (with the fused backward
+    reduction of the BN layer in front, as in the step) against fp64 on 4096 sampled rows and against the unfolded launch, five
+    repeats identical;
+  * a projection shortcut whose BN is in training mode in front of an eval-mode block (BN frozen per submodule);
+    a hook that replaces the gradient of a conv output whose BN backward was folded; recycling of the merge + finalise ticket
+    banks across many streams;
+  * the hipGraph-captured step under data parallelism as a collective construction (basemodel._graphed_batch,
+    GraphedTrainStep.build_collective): one rank on RCCL with the collective forced.
+"""
+import ctypes
+import math
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CNT_GATHER, CNT_G1_2, CNT_G1_4, CNT_BN_FUSED_FINAL, CNT_BN_FINAL_LAUNCH, CNT_BN_FINAL_NOBANK = 6, 7, 8, 10, 11, 13
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _lib_and_counter():
+    from convnets_amd import _lib
+    lib = _lib.load()
+    cnt = lib.cnk_debug_counter
+    cnt.restype, cnt.argtypes = ctypes.c_int64, [ctypes.c_int]
+    return _lib, lib, cnt
+
+
+def _st(stream=None):
+    return ctypes.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+
+# (N, Cin, Cout, H, kernel the unforced dispatch must take for the folded data gradient)
+BIG_FOLD = {
+    'c64_256_56': (256, 64, 256, 56, 'gather'),        # igemm_gather_kernel<64, CAT>: the step's largest launch, M = 802 816
+    'c128_512_28': (256, 128, 512, 28, 'gather'),      # igemm_gather_kernel<128, CAT>
+    'c256_1024_14': (256, 256, 1024, 14, 'ring'),      # gemm1x1_kernel, K = 1024 + 256
+}
+
+
+@pytest.mark.parametrize('case', sorted(BIG_FOLD))
+def test_fold_at_benchmark_size_under_load(case):
+    from convnets_amd import ops
+    _lib, lib, cnt = _lib_and_counter()
+    N, Cin, Cout, H, kernel = BIG_FOLD[case]
+    W = H
+    M = N * H * W
+    dev = 'cuda'
+    gen = torch.Generator(device=dev).manual_seed(1000 + H)
+    # conv input a = a ReLU output, NHWC bf16; the layer in front: a = relu(bn(u)) is NOT enforced -- u is an independent tensor
+    # whose re-derived mask the fused epilogue applies to the data gradient (any mask is a valid test of that epilogue)
+    a = torch.randn(N, H, W, Cin, generator=gen, device=dev).relu_().bfloat16().permute(0, 3, 1, 2)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen, device=dev) / math.sqrt(Cin)
+    d = ops.make_desc(a.shape, w.shape, (1, 1), (0, 0), _lib.CNK_BF16)
+    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)) == 1
+    w_fwd = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_FWD), dtype=torch.uint8, device=dev)
+    w_dgrad = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_DGRAD), dtype=torch.uint8, device=dev)
+    _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(w), P(w_fwd), P(w_dgrad), _st()))
+    y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=dev, memory_format=CL)
+    _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(a), P(w_fwd), None, P(y), None, None, 0, _st()))
+    y2 = y.permute(0, 2, 3, 1).reshape(M, Cout)
+    mean64 = y2.double().mean(0)
+    var64 = ((y2.double() - mean64) ** 2).mean(0)
+    invstd64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    mean, invstd = mean64.float(), invstd64.float()
+    gamma = 0.5 + torch.rand(Cout, generator=gen, device=dev)
+    # masked gradient w.r.t. the BN output, with a per-channel offset (B1 != 0) and a component along xhat (B2 != 0)
+    g = torch.randn(M, Cout, generator=gen, device=dev) * 0.5 + 0.1 * torch.randn(Cout, generator=gen, device=dev)
+    g += 0.2 * ((y2.float() - mean) * invstd) * torch.randn(Cout, generator=gen, device=dev)
+    g *= torch.rand(M, Cout, generator=gen, device=dev) > 0.4
+    g = g.bfloat16().reshape(N, H, W, Cout).permute(0, 3, 1, 2)
+    g2 = g.permute(0, 2, 3, 1).reshape(M, Cout)
+    S = g2.double().sum(0)
+    Q = (g2.double() * (y2.double() - mean.double())).sum(0) * invstd.double()
+    partial = torch.stack([S, Q], 1).reshape(1, Cout, 2).float().contiguous()
+    del S, Q
+    nbn = lib.cnk_bn_workspace_bytes(M, Cout)
+    bws = torch.empty(nbn, dtype=torch.uint8, device=dev)
+    coef = torch.empty(3 * Cout, device=dev)
+    dgamma, dbeta = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+    _lib.check(lib.cnk_bn_bwd_coef(None, None, P(partial), 1, P(gamma), P(mean), P(invstd), P(dgamma), P(dbeta), 0, P(coef), M, Cout,
+                                   _lib.CNK_BF16, P(bws), nbn, _st()))
+    # the unfolded pair's intermediate: the tensor the fold never writes
+    dxc = torch.empty_like(g, memory_format=CL)
+    dg_u, db_u = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+    beta0 = torch.zeros(Cout, device=dev)
+    _lib.check(lib.cnk_bn_bwd(P(g), P(y), None, None, P(gamma), P(beta0), P(mean), P(invstd), P(dxc), None, P(dg_u), P(db_u), 0,
+                              P(partial), 1, M, Cout, 0, _lib.CNK_BF16, P(bws), nbn, _st()))
+    assert torch.equal(dgamma, dg_u) and torch.equal(dbeta, db_u)
+    # the BN(+ReLU) layer in front of the conv, for the fused reduction in the data gradient's epilogue
+    u = (torch.randn(N, H, W, Cin, generator=gen, device=dev) * 1.2 + 0.1).bfloat16().permute(0, 3, 1, 2)
+    mean2 = 0.1 * torch.randn(Cin, generator=gen, device=dev)
+    invstd2 = 0.8 + 0.4 * torch.rand(Cin, generator=gen, device=dev)
+    gamma2 = 0.5 + torch.rand(Cin, generator=gen, device=dev)
+    beta2 = 0.1 * torch.randn(Cin, generator=gen, device=dev)
+    slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(d))
+    assert slices > 0
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    bias_fold = torch.empty(Cin, device=dev)
+    nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), _lib.PASS_WGRAD)
+    budget = max(int(nws * 0.5) // 256 * 256, lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(d), 0))     # the step's share
+    ws_main = torch.empty(nws, dtype=torch.uint8, device=dev)
+
+    # ---- the load beside it: a stride-1 3x3 weight gradient (112 KiB of LDS per workgroup) in a loop on a second stream
+    side = torch.cuda.Stream()
+    la = torch.randn(128, 56, 56, 64, generator=gen, device=dev).bfloat16().permute(0, 3, 1, 2)
+    ldy = torch.randn(128, 56, 56, 64, generator=gen, device=dev).bfloat16().permute(0, 3, 1, 2)
+    ld = ops.make_desc(la.shape, (64, 64, 3, 3), (1, 1), (1, 1), _lib.CNK_BF16)
+    lws_n = lib.cnk_conv2d_workspace_bytes(ctypes.byref(ld), _lib.PASS_WGRAD)
+    lws = torch.empty(lws_n, dtype=torch.uint8, device=dev)
+    ldw = torch.zeros(64, 64, 3, 3, device=dev)
+    torch.cuda.synchronize()
+
+    def load(reps):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(reps):
+                _lib.check(lib.cnk_conv2d_wgrad(ctypes.byref(ld), P(ldy), P(la), P(ldw), None, 0, P(lws), lws_n, _st(side)))
+
+    def unfolded():
+        fuse_part = torch.zeros(slices, Cin, 2, device=dev)
+        fuse = _lib.BnBwdFuse(u.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None,
+                              fuse_part.data_ptr(), 1)
+        da = torch.empty_like(a, memory_format=CL)
+        _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dxc), P(w_dgrad), P(da), None, None, ctypes.byref(fuse), None, 0, _st()))
+        dw = torch.zeros(Cout, Cin, 1, 1, device=dev)
+        _lib.check(lib.cnk_conv2d_wgrad(ctypes.byref(d), P(dxc), P(a), P(dw), None, 0, P(ws_main), budget, _st()))
+        return da, dw, fuse_part
+
+    def folded():
+        fuse_part = torch.zeros(slices, Cin, 2, device=dev)
+        fuse = _lib.BnBwdFuse(u.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None,
+                              fuse_part.data_ptr(), 1)
+        _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(w), P(w_dgrad), P(mean), P(invstd), P(coef), P(w_fold), P(bias_fold),
+                                                 _st()))
+        da = torch.full_like(a, float('nan'), memory_format=CL)
+        g0, r0 = cnt(CNT_GATHER), cnt(CNT_G1_2) + cnt(CNT_G1_4)
+        _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(g), P(a), P(w_fold), P(bias_fold), P(da), None, None,
+                                               ctypes.byref(fuse), _st()))
+        ran = (cnt(CNT_GATHER) - g0, cnt(CNT_G1_2) + cnt(CNT_G1_4) - r0)
+        dw = torch.zeros(Cout, Cin, 1, 1, device=dev)
+        _lib.check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(d), P(g), P(y), P(a), P(mean), P(invstd), P(coef), P(dw), 0, P(ws_main),
+                                               budget, _st()))
+        return da, dw, fuse_part, ran
+
+    load(6)
+    da_u, dw_u, part_u = unfolded()
+    torch.cuda.synchronize()
+    results = []
+    for rep in range(5):
+        load(8)
+        results.append(folded())
+        torch.cuda.synchronize()
+    for da_f, dw_f, part_f, ran in results:
+        assert ran == ((1, 0) if kernel == 'gather' else (0, 1)), 'the unforced dispatch took another kernel: %s' % (ran,)
+        assert torch.equal(dw_f, dw_u), 'folded weight gradient differs from cnk_bn_bwd + cnk_conv2d_wgrad at the same split depth'
+        assert torch.equal(da_f, results[0][0]) and torch.equal(part_f, results[0][2]), 'repeats under load differ'
+    da_f, dw_f, part_f, _ = results[0]
+    assert bool(torch.isfinite(da_f.float()).all())
+
+    # ---- fp64 restatement on 4096 sampled rows: BN backward + data gradient + the mask of the layer in front
+    idx = torch.randperm(M, generator=torch.Generator().manual_seed(7))[:4096].to(dev)
+    c64 = coef.double()
+    A, B1, B2 = c64[:Cout], c64[Cout:2 * Cout], c64[2 * Cout:]
+    dxc64 = A * (g2[idx].double() - B1 - (y2[idx].double() - mean.double()) * invstd.double() * B2)
+    da64 = dxc64 @ w.double().reshape(Cout, Cin)
+    u2 = u.permute(0, 2, 3, 1).reshape(M, Cin)
+    sc = (gamma2 * invstd2).double()
+    keep = (u2[idx].double() * sc + (beta2.double() - mean2.double() * sc)) > 0
+    ref = (da64 * keep).cpu().numpy()
+    f_rows = da_f.permute(0, 2, 3, 1).reshape(M, Cin)[idx]
+    u_rows = da_u.permute(0, 2, 3, 1).reshape(M, Cin)[idx]
+    e_f, e_u = rel_l2(f_rows.double().cpu().numpy(), ref), rel_l2(u_rows.double().cpu().numpy(), ref)
+    e_fu = rel_l2(f_rows.double().cpu().numpy(), u_rows.double().cpu().numpy())
+    print('%s: folded %.2e unfolded %.2e (vs fp64, 4096 rows); folded vs unfolded %.2e' % (case, e_f, e_u, e_fu))
+    assert e_f < 4e-3 and e_u < 4e-3 and e_fu < 6e-3
+    assert bool((f_rows[~keep] == 0).all())
+    # the intermediate the unfolded pair wrote, on the same rows
+    assert rel_l2(dxc.permute(0, 2, 3, 1).reshape(M, Cout)[idx].double().cpu().numpy(), dxc64.cpu().numpy()) < 4e-3
+    # the fused reduction's partial sums are those of the tensor the launch wrote
+    f2 = da_f.permute(0, 2, 3, 1).reshape(M, Cin).double()
+    S2 = f2.sum(0)
+    Q2 = (f2 * (u2.double() - mean2.double())).sum(0) * invstd2.double()
+    pf = part_f.double().sum(0)
+    scale = max(float(S2.abs().max()), float(Q2.abs().max()), 1.0)
+    assert float((pf[:, 0] - S2).abs().max()) / scale < 5e-5
+    assert float((pf[:, 1] - Q2).abs().max()) / scale < 5e-5
+    # weight gradient against fp64 on a sample of output channels (the full product is 802 816 x 256 x 64 in fp64)
+    ch = torch.arange(0, Cout, max(Cout // 16, 1), device=dev)
+    dxc_all = A[ch] * (g2[:, ch].double() - B1[ch] - (y2[:, ch].double() - mean.double()[ch]) * invstd.double()[ch] * B2[ch])
+    dw64 = dxc_all.t() @ a.permute(0, 2, 3, 1).reshape(M, Cin).double()
+    assert rel_l2(dw_f.reshape(Cout, Cin)[ch].double().cpu().numpy(), dw64.cpu().numpy()) < 4e-3
+
+
+def test_mixed_train_and_eval_bn_inside_one_bottleneck():
+    """BN frozen per submodule, autograd mode on, nothing requiring a gradient (feature extraction with frozen
+    weights): the projection shortcut's BN used to defer its apply pass to the block's last BN whatever mode that layer was in,
+    and an eval-mode last BN then added the UN-normalised shortcut tensor.  Now the shortcut asks its consumer first
+    (ConvBlock.applies_deferred_residual): with the last block in eval mode it applies its own BN and the block's output
+    equals the stock computation; a residual that still carries a deferred apply pass is refused by an eval-mode layer."""
+    import torch.nn.functional as F
+    import convnets_amd as ca
+    torch.manual_seed(3)
+    s = ca.Settings(kind=26, input_size=(3, 32, 32), num_classes=10, batch_size=8, dropout_rate=0, mixed_precision=False, device='cuda:0')
+    model = ca.ResNet(s).cuda()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    block = model.features[2]                      # first bottleneck: projection shortcut
+    assert block.dim_synch is not None
+    x = torch.randn(8, 64, 8, 8, device='cuda').contiguous(memory_format=CL)
+    model.train()
+    assert torch.is_grad_enabled()
+    assert block.res_bottleneck[2].applies_deferred_residual()
+    ref_all_train = block(x).clone()
+    last_bn = block.res_bottleneck[2][1]
+    last_bn.eval()                                 # freeze the main branch's last BN only
+    assert not block.res_bottleneck[2].applies_deferred_residual()
+    out = block(x)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        sc = block.dim_synch
+        idn = F.conv2d(x, sc[0].weight)
+        mu, var = idn.mean((0, 2, 3)), idn.var((0, 2, 3), unbiased=False)
+        idn = (idn - mu[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + sc[1].eps) * sc[1].weight[None, :, None, None] \
+            + sc[1].bias[None, :, None, None]
+        h = block.res_bottleneck[1](block.res_bottleneck[0](x))
+        h = F.conv2d(h, block.res_bottleneck[2][0].weight)
+        h = F.batch_norm(h, last_bn.running_mean, last_bn.running_var, last_bn.weight, last_bn.bias, False, 0.0, last_bn.eps)
+        want = torch.relu(h + idn)
+    assert float((out - want).norm() / want.norm()) < 1e-5
+    assert float((out - ref_all_train).norm()) > 0              # (a different function from the all-training block)
+    # a deferred residual handed to an eval-mode layer is refused loudly
+    last_bn.train()
+    ident = block.dim_synch(x, defer_apply=True)
+    assert getattr(ident, '_cnk_defer', None) is not None
+    last_bn.eval()
+    with pytest.raises(RuntimeError, match='deferred'):
+        block.res_bottleneck[2](torch.randn(8, 64, 8, 8, device='cuda').contiguous(memory_format=CL), residual=ident, relu_after_add=True)
+    with pytest.raises(RuntimeError, match='deferred'):
+        last_bn(torch.randn(8, 256, 8, 8, device='cuda').contiguous(memory_format=CL), residual=ident)
+
+
+def test_replaced_gradient_of_a_folded_conv_output_is_refused():
+    """BatchNormActFn.backward folded (it skipped its apply pass and returned the gradient w.r.t. the BN OUTPUT as
+    the conv's incoming gradient); a tensor hook on the conv output then hands Conv2dFn.backward a different tensor.  The plain
+    backward on it would be silently wrong: it raises.  Without the hook the same graph runs."""
+    from convnets_amd import ops
+    prev = ops.BN_FOLD_MIN_ELEMS
+    ops.BN_FOLD_MIN_ELEMS = 0
+    try:
+        for hook in (False, True):
+            torch.manual_seed(0)
+            x = torch.randn(8, 64, 14, 14, device='cuda').bfloat16().contiguous(memory_format=CL).requires_grad_(True)
+            w = (torch.randn(256, 64, 1, 1, device='cuda') / 8).requires_grad_(True)
+            gamma, beta = torch.ones(256, device='cuda', requires_grad=True), torch.zeros(256, device='cuda', requires_grad=True)
+            rm, rv = torch.zeros(256, device='cuda'), torch.ones(256, device='cuda')
+            rec = ops.FoldRecord()
+            y, partial = ops.Conv2dFn.apply(x, w, None, (1, 1), (0, 0), ops.PackedWeights(), True, None, None, 1, 1, rec)
+            assert rec.ok
+            if hook:
+                y.register_hook(lambda gr: gr.clone())
+            out = ops.BatchNormActFn.apply(y, gamma, beta, None, rm, rv, 1e-5, 0.1, False, partial, None, None, rec)
+            loss = (out.float() * torch.randn_like(out, dtype=torch.float32)).sum()
+            ops.FOLD_COUNTS['folded'] = 0
+            if hook:
+                with pytest.raises(RuntimeError, match='FoldRecord'):
+                    loss.backward()
+            else:
+                loss.backward()
+                ops.join_side_streams()
+                torch.cuda.synchronize()
+                assert ops.FOLD_COUNTS['folded'] == 1 and bool(torch.isfinite(x.grad.float()).all()) and bool(torch.isfinite(w.grad).all())
+    finally:
+        ops.BN_FOLD_MIN_ELEMS = prev
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+
+
+def test_ticket_banks_are_recycled_across_many_streams():
+    """the merge + finalise launch keeps its last-block tickets in banks keyed by stream.  Once every bank was
+    claimed, each further stream used to fall back to the two-kernel path for the rest of the process; now the least recently
+    used bank of an idle (or destroyed) stream moves on.  100 raw HIP streams -- more than there are banks --, one long-list
+    BN forward each: every one takes the single launch, none the fallback, all results equal."""
+    _lib, lib, cnt = _lib_and_counter()
+    hip = ctypes.CDLL('libamdhip64.so')
+    hip.hipStreamCreate.argtypes, hip.hipStreamCreate.restype = [ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int
+    hip.hipStreamSynchronize.argtypes, hip.hipStreamSynchronize.restype = [ctypes.c_void_p], ctypes.c_int
+    hip.hipStreamDestroy.argtypes, hip.hipStreamDestroy.restype = [ctypes.c_void_p], ctypes.c_int
+    M, C, slices = 4096 * 64, 64, 2048
+    dev = 'cuda'
+    gen = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(M, C, generator=gen, device=dev).bfloat16()
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    # per-slice (n, mean, M2) partials of x, as a conv epilogue would leave them
+    xs = x.float().reshape(slices, M // slices, C)
+    mu = xs.mean(1)
+    part = torch.stack([torch.full_like(mu, M // slices), mu, ((xs - mu[:, None, :]) ** 2).sum(1)], 2).contiguous()
+    nws = lib.cnk_bn_workspace_bytes(M, C)
+    outs, handles = [], []
+    torch.cuda.synchronize()
+    f0, n0, l0 = cnt(CNT_BN_FUSED_FINAL), cnt(CNT_BN_FINAL_NOBANK), cnt(CNT_BN_FINAL_LAUNCH)
+    try:
+        for k in range(100):
+            h = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+            handles.append(h)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            sm, si = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            y = torch.empty_like(x)
+            _lib.check(lib.cnk_bn_fwd_train(P(x), P(gamma), P(beta), None, P(y), None, None, None, P(sm), P(si), P(part), slices, M, C,
+                                            1e-5, 0.1, 0, _lib.CNK_BF16, P(ws), nws, h))
+            assert hip.hipStreamSynchronize(h) == 0
+            if k % 3 == 0:                         # some streams are gone by the time their bank is wanted, some merely idle
+                assert hip.hipStreamDestroy(handles.pop()) == 0
+            if k < 3 or k > 96:
+                outs.append((sm, si, y))
+    finally:
+        for h in handles:
+            hip.hipStreamDestroy(h)
+    assert cnt(CNT_BN_FUSED_FINAL) - f0 == 100, 'every stream must get a ticket bank'
+    assert cnt(CNT_BN_FINAL_NOBANK) - n0 == 0 and cnt(CNT_BN_FINAL_LAUNCH) - l0 == 0
+    for sm, si, y in outs[1:]:
+        assert torch.equal(sm, outs[0][0]) and torch.equal(si, outs[0][1]) and torch.equal(y, outs[0][2])
+    assert float((outs[0][0] - x.float().mean(0)).abs().max()) < 1e-4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Loader(list):
+    """An iterable of batches with the `.dataset` the reference's train_model reads the length of (basemodel.py:299)."""
+
+    def __init__(self, batches):
+        super().__init__(batches)
+        self.dataset = range(sum(len(b[1]) for b in batches))
+
+
+def _graph_dp_worker(rank, world, port, out):
+    """One rank on RCCL with the collective forced: train_model with Settings(hipgraph=True, hipgraph_dp=True) builds the graph
+    collectively at the first batch, replays it for batches of that shape and runs the eager step for the epoch's smaller last
+    batch (no second capture); an eager twin sees the same batches."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', CNK_DP_FORCE='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    sys.path.insert(0, ROOT)
+    import convnets_amd as ca
+    from convnets_amd import dp
+    from convnets_amd.graph import GraphedTrainStep
+    from oracle import torch_ref as tr
+    x, y = tr.synthetic_batch(40, (3, 32, 32), 10, seed=5)
+    batches = [(x[0:16], y[0:16]), (x[16:32], y[16:32]), (x[32:40], y[32:40])]        # the last batch of the epoch is smaller
+    res = {}
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(21)
+        s = ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, batch_size=16, dropout_rate=0, mixed_precision=True,
+                        learning_rate=1e-3, hipgraph=(mode == 'graph'), hipgraph_dp=True)
+        m = ca.ResNet(s).cuda()
+        m.init_optimizer()
+        red = dp.attach(m, bucket_bytes=256 << 10)
+        assert len(red.buckets) >= 2 and red.force
+        built = []
+        orig = GraphedTrainStep.build_collective.__func__
+        GraphedTrainStep.build_collective = classmethod(lambda cls, *a, **k: built.append(1) or orig(cls, *a, **k))
+        try:
+            epochs = [m.train_model(_Loader(batches)) for _ in range(2)]
+        finally:
+            GraphedTrainStep.build_collective = classmethod(orig)
+        torch.cuda.synchronize()
+        steps = m.__dict__.get('_graphed_steps', {})
+        res[mode] = dict(flat_p=m.optimizer.flat_p.cpu().clone(), epochs=epochs, built=len(built),
+                         replays=sum(st.replays for st in steps.values() if st is not None), graphs=len(steps))
+        red.remove()
+    torch.save(res, out % rank)
+    dist.destroy_process_group()
+
+
+def test_train_model_with_a_collectively_built_graph_under_dp(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'gdp%d.pt')
+    mp.start_processes(_graph_dp_worker, args=(1, _free_port(), out), nprocs=1, join=True, start_method='spawn')
+    r = torch.load(out % 0)
+    assert r['eager']['built'] == 0 and r['eager']['graphs'] == 0
+    assert r['graph']['built'] == 1 and r['graph']['graphs'] == 1, 'one collective construction, at the first batch'
+    assert r['graph']['replays'] == 4                                   # two full-size batches x two epochs; the small one ran eagerly
+    assert r['graph']['epochs'] == r['eager']['epochs']                 # (epoch loss, epoch accuracy)
+    assert torch.equal(r['graph']['flat_p'], r['eager']['flat_p'])

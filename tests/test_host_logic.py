@@ -60,17 +60,16 @@ def test_host_side_planning_queries_run_without_gpu():
     assert rc != 0 and b'kernel larger' in lib.cnk_last_error()
     with pytest.raises(_lib.CnkError):
         _lib.check(rc)
-    # round 4: which convs can take the folded BN backward, the image sizes of its two forms, the smallest weight-gradient workspace
+    # round 4: which convs can take the folded BN backward, the image size, the smallest weight-gradient workspace
     c3 = D(256, 56, 56, 64, 256, 1, 1, 1, 1, 0, 0, _lib.CNK_BF16)                  # a bottleneck's last conv
     assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(c3)) == 1
-    assert lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(c3), 0) == 64 * (256 + 64) * 2
-    assert lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(c3), 1) == 64 * (2 * 256) * 2
-    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(D(256, 56, 56, 256, 512, 1, 1, 2, 2, 0, 0, _lib.CNK_BF16))) == 1    # strided shortcut
+    assert lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(c3)) == 64 * (256 + 64) * 2
+    assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(D(256, 56, 56, 256, 512, 1, 1, 2, 2, 0, 0, _lib.CNK_BF16))) == 0    # stride 1 only (round 5)
     assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(D(256, 56, 56, 64, 256, 1, 1, 1, 1, 0, 0, _lib.CNK_F32))) == 0      # bf16 only
     assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)) == 0                                                        # 3x3
     assert lib.cnk_conv2d_bnfold_supported(ctypes.byref(D(8, 14, 14, 48, 96, 1, 1, 1, 1, 0, 0, _lib.CNK_BF16))) == 0        # off the 64 grid
     rc = lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
-                                       ctypes.c_void_p(16), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), None)
+                                       ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None)
     assert rc != 0 and b'cnk_conv2d_bnfold_supported' in lib.cnk_last_error()
     slab = 256 * 64 * 4
     assert lib.cnk_conv2d_wgrad_min_workspace_bytes(ctypes.byref(c3), 0) == slab
@@ -234,3 +233,66 @@ def test_committed_bench_line_keeps_the_contract():
     c = d['cpu_baseline']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
     assert abs(d['value'] - 256 * 1000.0 / d['ms_per_step']) / d['value'] < 1e-2     # value and ms_per_step describe the same run
+
+
+def test_graphed_batch_dispatch_under_data_parallelism():
+    """basemodel._graphed_batch (BASELINE config 5; the reference has one device, /root/reference/src/mngrdevice.py:18): under
+    data parallelism the graph is built ONCE, collectively, at the first training batch; batches of that shape replay it,
+    any other shape runs the eager step (same collectives as a replay) -- no rank can enter a second capture alone; without
+    Settings.hipgraph_dp a multi-rank model trains eagerly."""
+    import convnets_amd as ca
+    from convnets_amd import graph
+    from convnets_amd.basemodel import MultiClassBaseModel
+
+    class Red:
+        def __init__(self, world, force=False):
+            self.world, self.force, self.group = world, force, 'grp'
+
+    class FakeStep:
+        def __init__(self):
+            self.replays = 0
+
+        def replay(self, batch):
+            self.replays += 1
+            return 'replay', batch[0].shape[0]
+
+    class M(MultiClassBaseModel):
+        def train_batch(self, batch):
+            return 'eager', batch[0].shape[0]
+
+    built = []
+    orig = graph.GraphedTrainStep.build_collective
+
+    def fake_build(model, batch, group=None, **kw):
+        built.append((tuple(batch[0].shape), group))
+        return FakeStep()
+    graph.GraphedTrainStep.build_collective = staticmethod(fake_build)
+    try:
+        b16 = (torch.zeros(16, 3, 8, 8), torch.zeros(16, dtype=torch.int64))
+        b8 = (torch.zeros(8, 3, 8, 8), torch.zeros(8, dtype=torch.int64))
+        s = ca.Settings(kind=0, input_size=(3, 8, 8), num_classes=10, device='cpu', hipgraph=True, hipgraph_dp=True)
+        m = M(s)
+        m.grad_reducer = Red(world=2)
+        assert m._graphed_batch(b16) == ('replay', 16) and built == [((16, 3, 8, 8), 'grp')]
+        assert m._graphed_batch(b8) == ('eager', 8)                 # another shape: eager, no second construction
+        assert m._graphed_batch(b16) == ('replay', 16) and len(built) == 1
+        # a refused construction (None on every rank): eager from then on, never retried
+        graph.GraphedTrainStep.build_collective = staticmethod(lambda *a, **k: built.append('refused') or None)
+        m2 = M(s)
+        m2.grad_reducer = Red(world=2)
+        assert m2._graphed_batch(b16) == ('eager', 16) and m2._graphed_batch(b16) == ('eager', 16)
+        assert built.count('refused') == 1
+        # the flag off: multi-rank models train eagerly and never construct
+        s_off = ca.Settings(kind=0, input_size=(3, 8, 8), num_classes=10, device='cpu', hipgraph=True, hipgraph_dp=False)
+        m3 = M(s_off)
+        m3.grad_reducer = Red(world=2)
+        n = len(built)
+        assert m3._graphed_batch(b16) == ('eager', 16) and len(built) == n
+        # one rank with the collective forced (the single-GPU rehearsal of the path) takes the collective route, group None
+        graph.GraphedTrainStep.build_collective = staticmethod(fake_build)
+        m4 = M(s_off)
+        m4.grad_reducer = Red(world=1, force=True)
+        assert m4._graphed_batch(b16) == ('replay', 16) and built[-1] == ((16, 3, 8, 8), None)
+    finally:
+        graph.GraphedTrainStep.build_collective = orig
+    assert ca.Settings(kind=0, input_size=(3, 8, 8), num_classes=10, device='cpu').hipgraph_dp in (False, True)

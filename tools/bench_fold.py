@@ -40,7 +40,7 @@ for Cin, Cout, H, count in LAYERS:
     bpart = torch.zeros(max(nb, 1) * Cin * 2, device='cuda')
     fuses = [_lib.BnBwdFuse(u[i].data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None,
                             bpart.data_ptr(), 1) for i in range(copies)]
-    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(desc), 0), dtype=torch.uint8, device='cuda')
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(desc)), dtype=torch.uint8, device='cuda')
     bias_fold = torch.empty(Cin, device='cuda')
     D = ctypes.byref(desc)
     runs = {
@@ -49,8 +49,8 @@ for Cin, Cout, H, count in LAYERS:
         'dgrad': lambda i: lib.cnk_conv2d_dgrad(D, P(dxc[i]), P(wd), P(da[i]), None, None, ctypes.byref(fuses[i]), None, 0, st()),
         'wgrad': lambda i: lib.cnk_conv2d_wgrad(D, P(dxc[i]), P(a[i]), P(dw), None, 0, P(ws), nws, st()),
         'coef': lambda i: lib.cnk_bn_bwd_coef(None, None, P(part_in), nsl_in, P(gamma), P(mean), P(invstd), P(dgamma), P(dbeta), 0, P(coef), M, Cout, _lib.CNK_BF16, P(wsbn), nbn, st()),
-        'prep': lambda i: lib.cnk_conv2d_bnfold_prepare(D, P(w), P(wd), P(mean), P(invstd), P(coef), 0, P(w_fold), P(bias_fold), st()),
-        'dgrad_f': lambda i: lib.cnk_conv2d_dgrad_bnfold(D, P(g[i]), P(a[i]), 0, P(w_fold), P(bias_fold), P(da[i]), None, None, ctypes.byref(fuses[i]), st()),
+        'prep': lambda i: lib.cnk_conv2d_bnfold_prepare(D, P(w), P(wd), P(mean), P(invstd), P(coef), P(w_fold), P(bias_fold), st()),
+        'dgrad_f': lambda i: lib.cnk_conv2d_dgrad_bnfold(D, P(g[i]), P(a[i]), P(w_fold), P(bias_fold), P(da[i]), None, None, ctypes.byref(fuses[i]), st()),
         'wgrad_f': lambda i: lib.cnk_conv2d_wgrad_bnfold(D, P(g[i]), P(y[i]), P(a[i]), P(mean), P(invstd), P(coef), P(dw), 0, P(ws), nws, st()),
     }
     res = {}

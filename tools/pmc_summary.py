@@ -60,12 +60,21 @@ def main(fetch_dir, write_dir, stats_dir, tag):
     lines = ['%-58s %7s %12s %12s %10s %10s' % ('kernel', 'launch', 'fetch MB/l', 'write MB/l', 'avg us', 'GB/s')]
     for tot, k, n, fe, wr, avg in rows[:24]:
         lines.append('%-58s %7d %12.1f %12.1f %10.1f %10.0f' % (k, n, fe / 1e6, wr / 1e6, avg / 1e3, (fe + wr) / avg if avg else 0))
+    # whole-step traffic: every kernel's bytes per launch x its launches per step in the stats run (steps of that run = launches of
+    # the once-per-step optimizer kernel)
+    steps = next((c for k, (c, _, _) in stats.items() if k.startswith('adam_kernel')), 0)
+    step_bytes = sum((out[k]['fetch'] + out[k]['write']) * stats[k][0] for k in out if k in stats) / steps if steps else None
+    if step_bytes:
+        lines.append('whole step: %.2f GB HBM-side over %d profiled steps (sum over kernels of bytes/launch x launches/step)' % (step_bytes / 1e9, steps))
     txt = '\n'.join(lines)
     print(txt)
     os.makedirs('profiles', exist_ok=True)
     json.dump({'tag': tag, 'note': 'FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE exact; KiB->bytes; separate --pmc passes; '
                                    'families follow libcnk\'s ProfScope families: ' + ', '.join('%s -> %s' % kv for kv in sorted(FAMILY.items())),
                'kernels': out,
+               'step': {'bytes': round(step_bytes) if step_bytes else None, 'steps_profiled': steps,
+                        'note': 'HBM-side bytes of one training step: sum over kernels of (fetch + write per launch) x launches per step of the '
+                                'kernel-stats run; steps = launches of adam_kernel'},
                'families': {k: {'unit': 'bytes/launch (launch-weighted mean over template variants)', 'launches_profiled': v[0],
                                 'fetch': round(v[1] / v[0]), 'write': round(v[2] / v[0]), 'total': round((v[1] + v[2]) / v[0]),
                                 'avg_launch_us': round(v[3] / v[0] / 1e3, 2)} for k, v in fam.items() if v[0]}},
