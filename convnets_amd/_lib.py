@@ -27,15 +27,7 @@ class ConvDesc(ctypes.Structure):
 class BnBwdFuse(ctypes.Structure):
     """cnk_bn_bwd_fuse (include/cnk.h): BN backward folded into the conv dgrad epilogue."""
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'mean', 'invstd', 'gamma', 'beta', 'relu_mask', 'partial')] + \
-               [('relu', ctypes.c_int32)] + \
-               [(n, ctypes.c_void_p) for n in ('final_coef', 'final_tickets', 'final_scratch')]       # round 5: in-kernel finalisation
-
-
-class BnFwdFinal(ctypes.Structure):
-    """cnk_bn_fwd_final (include/cnk.h): the BatchNorm2d behind a conv, finalised by the conv launch itself."""
-    _fields_ = [(n, ctypes.c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'save_mean', 'save_invstd', 'scale_shift')] + \
-               [('eps', ctypes.c_float), ('momentum', ctypes.c_float)] + \
-               [(n, ctypes.c_void_p) for n in ('tickets', 'scratch')]
+               [('relu', ctypes.c_int32)]
 
 
 class PackJob(ctypes.Structure):
@@ -60,12 +52,6 @@ SIGNATURES = {
     'cnk_pack_batch': (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     'cnk_conv2d_fwd_bn_partial_slices': (_i64, [_dp]),
     'cnk_conv2d_fwd': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'cnk_bn_final_ticket_bytes': (_sz, []),
-    'cnk_conv2d_bn_final_scratch_bytes': (_sz, [_dp, ctypes.c_int]),
-    'cnk_conv2d_fwd_bn_final': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnFwdFinal), _vp]),
-    'cnk_bn_fwd_apply': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_int, ctypes.c_int, _vp]),
-    'cnk_bn_bwd_apply_coef': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _i64, _i32, ctypes.c_int, _vp]),
-    'cnk_conv2d_bnfold_prepare_commit': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
     'cnk_conv2d_fwd_act_supported': (ctypes.c_int, [_dp]),
     'cnk_conv2d_fwd_act': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
     'cnk_conv2d_dgrad_accepts_mask': (ctypes.c_int, [_dp]),

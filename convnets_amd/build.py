@@ -30,7 +30,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bn_tail.h'), os.path.join(HERE, '..', 'include', 'cnk.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'cnk.h')]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -14,17 +14,13 @@ bool igemm_supported(const cnk_conv_desc* d, int pass);
 bool igemm_grouped_ok(const cnk_conv_desc* d);
 bool igemm_on_grid(const cnk_conv_desc* d, int pass);
 size_t igemm_image_elems(const cnk_conv_desc* d, int pass, int ntaps);
-int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s, const BnTailParams* tail = nullptr);
-bool igemm_tail_ok(const cnk_conv_desc* d, int pass);
-size_t igemm_tail_scratch_bytes(const cnk_conv_desc* d, int pass);
-int bn_fwd_apply(const void* x, const float* scale_shift, const void* res, const float* raff, void* y, unsigned char* mask, int64_t M, int C, int relu, int dtype, hipStream_t s);
-int bn_bwd_apply_coef(const void* dy, const void* x, const float* coef5, const float* sm, const float* si, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, int dtype, hipStream_t s);
+int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* stats, const void* residual, int relu, hipStream_t s);
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x2, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 bool bnfold_supported(const cnk_conv_desc* d);
 size_t bnfold_image_bytes(const cnk_conv_desc* d);
-int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr, int accumulate = 0);
+int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s);
 int bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* sm, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, int dtype, float* ws, hipStream_t s);
 int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d);
 bool dwconv_supported(const cnk_conv_desc* d);
@@ -130,7 +126,6 @@ static CnkSwitches read_switches() {
     w.wgrad3_slots_pct = env("CNK_WGRAD3_SLOTS_PCT", -1);
     w.bn_pool_elementwise = getenv("CNK_BN_POOL_ELEMENTWISE") ? 1 : 0;
     w.bn_fused_final = env("CNK_BN_FUSED_FINAL", 1);
-    w.bn_tail = env("CNK_BN_TAIL", 1);
     return w;
 }
 static CnkSwitches g_switches = read_switches();          // dynamic initialiser: runs when the library is loaded
@@ -379,47 +374,6 @@ int cnk_conv2d_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, con
     return direct_fwd(d, x, w_fwd, bias, y, S(stream));
 }
 
-size_t cnk_bn_final_ticket_bytes(void) { return BNT_TICKET_BYTES; }
-
-size_t cnk_conv2d_bn_final_scratch_bytes(const cnk_conv_desc* d, int pass) {
-    if (check_desc(d, "cnk_conv2d_bn_final_scratch_bytes") || (pass != CNK_PASS_FWD && pass != CNK_PASS_DGRAD)) return 0;
-    if (pass == CNK_PASS_DGRAD && cnk_conv2d_dgrad_bn_slices(d) <= 0) return 0;
-    return igemm_tail_scratch_bytes(d, pass);
-}
-
-int cnk_conv2d_fwd_bn_final(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y, float* bn_partial, const cnk_bn_fwd_final* fin, void* stream) {
-    if (int rc = check_desc(d, "cnk_conv2d_fwd_bn_final")) return rc;
-    CNK_CHECK_ARG(x && w_fwd && y && bn_partial && fin, "cnk_conv2d_fwd_bn_final: null pointer");
-    CNK_CHECK_ARG(igemm_tail_scratch_bytes(d, CNK_PASS_FWD) > 0, "cnk_conv2d_fwd_bn_final: this conv cannot finalise its BN partials in the epilogue (cnk_conv2d_bn_final_scratch_bytes == 0)");
-    CNK_CHECK_ARG(fin->gamma && fin->beta && fin->save_mean && fin->save_invstd && fin->scale_shift && fin->tickets && fin->scratch, "cnk_conv2d_fwd_bn_final: null pointer in the finalise record");
-    CNK_CHECK_ARG((fin->running_mean == nullptr) == (fin->running_var == nullptr), "cnk_conv2d_fwd_bn_final: running stats must both be given or both NULL");
-    BnTailParams t = {};
-    t.tickets = fin->tickets; t.l2 = fin->scratch; t.gamma = fin->gamma; t.beta = fin->beta;
-    t.running_mean = fin->running_mean; t.running_var = fin->running_var; t.save_mean = fin->save_mean; t.save_invstd = fin->save_invstd;
-    t.out = fin->scale_shift; t.eps = fin->eps; t.momentum = fin->momentum;
-    double fl, by;
-    conv_cost(d, &fl, &by);
-    ProfScope ps(conv_cls(d, 0), S(stream), fl, by);
-    return igemm_fwd(d, x, w_fwd, bias, y, bn_partial, nullptr, 0, S(stream), &t);
-}
-
-int cnk_bn_fwd_apply(const void* x, const float* scale_shift, const void* residual, const float* residual_scale_shift, void* y, uint8_t* relu_mask, int64_t M, int32_t C, int relu, int dtype, void* stream) {
-    CNK_CHECK_ARG(x && scale_shift && y, "cnk_bn_fwd_apply: null pointer");
-    CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_fwd_apply: empty tensor");
-    CNK_CHECK_ARG(!residual_scale_shift || residual, "cnk_bn_fwd_apply: residual_scale_shift without a residual operand");
-    CNK_CHECK_ARG(!relu_mask || relu, "cnk_bn_fwd_apply: relu_mask without relu");
-    ProfScope ps(CNK_CLS_BN_FWD, S(stream), 0.0, (residual ? 3.0 : 2.0) * (double)M * C * esize(dtype));
-    return bn_fwd_apply(x, scale_shift, residual, residual_scale_shift, y, relu_mask, M, C, relu, dtype, S(stream));
-}
-
-int cnk_bn_bwd_apply_coef(const void* dy, const void* x, const float* coef5, const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int dtype, void* stream) {
-    CNK_CHECK_ARG(coef5 && dgamma && dbeta, "cnk_bn_bwd_apply_coef: null pointer");
-    CNK_CHECK_ARG(!dx || (dy && x && save_mean && save_invstd), "cnk_bn_bwd_apply_coef: the apply pass needs dy, x and the saved statistics");
-    CNK_CHECK_ARG(M > 0 && C > 0, "cnk_bn_bwd_apply_coef: empty tensor");
-    ProfScope ps(CNK_CLS_BN_BWD, S(stream), 0.0, dx ? 3.0 * (double)M * C * esize(dtype) : 0.0);
-    return bn_bwd_apply_coef(dy, x, coef5, save_mean, save_invstd, dx, dgamma, dbeta, accumulate, M, C, dtype, S(stream));
-}
-
 int cnk_conv2d_fwd_act_supported(const cnk_conv_desc* d) {
     return check_desc(d, "cnk_conv2d_fwd_act_supported") == 0 && igemm_supported(d, CNK_PASS_FWD) &&
            d->Cout % (d->dtype == CNK_BF16 ? 8 : 4) == 0;
@@ -539,13 +493,6 @@ int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void
     CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_bnfold_prepare: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
     CNK_CHECK_ARG(w && w_dgrad && save_mean && save_invstd && coef && w_fold && bias_fold, "cnk_conv2d_bnfold_prepare: null pointer");
     return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef, w_fold, bias_fold, S(stream));
-}
-
-int cnk_conv2d_bnfold_prepare_commit(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean, const float* save_invstd, const float* coef5, void* w_fold, float* bias_fold, float* dgamma, float* dbeta, int accumulate, void* stream) {
-    if (int rc = check_desc(d, "cnk_conv2d_bnfold_prepare_commit")) return rc;
-    CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d), "cnk_conv2d_bnfold_prepare_commit: this conv shape has no folded BN backward (cnk_conv2d_bnfold_supported == 0)");
-    CNK_CHECK_ARG(w && w_dgrad && save_mean && save_invstd && coef5 && w_fold && bias_fold && dgamma && dbeta, "cnk_conv2d_bnfold_prepare_commit: null pointer");
-    return bnfold_prepare(d, w, w_dgrad, save_mean, save_invstd, coef5, w_fold, bias_fold, S(stream), dgamma, dbeta, accumulate);
 }
 
 int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn, void* stream) {

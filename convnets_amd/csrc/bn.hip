@@ -776,22 +776,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     T* __restrict__ dres, const unsigned char* __restrict__ mask, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ coefA, const float* __restrict__ coefB1,
-    const float* __restrict__ coefB2, int64_t M, int C, SliceGeom g,
-    const float* __restrict__ commit_sums, float* dgamma, float* dbeta, int accumulate) {
+    const float* __restrict__ coefB2, int64_t M, int C, SliceGeom g) {
     const int tid = threadIdx.x, tcol = tid % g.cpb, trow = tid / g.cpb;
     const int vcol = blockIdx.y * g.cpb + tcol;
     if (trow >= g.rpb || vcol >= g.cols) return;
-    // (cnk_bn_bwd_apply_coef: the coefficients came finalised out of a conv epilogue together with the two raw sums, which
-    // the first row-block of each column group adds to the parameter gradients -- the fused path is confirmed by now)
-    if (commit_sums && blockIdx.x == 0 && trow == 0) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const int c = vcol * VEC + k;
-            const float sb = commit_sums[c], sg = commit_sums[C + c];
-            dbeta[c] = accumulate ? dbeta[c] + sb : sb;
-            dgamma[c] = accumulate ? dgamma[c] + sg : sg;
-        }
-    }
     const int64_t m0 = (int64_t)blockIdx.x * g.slice_rows;
     const int64_t m1 = m0 + g.slice_rows < M ? m0 + g.slice_rows : M;
     const int64_t rstep = (int64_t)g.rpb * C;
@@ -1167,44 +1155,6 @@ static int bn_merge_final(const float* partial, int slices, int C, int64_t M, fl
     return 1;
 }
 
-// the apply pass alone (also cnk_bn_fwd_apply: coefficients finalised elsewhere)
-template <typename T, int VEC>
-static int bn_apply_launch(const void* x, const void* res, void* y, const float* scale, const float* shift, unsigned char* mask,
-                           int64_t M, int C, int relu, const float* raff, hipStream_t s) {
-    SliceGeom g = make_geom(M, C, VEC);
-    const dim3 grid(g.slices, g.colgroups);
-#define CNK_BN_APPLY(R, A, W)                                                                              \
-    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, R, A, W>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
-                       (T*)y, scale, shift, mask, M, C, g, nullptr)
-#define CNK_BN_APPLY_RAFF(A, W)                                                                                        \
-    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, true, A, W, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
-                       (T*)y, scale, shift, mask, M, C, g, raff)
-    const int key = (res ? 4 : 0) | (relu ? 2 : 0) | (mask ? 1 : 0);
-    ProfScope kscope(CNK_KF_BN_APPLY, s, 0.0, (double)M * C * sizeof(T) * (res ? 3 : 2) + (mask ? (double)M * C / 8 : 0.0));
-    if (raff && res) {
-        switch (key & 3) {
-            case 0: CNK_BN_APPLY_RAFF(false, false); break;
-            case 1: CNK_BN_APPLY_RAFF(false, true); break;
-            case 2: CNK_BN_APPLY_RAFF(true, false); break;
-            default: CNK_BN_APPLY_RAFF(true, true); break;
-        }
-    } else
-    switch (key) {
-        case 0: CNK_BN_APPLY(false, false, false); break;
-        case 1: CNK_BN_APPLY(false, false, true); break;
-        case 2: CNK_BN_APPLY(false, true, false); break;
-        case 3: CNK_BN_APPLY(false, true, true); break;
-        case 4: CNK_BN_APPLY(true, false, false); break;
-        case 5: CNK_BN_APPLY(true, false, true); break;
-        case 6: CNK_BN_APPLY(true, true, false); break;
-        default: CNK_BN_APPLY(true, true, true); break;
-    }
-#undef CNK_BN_APPLY
-#undef CNK_BN_APPLY_RAFF
-    CNK_CHECK_LAUNCH("bn_apply");
-    return 0;
-}
-
 template <typename T, int VEC>
 static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, const void* res,
                           void* y, unsigned char* mask, float* rm, float* rv, float* sm, float* si,
@@ -1238,7 +1188,37 @@ static int bn_fwd_train_t(const void* x, const float* gamma, const float* beta, 
         cnk_count(CNK_CNT_BN_FINAL_LAUNCH);
     }
     if (!y) return 0;                        // statistics only: scale | shift stay at ws[0..C) | ws[C..2C) for the caller
-    return bn_apply_launch<T, VEC>(x, res, y, scale, shift, mask, M, C, relu, raff, s);
+    const dim3 grid(g.slices, g.colgroups);
+#define CNK_BN_APPLY(R, A, W)                                                                              \
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, R, A, W>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
+                       (T*)y, scale, shift, mask, M, C, g, nullptr)
+#define CNK_BN_APPLY_RAFF(A, W)                                                                                        \
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, true, A, W, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
+                       (T*)y, scale, shift, mask, M, C, g, raff)
+    const int key = (res ? 4 : 0) | (relu ? 2 : 0) | (mask ? 1 : 0);
+    ProfScope kscope(CNK_KF_BN_APPLY, s, 0.0, (double)M * C * sizeof(T) * (res ? 3 : 2) + (mask ? (double)M * C / 8 : 0.0));
+    if (raff && res) {
+        switch (key & 3) {
+            case 0: CNK_BN_APPLY_RAFF(false, false); break;
+            case 1: CNK_BN_APPLY_RAFF(false, true); break;
+            case 2: CNK_BN_APPLY_RAFF(true, false); break;
+            default: CNK_BN_APPLY_RAFF(true, true); break;
+        }
+    } else
+    switch (key) {
+        case 0: CNK_BN_APPLY(false, false, false); break;
+        case 1: CNK_BN_APPLY(false, false, true); break;
+        case 2: CNK_BN_APPLY(false, true, false); break;
+        case 3: CNK_BN_APPLY(false, true, true); break;
+        case 4: CNK_BN_APPLY(true, false, false); break;
+        case 5: CNK_BN_APPLY(true, false, true); break;
+        case 6: CNK_BN_APPLY(true, true, false); break;
+        default: CNK_BN_APPLY(true, true, true); break;
+    }
+#undef CNK_BN_APPLY
+#undef CNK_BN_APPLY_RAFF
+    CNK_CHECK_LAUNCH("bn_apply");
+    return 0;
 }
 
 int bn_fwd_train(const void* x, const float* gamma, const float* beta, const void* res, void* y,
@@ -1250,18 +1230,6 @@ int bn_fwd_train(const void* x, const float* gamma, const float* beta, const voi
     }
     if (C % 4 == 0) return bn_fwd_train_t<float, 4>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s, raff);
     return bn_fwd_train_t<float, 1>(x, gamma, beta, res, y, mask, rm, rv, sm, si, ep, es, M, C, eps, mom, relu, ws, s, raff);
-}
-
-int bn_fwd_apply(const void* x, const float* scale_shift, const void* res, const float* raff, void* y, unsigned char* mask, int64_t M,
-                 int C, int relu, int dtype, hipStream_t s) {
-    const float* scale = scale_shift;
-    const float* shift = scale_shift + C;
-    if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_apply_launch<bf16, 8>(x, res, y, scale, shift, mask, M, C, relu, raff, s);
-        return bn_apply_launch<bf16, 1>(x, res, y, scale, shift, mask, M, C, relu, raff, s);
-    }
-    if (C % 4 == 0) return bn_apply_launch<float, 4>(x, res, y, scale, shift, mask, M, C, relu, raff, s);
-    return bn_apply_launch<float, 1>(x, res, y, scale, shift, mask, M, C, relu, raff, s);
 }
 
 template <typename T, int VEC>
@@ -1332,7 +1300,7 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
     }
 #define CNK_BN_BAPP(A, W)                                                                                     \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, A, W>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \
-                       (const T*)y, (T*)dx, (T*)dres, mask, beta, sm, si, coefA, coefB1, coefB2, M, C, g, nullptr, nullptr, nullptr, 0)
+                       (const T*)y, (T*)dx, (T*)dres, mask, beta, sm, si, coefA, coefB1, coefB2, M, C, g)
     ProfScope kscope(CNK_KF_BN_BWD_APPLY, s, 0.0, (double)M * C * sizeof(T) * (dres ? 4 : 3));
     switch (act * 2 + (dres ? 1 : 0)) {
         case ACT_NONE * 2: CNK_BN_BAPP(ACT_NONE, false); break;
@@ -1347,46 +1315,6 @@ static int bn_bwd_t(const void* dy, const void* x, const void* y, const unsigned
 #undef CNK_BN_BAPP
     CNK_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
-}
-
-// cnk_bn_bwd_apply_coef: the apply pass of the fused path from coefficients a conv epilogue finalised (bn_tail.h); the two raw
-// sums behind them are added to dbeta / dgamma by the same launch.  dx == nullptr: the sums only (one small launch).
-namespace {
-__global__ void bn_commit_kernel(const float* __restrict__ sums, float* dgamma, float* dbeta, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float sb = sums[c], sg = sums[C + c];
-    dbeta[c] = accumulate ? dbeta[c] + sb : sb;
-    dgamma[c] = accumulate ? dgamma[c] + sg : sg;
-}
-}  // namespace
-
-template <typename T, int VEC>
-static int bn_bwd_apply_coef_t(const void* dy, const void* x, const float* coef5, const float* sm, const float* si, void* dx,
-                               float* dgamma, float* dbeta, int accumulate, int64_t M, int C, hipStream_t s) {
-    SliceGeom g = make_geom(M, C, VEC);
-    const dim3 grid(g.slices, g.colgroups);
-    ProfScope kscope(CNK_KF_BN_BWD_APPLY, s, 0.0, (double)M * C * sizeof(T) * 3);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, VEC, ACT_NONE, false>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)nullptr,
-                       (T*)dx, (T*)nullptr, (const unsigned char*)nullptr, (const float*)nullptr, sm, si, coef5, coef5 + C, coef5 + 2 * (size_t)C,
-                       M, C, g, coef5 + 3 * (size_t)C, dgamma, dbeta, accumulate);
-    CNK_CHECK_LAUNCH("bn_bwd_apply (coef)");
-    return 0;
-}
-
-int bn_bwd_apply_coef(const void* dy, const void* x, const float* coef5, const float* sm, const float* si, void* dx, float* dgamma,
-                      float* dbeta, int accumulate, int64_t M, int C, int dtype, hipStream_t s) {
-    if (!dx) {
-        hipLaunchKernelGGL(bn_commit_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, coef5 + 3 * (size_t)C, dgamma, dbeta, C, accumulate);
-        CNK_CHECK_LAUNCH("bn_commit");
-        return 0;
-    }
-    if (dtype == CNK_BF16) {
-        if (C % 8 == 0) return bn_bwd_apply_coef_t<bf16, 8>(dy, x, coef5, sm, si, dx, dgamma, dbeta, accumulate, M, C, s);
-        return bn_bwd_apply_coef_t<bf16, 1>(dy, x, coef5, sm, si, dx, dgamma, dbeta, accumulate, M, C, s);
-    }
-    if (C % 4 == 0) return bn_bwd_apply_coef_t<float, 4>(dy, x, coef5, sm, si, dx, dgamma, dbeta, accumulate, M, C, s);
-    return bn_bwd_apply_coef_t<float, 1>(dy, x, coef5, sm, si, dx, dgamma, dbeta, accumulate, M, C, s);
 }
 
 int bn_bwd(const void* dy, const void* x, const void* y, const unsigned char* mask, const float* gamma, const float* beta, const float* sm,

@@ -34,11 +34,7 @@ struct FoldPrepParams {
     bf16* wf;              // [Cin][Cout + Cin]
     float* biasf;          // [Cin]
     int Cout, Cin;
-    int nb_w, nb_m;        // blocks of the first two roles (then Cin / 8 bias blocks, then the commit blocks)
-    // optional fourth role (coef is then an in-kernel-finalised coef5, bn_tail.h): dbeta / dgamma (+)= coef5[3] / coef5[4]
-    float* dgamma;
-    float* dbeta;
-    int accumulate;
+    int nb_w, nb_m;        // blocks of the first two roles (the rest: bias)
 };
 
 constexpr int FP_MAXC = 4096;          // Cout bound: one fp32 vector of it lives in LDS
@@ -116,16 +112,6 @@ __global__ __launch_bounds__(256) void bnfold_prep_kernel(const FoldPrepParams p
         return;
     }
     b -= p.nb_m;
-    if (b >= p.Cin / 8) {
-        // ---- commit: the BN layer's parameter gradients from the raw sums behind the three coefficient vectors
-        const int k = (b - p.Cin / 8) * 256 + tid;
-        if (k < p.Cout) {
-            const float sb = p.coef[3 * (size_t)p.Cout + k], sg = p.coef[4 * (size_t)p.Cout + k];
-            p.dbeta[k] = p.accumulate ? p.dbeta[k] + sb : sb;
-            p.dgamma[k] = p.accumulate ? p.dgamma[k] + sg : sg;
-        }
-        return;
-    }
     {
         // ---- bias: 8 input channels j per block, 32 k phases, eight loads in flight per thread
         for (int k = tid; k < p.Cout; k += 256) {
@@ -171,14 +157,13 @@ size_t bnfold_image_bytes(const cnk_conv_desc* d) {
 }
 
 int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd,
-                   const float* coef, void* w_fold, float* bias_fold, hipStream_t s, float* dgamma, float* dbeta, int accumulate) {
+                   const float* coef, void* w_fold, float* bias_fold, hipStream_t s) {
     FoldPrepParams p = {};
     p.w = w; p.wd = (const bf16*)w_dgrad; p.coef = coef; p.mean = mean; p.invstd = invstd;
     p.wf = (bf16*)w_fold; p.biasf = bias_fold; p.Cout = d->Cout; p.Cin = d->Cin;
     p.nb_w = (d->Cout / 32) * (d->Cin / 32);
     p.nb_m = (d->Cin / 32) * (d->Cin / 32);
-    p.dgamma = dgamma; p.dbeta = dbeta; p.accumulate = accumulate;
-    const int grid = p.nb_w + p.nb_m + d->Cin / 8 + (dgamma ? ceil_div(d->Cout, 256) : 0);
+    const int grid = p.nb_w + p.nb_m + d->Cin / 8;
     hipLaunchKernelGGL(bnfold_prep_kernel, dim3(grid), dim3(256), 0, s, p);
     CNK_CHECK_LAUNCH("bnfold_prep");
     return 0;

@@ -58,7 +58,6 @@ struct CnkSwitches {
     int wgrad_slots_pct;       // CNK_WGRAD_SLOTS_PCT (-1: all): A/B override of the share of the workgroup slots the weight gradients' split-K fills
     int bn_pool_elementwise;   // CNK_BN_POOL_ELEMENTWISE (0)
     int bn_fused_final;        // CNK_BN_FUSED_FINAL (1): finalisation of the BN partials inside the merge launch
-    int bn_tail;               // CNK_BN_TAIL (1): finalisation of the BN partials inside the conv kernel that writes them (bn_tail.h)
 };
 const CnkSwitches& cnk_sw();
 
@@ -179,33 +178,6 @@ struct DgradClass {
     signed char kh[32], kw[32], dh[32], dw[32];
 };
 
-// ---- in-kernel finalisation of BN partial lists (bn_tail.h) ----------------------------------------------------------------
-constexpr int BNT_FAN = 64;
-
-struct BnTailParams {
-    int kind;                  // 0: off;  1: forward statistics (NV = 3);  2: backward sums (NV = 2)
-    int slices;                // level-0 records per channel written by THIS launch (its row tiles)
-    int C;                     // channels of the list (record row length)
-    int pad_;
-    unsigned int* tickets;     // [ngroups * ncg] level-1 counters, then [ncg] level-2 counters (ncg = column tiles of the launch)
-    float* l2;                 // level-1 results [ngroups][C][NV]
-    int64_t M;                 // rows of the BN tensor
-    const float* gamma;        // both kinds
-    // kind 1
-    const float* beta;
-    float* running_mean;       // may be null (with running_var)
-    float* running_var;
-    float* save_mean;
-    float* save_invstd;        // kind 1: out;  kind 2: in (the layer's saved invstd)
-    float* out;                // kind 1: scale | shift [2][C];  kind 2: A | B1 | B2 | sum(dy') | sum(dy' xhat) [5][C]
-    float eps, momentum;
-};
-
-static inline int bnt_groups(int slices) { return (slices + BNT_FAN - 1) / BNT_FAN; }
-static inline size_t bnt_ticket_count(int slices, int ncg) { return (size_t)(bnt_groups(slices) + 1) * ncg; }
-static inline size_t bnt_scratch_floats(int slices, int C) { return (size_t)bnt_groups(slices) * C * 3; }
-constexpr size_t BNT_TICKET_BYTES = 256 * 1024;          // what the host side keeps per stream (cnk_bn_final_ticket_bytes)
-
 // Ping-pong 3x3 core (conv_pp.hip): arguments of one launch, filled by conv_igemm.hip from its GatherParams.
 struct PPArgs {
     const void* src;
@@ -243,7 +215,6 @@ struct G1Args {
     const unsigned char* bnf_mask; float* bnf_partial; int bnf_relu, bnf_tile0;
     int64_t M; int K, Nout;
     double algo_flops, algo_bytes;
-    BnTailParams tail;                                // kind 0: off
 };
 int gemm1x1_launch(int nj, const G1Args& a, hipStream_t s);
 

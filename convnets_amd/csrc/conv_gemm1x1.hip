@@ -26,7 +26,6 @@
 #include <cstdlib>
 
 #include "common.h"
-#include "bn_tail.h"
 
 #ifndef G1_ABL
 #define G1_ABL 0      // debug builds (tools/ablate_g1.sh): 1 no MFMAs, 2 no DMAs, 4 no fragment reads
@@ -72,7 +71,6 @@ struct G1Params {
     float* bnf_partial;     // [bnf_tile0 + tiles_m][Nout][2]
     int bnf_relu, bnf_tile0;
     int M, K, K2, Nout, tiles_m, tiles_n, nk;
-    BnTailParams tail;      // in-kernel finalisation of the stats / bnf_partial list (bn_tail.h); kind 0: off
 };
 
 __device__ __forceinline__ void g1_dma16(const void* g, uint32_t lds_addr) {        // M0 saved / restored inside
@@ -359,26 +357,21 @@ __global__ __launch_bounds__(512, (NJ == 2 && MODE < 2) ? 4 : 2) void gemm1x1_ke
                 S += red[((size_t)w * BN + tid) * 2];
                 Q += red[((size_t)w * BN + tid) * 2 + 1];
             }
-            // (write-through stores: with p.tail the list is merged by the last workgroups of this very launch, bn_tail.h)
             if constexpr (FULL) {
                 const int c = n0 + tid;
                 float* o = p.bnf_partial + ((size_t)(p.bnf_tile0 + tile_m) * p.Nout + c) * 2;
-                bnt_st(o, S);
-                bnt_st(o + 1, Q * is_fin);
+                o[0] = S;
+                o[1] = Q * is_fin;
             } else {
                 const int nvalid = min(G1_BM, p.M - m0);
                 const float mean = S / (float)nvalid;
                 const float m2 = Q - S * mean;
                 float* o = p.stats + ((size_t)tile_m * p.Nout + n0 + tid) * 3;
-                bnt_st(o, (float)nvalid);
-                bnt_st(o + 1, mean);
-                bnt_st(o + 2, m2 > 0.f ? m2 : 0.f);
+                o[0] = (float)nvalid;
+                o[1] = mean;
+                o[2] = m2 > 0.f ? m2 : 0.f;
             }
         }
-        // in-kernel finalisation of the list (p.tail.kind, uniform); the ring is idle: its first bytes are the scratch
-        if (p.tail.kind)
-            bn_tail<512, BN>(p.tail, FULL ? p.bnf_partial : p.stats, (FULL ? p.bnf_tile0 : 0) + tile_m, n0, BN, tile_n, p.tiles_n,
-                             (float*)smem, tid);
     }
 }
 
@@ -449,11 +442,6 @@ int gemm1x1_launch(int nj, const G1Args& a, hipStream_t s) {
     p.M = (int)a.M; p.K = a.K; p.K2 = a.a2 ? a.K2 : 0; p.Nout = a.Nout;
     CNK_CHECK_ARG(p.K2 % G1_KC == 0, "gemm1x1: second K segment off the 32-channel grid");
     p.tiles_m = (int)((a.M + G1_BM - 1) / G1_BM); p.tiles_n = 0; p.nk = (p.K + p.K2) / G1_KC;
-    p.tail = a.tail;
-    if (p.tail.kind) {
-        CNK_CHECK_ARG(p.stats || p.bnf_x, "gemm1x1: in-kernel BN finalisation without a partial list");
-        p.tail.slices = p.tiles_m;                   // one record per 256-row tile
-    }
     CNK_CHECK_ARG(!(p.stats && (p.addend || p.bnf_x)), "gemm1x1: statistics partials and data-gradient side operands are exclusive");
     return nj == 4 ? gemm1x1_launch_t<4>(p, a.algo_flops, a.algo_bytes, s) : gemm1x1_launch_t<2>(p, a.algo_flops, a.algo_bytes, s);
 }

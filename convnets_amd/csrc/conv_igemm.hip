@@ -19,7 +19,6 @@
 #include <cstdlib>
 
 #include "common.h"
-#include "bn_tail.h"
 
 #ifndef CNK_ABLATE
 #define CNK_ABLATE 0      // debug builds only (tools/ablate.sh): 1 no MFMA phase, 2 no global loads, 4 no LDS reads, 16 no tap masks
@@ -67,7 +66,6 @@ struct GatherParams {
     int M;
     int tiles_n;
     int tiles_total;
-    BnTailParams tail;       // in-kernel finalisation of the stats / bnf_partial list (bn_tail.h); kind 0: off
     FastDiv fd_ohw, fd_ow;
     signed char dh[MAX_TAPS], dw[MAX_TAPS];
 };
@@ -292,26 +290,21 @@ __device__ __forceinline__ void igemm_epilogue(const GatherParams& p, unsigned c
                 S += red[r * BN + tid];
                 Q += red[(RPP + r) * BN + tid];
             }
-            // (write-through stores: with p.tail the list is merged by the last workgroups of this very launch, bn_tail.h)
             if (bnf) {
                 const int c = tile_n * BN + tid;
                 float* o = p.bnf_partial + ((size_t)(p.bnf_tile0 + tile_m) * p.Nout + c) * 2;
-                bnt_st(o, S);
-                bnt_st(o + 1, Q * is_fin);
+                o[0] = S;
+                o[1] = Q * is_fin;
             } else {
                 const int nvalid = min(BM, p.M - tile_m * BM);
                 const float mean = S / (float)nvalid;
                 float m2 = Q - S * mean;
                 float* o = p.stats + ((size_t)tile_m * p.Nout + tile_n * BN + tid) * 3;
-                bnt_st(o, (float)nvalid);
-                bnt_st(o + 1, mean);
-                bnt_st(o + 2, m2 > 0.f ? m2 : 0.f);
+                o[0] = (float)nvalid;
+                o[1] = mean;
+                o[2] = m2 > 0.f ? m2 : 0.f;
             }
         }
-        // in-kernel finalisation of the list (p.tail.kind, wave-uniform): the scratch reuses the reduction area
-        if (p.tail.kind)
-            bn_tail<256, BN>(p.tail, bnf ? p.bnf_partial : p.stats, (bnf ? p.bnf_tile0 : 0) + tile_m, tile_n * BN, ncols, tile_n, p.tiles_n,
-                             (float*)Cs, tid);
     }
 }
 
@@ -870,12 +863,10 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
         p.tiles_n = ceil_div(p.Nout, 64);
         p.tiles_total = tiles_m * p.tiles_n;
         if (p.tiles_total == 0) return 0;
-        if (p.tail.kind) p.tail.slices = tiles_m;
         return launch_gather<T, 64, true>(p, s);
     }
     if (sizeof(T) == 2 && !p.chunked && halo_shape(p) && pp3x3_ok(p.N, p.IH, p.IW, p.C, p.Nout, p.is_dgrad, p.bnf_x != nullptr)) {
         // stride-1 3x3 on the ping-pong core (conv_pp.hip); partials are per 64-row slice there
-        CNK_CHECK_ARG(!p.tail.kind, "igemm: the ping-pong core does not finalise BN partials in its epilogue (igemm_tail_ok)");
         PPArgs a = {};
         a.src = p.src; a.wpk = p.wpk; a.dst = p.dst; a.bias = p.bias; a.addend = p.addend; a.addend_mask = p.addend_mask;
         a.stats = p.stats; a.bnf_x = p.bnf_x; a.bnf_mean = p.bnf_mean; a.bnf_invstd = p.bnf_invstd; a.bnf_gamma = p.bnf_gamma;
@@ -899,7 +890,6 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
             a.bnf_mask = p.bnf_mask; a.bnf_partial = p.bnf_partial; a.bnf_relu = p.bnf_relu; a.bnf_tile0 = p.bnf_tile0;
             a.M = p.M; a.K = p.C; a.Nout = p.Nout;
             a.algo_flops = gather_flops(p); a.algo_bytes = gather_bytes(p, sizeof(T));
-            a.tail = p.tail;
             return gemm1x1_launch(nj, a, s);
         }
     bool use128 = !p.chunked && pick_bn128(p.M, p.Nout);
@@ -907,7 +897,6 @@ template <typename T> int launch_gather_bn(GatherParams& p, hipStream_t s) {
     p.tiles_n = p.Nout / bn;
     p.tiles_total = tiles_m * p.tiles_n;
     if (p.tiles_total == 0) return 0;
-    if (p.tail.kind) p.tail.slices = tiles_m;        // one record per BM-row tile (the kernels below end in igemm_epilogue)
     if (igemm_halo_enabled() && !p.chunked && halo_shape(p)) {
         // three workgroups per CU need <= 53 KiB each; wider images fall back to the gather kernel
         size_t lds = use128 ? halo_lds<T, 128>(p) : halo_lds<T, 64>(p);
@@ -970,29 +959,6 @@ static bool pp_desc(const cnk_conv_desc* d, int pass) {
     return pp3x3_ok(d->N, d->H, d->W, cred, nout, pass == CNK_PASS_DGRAD, 1);
 }
 
-// In-kernel finalisation of the BN partials this conv pass emits (bn_tail.h): every kernel that ends in igemm_epilogue or in
-// the ring GEMM's epilogue -- i.e. not the ping-pong core (per-wave epilogues, no workgroup barrier to hang a ticket on), and
-// stride-1 data gradients only (the stride-parity classes of a strided one are separate launches with their own tilings).
-bool igemm_tail_ok(const cnk_conv_desc* d, int pass) {
-    if (!cnk_sw().bn_tail || !igemm_supported(d, pass) || pp_desc(d, pass)) return false;
-    int Ho, Wo;
-    cnk_conv2d_out_hw(d, &Ho, &Wo);
-    if (pass == CNK_PASS_DGRAD && (d->stride_h != 1 || d->stride_w != 1)) return false;
-    const int64_t M = pass == CNK_PASS_FWD ? (int64_t)d->N * Ho * Wo : (int64_t)d->N * d->H * d->W;
-    const int nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
-    if (M <= 0 || M >= (1ll << 31)) return false;
-    return bnt_ticket_count((int)ceil_div64(M, BM), ceil_div(nout, 64)) * sizeof(unsigned int) <= BNT_TICKET_BYTES;
-}
-
-size_t igemm_tail_scratch_bytes(const cnk_conv_desc* d, int pass) {
-    if (!igemm_tail_ok(d, pass)) return 0;
-    int Ho, Wo;
-    cnk_conv2d_out_hw(d, &Ho, &Wo);
-    const int64_t M = pass == CNK_PASS_FWD ? (int64_t)d->N * Ho * Wo : (int64_t)d->N * d->H * d->W;
-    const int nout = pass == CNK_PASS_FWD ? d->Cout : d->Cin;
-    return (bnt_scratch_floats((int)ceil_div64(M, BM), nout) + 4) * sizeof(float);
-}
-
 int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
@@ -1004,16 +970,11 @@ int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d) {
 }
 
 int igemm_fwd(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
-              float* stats, const void* residual, int relu, hipStream_t s, const BnTailParams* tail) {
+              float* stats, const void* residual, int relu, hipStream_t s) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     GatherParams p = {};
     p.src = x; p.wpk = w_fwd; p.dst = y; p.bias = bias; p.stats = stats;
-    if (tail) {
-        CNK_CHECK_ARG(stats && igemm_tail_ok(d, CNK_PASS_FWD), "igemm_fwd: this conv cannot finalise its BN partials in the epilogue");
-        p.tail = *tail;
-        p.tail.kind = 1; p.tail.C = d->Cout; p.tail.M = (int64_t)d->N * Ho * Wo;
-    }
     p.addend = residual; p.relu = relu; p.chunked = conv_groups(d) > 1;
     p.N = d->N; p.IH = d->H; p.IW = d->W; p.C = d->Cin;
     p.OH = Ho; p.OW = Wo; p.FH = Ho; p.FW = Wo; p.Nout = d->Cout;
@@ -1075,18 +1036,6 @@ int64_t igemm_dgrad_bn_slices(const cnk_conv_desc* d) {
     return n;
 }
 
-// the consumer-side finalisation of a fused BN backward (cnk_bn_bwd_fuse.final_coef): stride-1 data gradients only
-static int dgrad_tail(const cnk_conv_desc* d, const cnk_bn_bwd_fuse* bn, GatherParams& p) {
-    if (!bn || !bn->final_coef) return 0;
-    CNK_CHECK_ARG(igemm_tail_ok(d, CNK_PASS_DGRAD), "igemm_dgrad: this data gradient cannot finalise the fused BN backward (cnk_conv2d_bn_final_scratch_bytes == 0)");
-    CNK_CHECK_ARG(bn->gamma && bn->final_tickets && bn->final_scratch, "igemm_dgrad: in-kernel finalisation needs gamma, tickets and scratch");
-    p.tail = BnTailParams{};
-    p.tail.kind = 2; p.tail.C = d->Cin; p.tail.M = (int64_t)d->N * d->H * d->W;
-    p.tail.tickets = bn->final_tickets; p.tail.l2 = bn->final_scratch;
-    p.tail.gamma = bn->gamma; p.tail.save_invstd = const_cast<float*>(bn->invstd); p.tail.out = bn->final_coef;
-    return 0;
-}
-
 // Data gradient of a 1x1 / stride-1 conv (no padding) with the backward of the BN layer behind it folded in (csrc/bnfold.hip):
 // K = [g (Cout channels) | x (Cin channels)], weight image w_fold [Cin][Cout + Cin], bias c (+ addend, + fused BN backward of the
 // layer in front).
@@ -1107,7 +1056,6 @@ int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, con
         p.bnf_x = bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma;
         p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
         p.bnf_relu = bn->relu; p.bnf_tile0 = 0;
-        if (int rc = dgrad_tail(d, bn, p)) return rc;
     }
     p.fd_ohw = make_fastdiv(d->H * d->W);
     p.fd_ow = make_fastdiv(d->W);
@@ -1144,7 +1092,6 @@ int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, voi
             p.bnf_beta = bn->beta; p.bnf_mask = bn->relu_mask; p.bnf_partial = bn->partial;
             p.bnf_relu = bn->relu; p.bnf_tile0 = tile0;
             tile0 += ceil_div(p.M, BM);
-            if (int rc = dgrad_tail(d, bn, p)) return rc;
         }
         p.fd_ohw = make_fastdiv(k.OH * k.OW);
         p.fd_ow = make_fastdiv(k.OW);

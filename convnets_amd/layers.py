@@ -59,7 +59,7 @@ class Conv2d(nn.Conv2d):
             new.__dict__[k] = ops.PackedWeights() if k == '_packed' else copy.deepcopy(v, memo)
         return new
 
-    def forward(self, x, want_bn_partial=False, link=None, fold=None, bn_final=None):
+    def forward(self, x, want_bn_partial=False, link=None, fold=None):
         if self._depthwise:                      # conv2d_depthwise (basemodel.py:981-997)
             y = ops.DepthwiseConv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding))
             return (y, torch.empty(0, device=x.device)) if want_bn_partial else y
@@ -76,7 +76,7 @@ class Conv2d(nn.Conv2d):
                                       self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), 1)
         return ops.Conv2dFn.apply(x, self.weight, self.bias, _pair(self.stride), _pair(self.padding),
                                   self._packed, want_bn_partial, link, getattr(x, '_cnk_bn', None), self.groups,
-                                  self._dil, fold, bn_final)
+                                  self._dil, fold)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -305,11 +305,7 @@ class ConvBlock(nn.Sequential):
                 # (fold: the BN backward's apply pass runs inside this conv's backward where the shape allows, ops.FoldRecord)
                 fold = ops.FoldRecord() if (ops.BN_FOLD and torch.is_grad_enabled()
                                             and isinstance(conv, Conv2d) and conv.kernel_size == (1, 1)) else None
-                # (bn_final: where the conv's kernel can, its launch finalises this BN layer too -- ops.Conv2dFn.forward --
-                # and `partial` comes back as the finalised statistics)
-                bn_final = (bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum)) \
-                    if (isinstance(conv, Conv2d) and bn.affine and bn.track_running_stats and bn.momentum is not None) else None
-                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold, bn_final=bn_final)
+                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold)
                 pool = self._linked_pool()
                 if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back

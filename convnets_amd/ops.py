@@ -100,26 +100,6 @@ def workspace(nbytes, device):
     return ws
 
 
-# In-kernel finalisation of BN partial lists (csrc/bn_tail.h): a conv epilogue that emits BN partials also
-# merges them -- "the last workgroup to arrive" -- so the dependent finalise launch in front of the BN pass (120 per ResNet-50
-# step, ~9 us + a ~4.4 us launch gap each, all on the critical path) disappears where the conv runs on a kernel that can
-# (everything but the ping-pong 3x3 core and strided data gradients).  A/B switch: CNK_BN_TAIL=0 (library side).
-BN_TAIL = os.environ.get('CNK_BN_TAIL', '1') != '0'
-TAIL_COUNTS = {'fwd': 0, 'bwd': 0}            # convs that finalised a BN layer in their own launch (tests read this)
-_tickets = {}
-
-
-def final_tickets(device):
-    """The ticket counters of the in-kernel finalisation: zero once, every launch resets what it used, so one buffer per
-    (device, stream) serves all calls of that stream (launches of different streams may overlap: separate buffers)."""
-    key = (device, _raw_stream(device.index) if (_raw_stream is not None and device.index is not None)
-           else torch.cuda.current_stream(device).cuda_stream)
-    t = _tickets.get(key)
-    if t is None:
-        t = _tickets[key] = torch.zeros(_lib.load().cnk_bn_final_ticket_bytes(), dtype=torch.uint8, device=device)
-    return t
-
-
 # ---- second HIP stream for the weight gradients -------------------------------------------------------
 # In the backward of a conv, dgrad (needed by the next backward op) and wgrad (needed only by the
 # optimizer / the gradient all-reduce) both depend on dy alone.  Both kernels are latency-bound and end
@@ -197,7 +177,7 @@ def join_side_streams(device=None):
 # ~1,900 launches from Python).  _lib.reload_switches() (tests, A/B tools) moves the epoch and drops them.
 class ConvPlan:
     __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'wgrad_min_ws', 'wgrad_min_ws_bias', 'accepts_mask',
-                 'bnfold', 'fold_bytes', 'fwd_final_scratch', 'dgrad_final_scratch')
+                 'bnfold', 'fold_bytes')
 
 
 _conv_plans = {}
@@ -222,9 +202,6 @@ def conv_plan(x_shape, weight_shape, stride, padding, dtype_code, groups, dilati
         pl.accepts_mask = bool(lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(d)))
         pl.bnfold = bool(lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)))
         pl.fold_bytes = lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)) if pl.bnfold else 0
-        # in-kernel finalisation of the BN partials this conv emits (csrc/bn_tail.h): bytes of level-2 scratch, 0 = not available
-        pl.fwd_final_scratch = lib.cnk_conv2d_bn_final_scratch_bytes(ctypes.byref(d), PASS_FWD) if pl.fwd_slices > 0 else 0
-        pl.dgrad_final_scratch = lib.cnk_conv2d_bn_final_scratch_bytes(ctypes.byref(d), PASS_DGRAD) if pl.dgrad_slices > 0 else 0
         if len(_conv_plans) > 4096:
             _conv_plans.clear()
         _conv_plans[key] = pl
@@ -280,14 +257,11 @@ class FoldRecord:
     (dgamma, dbeta, the three coefficient vectors), parks them here together with the gradient w.r.t. the BN OUTPUT, and hands
     that very tensor to autograd as the "gradient" of the conv output; Conv2dFn.backward recognises it (same storage) and runs
     cnk_conv2d_dgrad_bnfold / cnk_conv2d_wgrad_bnfold.  The [M][Cout] gradient w.r.t. the conv output is never written."""
-    __slots__ = ('ok', 'g', 'y', 'mean', 'invstd', 'coef', 'commit')
+    __slots__ = ('ok', 'g', 'y', 'mean', 'invstd', 'coef')
 
     def __init__(self):
         self.ok = False                   # set by Conv2dFn.forward when the conv shape can fold
         self.g = self.y = self.mean = self.invstd = self.coef = None
-        # (dgamma buffer, dbeta buffer, gamma, beta): coef is an in-kernel-finalised coef5 whose two raw sums the conv's
-        # prepare launch still has to add to the BN layer's parameter gradients (cnk_conv2d_bnfold_prepare_commit)
-        self.commit = None
 
 
 BN_FOLD = os.environ.get('CNK_BN_FOLD', '1') != '0'
@@ -480,14 +454,10 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, packed, want_bn_partial=False, link=None,
-                bn_rec=None, groups=1, dilation=1, fold=None, bn_final=None):
+                bn_rec=None, groups=1, dilation=1, fold=None):
         """Returns y, or (y, bn_partial) when want_bn_partial: the per-tile BN statistics partials
         of y emitted by the conv epilogue (None when this conv shape cannot produce them).
-        link: optional GradLink shared with the other consumer of x (residual blocks).
-        bn_final: (gamma, beta, running_mean, running_var, eps, momentum) of the training-mode BatchNorm2d that is y's only
-        consumer (layers.ConvBlock): where the conv's kernel can, it finalises that layer in its own launch (csrc/bn_tail.h)
-        and the second result is the FINALISED statistics, a [4][Cout] tensor save_mean | save_invstd | scale | shift (2-D:
-        that is how BatchNormActFn tells it from a partial list) -- the BN call then runs its apply pass only."""
+        link: optional GradLink shared with the other consumer of x (residual blocks)."""
         _require_gpu(x)
         lib = _lib.load()
         ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) bn_partial
@@ -501,26 +471,12 @@ class Conv2dFn(torch.autograd.Function):
         y = torch.empty((desc.N, desc.Cout, plan.Ho, plan.Wo), dtype=x.dtype, device=x.device,
                         memory_format=CL)
         partial = None
-        if want_bn_partial and bn_final is not None and BN_TAIL and plan.fwd_final_scratch > 0:
-            # the partial list and the level-2 records only live inside this launch: both in the stream's workspace
-            gamma, beta, rmean, rvar, eps, momentum = bn_final
-            nlist = plan.fwd_slices * desc.Cout * 12
-            ws = workspace(nlist + plan.fwd_final_scratch, x.device)
-            partial = torch.empty((4, desc.Cout), dtype=torch.float32, device=x.device)
-            base = partial.data_ptr()
-            fin = _lib.BnFwdFinal(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr() if rmean is not None else None,
-                                  rvar.data_ptr() if rvar is not None else None, base, base + 4 * desc.Cout, base + 8 * desc.Cout,
-                                  float(eps), float(momentum), final_tickets(x.device).data_ptr(), ws.data_ptr() + nlist)
-            check(lib.cnk_conv2d_fwd_bn_final(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(ws), ctypes.byref(fin),
-                                              _stream()))
-            TAIL_COUNTS['fwd'] += 1
-        else:
-            if want_bn_partial:
-                slices = plan.fwd_slices
-                if slices > 0:
-                    partial = torch.empty((slices, desc.Cout, 3), dtype=torch.float32, device=x.device)
-            check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial),
-                                     None, 0, _stream()))
+        if want_bn_partial:
+            slices = plan.fwd_slices
+            if slices > 0:
+                partial = torch.empty((slices, desc.Cout, 3), dtype=torch.float32, device=x.device)
+        check(lib.cnk_conv2d_fwd(ctypes.byref(desc), _p(x), _p(w_fwd), _p(bias), _p(y), _p(partial),
+                                 None, 0, _stream()))
         ctx.save_for_backward(x, w)
         ctx.desc, ctx.w_dgrad, ctx.has_bias, ctx.plan = desc, w_dgrad, bias is not None, plan
         ctx.params = (weight, bias)
@@ -545,7 +501,7 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dpartial=None):
         lib = _lib.load()
         if dy is None:                        # y took no part in the loss
-            return (None,) * 13
+            return (None,) * 12
         x, w = ctx.saved_tensors
         desc = ctx.desc
         # folded BN backward: dy is the gradient w.r.t. the BN OUTPUT, parked by BatchNormActFn.backward
@@ -559,7 +515,7 @@ class Conv2dFn(torch.autograd.Function):
                 # as this conv's "gradient"), but autograd delivers a different tensor -- a hook cloned or rescaled it, or a
                 # second consumer's gradient was accumulated on top: the plain backward on it would be silently wrong
                 # 
-                fold.g = fold.y = fold.mean = fold.invstd = fold.coef = fold.commit = None
+                fold.g = fold.y = fold.mean = fold.invstd = fold.coef = None
                 raise RuntimeError('convnets_amd: the gradient of a conv output whose BN backward was folded into the conv '
                                    '(ops.FoldRecord) reached Conv2dFn.backward as a different tensor (a tensor hook or a second '
                                    'consumer of the conv output?); run with CNK_BN_FOLD=0')
@@ -570,18 +526,8 @@ class Conv2dFn(torch.autograd.Function):
             FOLD_COUNTS['folded'] += 1
             w_fold = torch.empty(ctx.plan.fold_bytes, dtype=torch.uint8, device=x.device)
             bias_fold = torch.empty(desc.Cin, dtype=torch.float32, device=x.device)
-            if fold.commit is not None:
-                # the coefficients came finalised out of the consumer's data gradient: this launch also adds the two raw sums
-                # to the BN layer's dbeta / dgamma -- and only NOW are those gradients written (the reducer may look)
-                dg_buf, db_buf, pg, pb = fold.commit
-                check(lib.cnk_conv2d_bnfold_prepare_commit(ctypes.byref(desc), _p(w), _p(ctx.w_dgrad), _p(fold.mean), _p(fold.invstd),
-                                                           _p(fold.coef), _p(w_fold), _p(bias_fold), _p(dg_buf), _p(db_buf), 1,
-                                                           _stream()))
-                _grad_written(pg)
-                _grad_written(pb)
-            else:
-                check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(desc), _p(w), _p(ctx.w_dgrad), _p(fold.mean), _p(fold.invstd),
-                                                    _p(fold.coef), _p(w_fold), _p(bias_fold), _stream()))
+            check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(desc), _p(w), _p(ctx.w_dgrad), _p(fold.mean), _p(fold.invstd),
+                                                _p(fold.coef), _p(w_fold), _p(bias_fold), _stream()))
         # dy is complete on the compute stream HERE: the weight gradient (issued below on the second
         # stream) waits for this point only, so it also overlaps this conv's own data gradient
         dy_ready = None
@@ -602,25 +548,12 @@ class Conv2dFn(torch.autograd.Function):
                 out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=CL)
                 # x is the output of a BN(+ReLU) layer and `out` the TOTAL gradient w.r.t. it: run the
                 # first pass of that layer's backward in this epilogue (BnRecord)
-                rec, fuse, partial, coef5 = ctx.bn_rec, None, None, None
+                rec, fuse, partial = ctx.bn_rec, None, None
                 if rec is not None and (ctx.link is None or ctx.link.final) and rec.x is not None \
                         and rec.x.shape == x.shape and rec.x.dtype == x.dtype \
                         and (BN_BWD_FUSE_3X3 or desc.kh != 3 or desc.stride_h != 1):
                     slices = ctx.plan.dgrad_slices
-                    if slices > 0 and BN_TAIL and ctx.plan.dgrad_final_scratch > 0:
-                        # the launch also finalises the sums (csrc/bn_tail.h): the list and the level-2 records live in the
-                        # stream's workspace, what comes out is coef5 = A | B1 | B2 | sum(dx') | sum(dx' xhat)
-                        nlist = slices * desc.Cin * 8
-                        ws = workspace(nlist + ctx.plan.dgrad_final_scratch, x.device)
-                        coef5 = torch.empty(5 * desc.Cin, dtype=torch.float32, device=x.device)
-                        partial = ws
-                        fuse = _lib.BnBwdFuse(rec.x.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr(),
-                                              rec.gamma.data_ptr(), rec.beta.data_ptr(),
-                                              rec.mask.data_ptr() if rec.mask is not None else None,
-                                              ws.data_ptr(), int(rec.relu), coef5.data_ptr(),
-                                              final_tickets(x.device).data_ptr(), ws.data_ptr() + nlist)
-                        TAIL_COUNTS['bwd'] += 1
-                    elif slices > 0:
+                    if slices > 0:
                         partial = torch.empty((slices, desc.Cin, 2), dtype=torch.float32, device=x.device)
                         fuse = _lib.BnBwdFuse(rec.x.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr(),
                                               rec.gamma.data_ptr(), rec.beta.data_ptr(),
@@ -635,7 +568,7 @@ class Conv2dFn(torch.autograd.Function):
                                                _p(addend), _p(amask), ctypes.byref(fuse) if fuse else None,
                                                None, 0, _stream()))
                 if fuse is not None:
-                    rec.fused = (out, partial if coef5 is None else None, coef5)
+                    rec.fused = (out, partial)
                 return out
             dx = ctx.link.contribute(dgrad) if ctx.link is not None else dgrad(None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -694,8 +627,8 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 run_wgrad()
         if fold is not None:
-            fold.g = fold.y = fold.mean = fold.invstd = fold.coef = fold.commit = None
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+            fold.g = fold.y = fold.mean = fold.invstd = fold.coef = None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -724,40 +657,19 @@ class BatchNormActFn(torch.autograd.Function):
         M = N * H * W
         if defer is not None and (relu or residual is not None):
             raise ValueError('batch_norm: a deferred apply pass takes neither an activation nor a residual operand')
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws_bytes, mask_bytes = bn_sizes(M, C, _dtype_code(x))
+        ws = workspace(ws_bytes, x.device)
         if partial is not None and partial.numel() == 0:
             partial = None
-        # finalised by the producing conv's own launch (Conv2dFn.forward, bn_final): [4][C] = save_mean | save_invstd | scale | shift
-        final = partial if (partial is not None and partial.dim() == 2) else None
-        if final is not None:
-            if final.shape != (4, C):
-                raise ValueError('batch_norm: finalised statistics must be [4][C]')
-            partial = None
-            save_mean, save_invstd = final[0], final[1]
-            scale_shift = ctypes.c_void_p(final.data_ptr() + 8 * C)
-            ws = None
-        else:
-            save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
-            save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-            ws = workspace(ws_bytes, x.device)
         nsl = 0 if partial is None else partial.shape[0]
         # with a residual operand the ReLU mask cannot be re-derived from x alone: keep it as a
         # packed bit mask (1/16 of y's bytes) for the backward instead of re-reading y twice
         mask = None
         if relu and residual is not None and x_needs_grad:
             mask = torch.empty(mask_bytes, dtype=torch.uint8, device=x.device)
-        if res_affine is not None and residual is None:
-            raise ValueError('batch_norm: res_affine without a residual operand')
-        if final is not None:
-            # statistics, running statistics and coefficients are done: the apply pass alone (none at all when it is deferred)
-            if defer is not None:
-                defer.append(final[2:4].reshape(-1))
-                y = x.detach()
-            else:
-                y = torch.empty_like(x, memory_format=CL)
-                check(lib.cnk_bn_fwd_apply(_p(x), scale_shift, _p(residual), _p(res_affine), _p(y), _p(mask), M, C, int(relu),
-                                           _dtype_code(x), _stream()))
-        elif defer is not None:
+        if defer is not None:
             # statistics only; scale | shift are left at the start of the (shared) workspace: keep a copy for the consumer
             check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), None, None, None,
                                        _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial), nsl,
@@ -765,6 +677,8 @@ class BatchNormActFn(torch.autograd.Function):
             defer.append(ws[:8 * C].view(torch.float32).clone())
             y = x.detach()                   # alias: the consumer reads the un-normalised tensor + the coefficients
         elif res_affine is not None:
+            if residual is None:
+                raise ValueError('batch_norm: res_affine without a residual operand')
             y = torch.empty_like(x, memory_format=CL)
             check(lib.cnk_bn_fwd_train_res_affine(_p(x), _p(gamma), _p(beta), _p(residual), _p(res_affine), _p(y), _p(mask),
                                                   _p(running_mean), _p(running_var), _p(save_mean), _p(save_invstd), _p(partial),
@@ -797,22 +711,22 @@ class BatchNormActFn(torch.autograd.Function):
         x, y, mask, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
         # first pass already done by the consumer conv's dgrad epilogue?  Only if autograd hands back
         # exactly the tensor that conv wrote (no other gradient was accumulated on top of it)
-        fused, ext_partial, coef5 = None, None, None
+        fused, ext_partial = None, None
         if ctx.rec is not None:
             fused, ctx.rec.fused = ctx.rec.fused, None
             ctx.rec.x = None
         if fused is not None and fused[0].data_ptr() == dy.data_ptr() and fused[0].shape == dy.shape \
                 and dy.is_contiguous(memory_format=CL):
-            ext_partial, coef5 = fused[1], fused[2]      # (coef5: the consumer's launch also finalised the sums, csrc/bn_tail.h)
+            ext_partial = fused[1]
         dy = _nhwc(dy)
         N, C, H, W = x.shape
         M = N * H * W
         dx = torch.empty_like(x, memory_format=CL)
         want_res = ctx.has_res and ctx.needs_input_grad[3]
-        FUSE_COUNTS['bn_bwd_fused' if (ext_partial is not None or coef5 is not None) else 'bn_bwd_unfused'] += 1
-        if ext_partial is not None or coef5 is not None:
+        FUSE_COUNTS['bn_bwd_fused' if ext_partial is not None else 'bn_bwd_unfused'] += 1
+        if ext_partial is not None:
             return BatchNormActFn._backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx,
-                                                  want_res, ext_partial, M, C, coef5)
+                                                  want_res, ext_partial, M, C)
         # identity shortcut with a saved bit mask: the residual gradient dy*mask is NOT written here;
         # (dy, mask) is parked for the block's first conv, whose dgrad epilogue applies the mask
         defer_res = want_res and ctx.relu and mask is not None and ctx.link is not None \
@@ -860,11 +774,10 @@ class BatchNormActFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
-    def _backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx, want_res, ext_partial, M, C, coef5=None):
+    def _backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx, want_res, ext_partial, M, C):
         """Second half of the backward when the consumer conv's dgrad epilogue has already masked dy
         and reduced it: dgamma/dbeta from the partials, then one apply pass.  The residual gradient
-        is dy itself.  coef5: that launch also FINALISED the sums (A | B1 | B2 | sum(dy) | sum(dy xhat)): no finalise launch
-        here -- the apply pass (or, for a folded layer, the conv's image launch) adds the two raw sums to dbeta / dgamma."""
+        is dy itself."""
         pg, pb = ctx.params
         gg, gb = _arena_grad(pg), _arena_grad(pb)
         direct = gg is not None and gb is not None
@@ -873,38 +786,23 @@ class BatchNormActFn(torch.autograd.Function):
         else:
             dg_buf = dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             db_buf = dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(bn_sizes(M, C, _dtype_code(x))[0], x.device)
         fold = ctx.fold
-        written = True
         if fold is not None and fold.ok:
             # the apply pass is folded into the backward of the 1x1 conv that produced x (FoldRecord): finalise only, and
             # hand dy itself on as that conv's incoming "gradient"
-            if coef5 is not None:
-                coef = coef5
-                if direct:
-                    fold.commit = (dg_buf, db_buf, pg, pb)        # written by the conv's image launch (Conv2dFn.backward)
-                    written = False
-                else:
-                    # gradients that autograd accumulates itself must be complete when this node returns: one small launch
-                    check(lib.cnk_bn_bwd_apply_coef(None, None, _p(coef5), None, None, None, _p(dg_buf), _p(db_buf), 0, M, C,
-                                                    _dtype_code(x), _stream()))
-            else:
-                ws = workspace(bn_sizes(M, C, _dtype_code(x))[0], x.device)
-                coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
-                check(lib.cnk_bn_bwd_coef(None, None, _p(ext_partial), ext_partial.shape[0], _p(gamma), _p(save_mean), _p(save_invstd),
-                                          _p(dg_buf), _p(db_buf), int(direct), _p(coef), M, C, _dtype_code(x), _p(ws), ws.numel(),
-                                          _stream()))
+            coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+            check(lib.cnk_bn_bwd_coef(None, None, _p(ext_partial), ext_partial.shape[0], _p(gamma), _p(save_mean), _p(save_invstd),
+                                      _p(dg_buf), _p(db_buf), int(direct), _p(coef), M, C, _dtype_code(x), _p(ws), ws.numel(),
+                                      _stream()))
             fold.g, fold.y, fold.mean, fold.invstd, fold.coef = dy, x, save_mean, save_invstd, coef
             dx = dy
-        elif coef5 is not None:
-            check(lib.cnk_bn_bwd_apply_coef(_p(dy), _p(x), _p(coef5), _p(save_mean), _p(save_invstd), _p(dx), _p(dg_buf), _p(db_buf),
-                                            int(direct), M, C, _dtype_code(x), _stream()))
         else:
-            ws = workspace(bn_sizes(M, C, _dtype_code(x))[0], x.device)
             check(lib.cnk_bn_bwd(_p(dy), _p(x), None, None, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
                                  _p(dx), None, _p(dg_buf), _p(db_buf), int(direct), _p(ext_partial),
                                  ext_partial.shape[0], M, C, int(ctx.relu), _dtype_code(x), _p(ws), ws.numel(),
                                  _stream()))
-        if direct and written:
+        if direct:
             _grad_written(pg)
             _grad_written(pb)
         dres = None
@@ -953,25 +851,20 @@ class BatchNormActMaxPoolFn(torch.autograd.Function):
         x = _nhwc(x)
         N, C, H, W = x.shape
         M = N * H * W
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
         if partial is not None and partial.numel() == 0:
             partial = None
-        if partial is not None and partial.dim() == 2:
-            # finalised by the producing conv's own launch (Conv2dFn.forward, bn_final): save_mean | save_invstd | scale | shift
-            save_mean, save_invstd = partial[0], partial[1]
-            scale, shift = ctypes.c_void_p(partial.data_ptr() + 8 * C), ctypes.c_void_p(partial.data_ptr() + 12 * C)
-        else:
-            save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
-            save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-            ws = workspace(lib.cnk_bn_workspace_bytes(M, C), x.device)
-            nsl = 0 if partial is None else partial.shape[0]
-            check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), None, None, None, _p(running_mean), _p(running_var),
-                                       _p(save_mean), _p(save_invstd), _p(partial), nsl, M, C, eps, momentum, int(relu),
-                                       _dtype_code(x), _p(ws), ws.numel(), _stream()))
-            scale, shift = ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(ws.data_ptr() + 4 * C)   # left there by the BN call
+        nsl = 0 if partial is None else partial.shape[0]
+        check(lib.cnk_bn_fwd_train(_p(x), _p(gamma), _p(beta), None, None, None, _p(running_mean), _p(running_var),
+                                   _p(save_mean), _p(save_invstd), _p(partial), nsl, M, C, eps, momentum, int(relu),
+                                   _dtype_code(x), _p(ws), ws.numel(), _stream()))
         Ho = (H + 2 * padding[0] - ksize[0]) // stride[0] + 1
         Wo = (W + 2 * padding[1] - ksize[1]) // stride[1] + 1
         y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=CL)
         idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        scale, shift = ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(ws.data_ptr() + 4 * C)   # left there by the BN call
         # stride-2 pools whose backward gathers through <= 2 x 2 windows: the pooling pass also keeps the INPUT value at every
         # arg-max (a quarter of x), and the backward's reduction pass then reads that and the pooled gradient instead of
         # gathering over all of x (cnk_bn_bwd_maxpool_kept)

@@ -137,58 +137,11 @@ typedef struct cnk_bn_bwd_fuse {
     const uint8_t* relu_mask;
     float* partial;
     int32_t relu;
-    /* round 5 (all three NULL: off): the data gradient's last workgroups also FINALISE the partial sums -- see "In-kernel
-     * finalisation" below -- into final_coef[5][Cin] = A | B1 | B2 | sum(dx') | sum(dx' xhat) (fp32); needs gamma.
-     * cnk_bn_bwd_apply_coef / cnk_conv2d_bnfold_prepare then take the coefficients as they are: no finalise launch. */
-    float* final_coef;
-    uint32_t* final_tickets;
-    float* final_scratch;
 } cnk_bn_bwd_fuse;
 int64_t cnk_conv2d_dgrad_bn_slices(const cnk_conv_desc* d);
 int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                      const void* addend, const uint8_t* addend_mask, const cnk_bn_bwd_fuse* bn,
                      void* workspace, size_t workspace_bytes, void* stream);
-
-/* In-kernel finalisation of BN partial lists (round 5; csrc/bn_tail.h).  The partial lists above used to be merged by a
- * dependent ~6-14 us launch in front of every BN pass (cnk_bn_fwd_train / cnk_bn_bwd called with partials): 120 launches per
- * ResNet-50 step on the critical path (conv2d_block chains, basemodel.py:999-1015; BatchNorm2d at :1008).  The conv kernel
- * can merge its own list instead -- "the last workgroup to arrive merges", two levels, fixed summation order (bit-reproducible
- * run to run; NOT bit-identical to the separate finalise kernels: another merge tree):
- *   forward   cnk_conv2d_fwd_bn_final: as cnk_conv2d_fwd with bn_partial, and the BatchNorm2d behind the conv is finalised by
- *             the launch: save_mean, save_invstd, the running statistics' momentum update, scale_shift[2][Cout]; the apply
- *             pass is then cnk_bn_fwd_apply (no statistics work at all);
- *   backward  cnk_conv2d_dgrad / cnk_conv2d_dgrad_bnfold with cnk_bn_bwd_fuse.final_coef set; the apply pass is then
- *             cnk_bn_bwd_apply_coef (or, for a folded layer, cnk_conv2d_bnfold_prepare straight from final_coef), which also
- *             adds the two raw sums to dbeta / dgamma.
- * cnk_conv2d_bn_final_scratch_bytes(d, pass): bytes of `scratch` for pass CNK_PASS_FWD / CNK_PASS_DGRAD; 0 = this conv pass
- * cannot finalise (the ping-pong 3x3 core, strided data gradients, small-channel kernels): use the partial-list entry points.
- * tickets: cnk_bn_final_ticket_bytes() bytes that are ZERO before the first use; every counter is reset by the launch
- * that used it, so ONE buffer serves all calls of one stream (calls that may run concurrently need separate buffers). */
-typedef struct cnk_bn_fwd_final {
-    const float* gamma;
-    const float* beta;
-    float* running_mean;       /* may be NULL together with running_var */
-    float* running_var;
-    float* save_mean;          /* out [Cout] */
-    float* save_invstd;        /* out [Cout] */
-    float* scale_shift;        /* out [2][Cout] */
-    float eps, momentum;
-    uint32_t* tickets;
-    float* scratch;
-} cnk_bn_fwd_final;
-size_t cnk_bn_final_ticket_bytes(void);
-size_t cnk_conv2d_bn_final_scratch_bytes(const cnk_conv_desc* d, int pass);
-int cnk_conv2d_fwd_bn_final(const cnk_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
-                            float* bn_partial, const cnk_bn_fwd_final* fin, void* stream);
-/* y = act( x*scale + shift [+ residual] ), residual optionally round_dtype(r * rscale + rshift) (a deferred projection-shortcut
- * BN, cnk_bn_fwd_train_res_affine): the apply pass of cnk_bn_fwd_train alone, from finalised coefficients. */
-int cnk_bn_fwd_apply(const void* x, const float* scale_shift, const void* residual, const float* residual_scale_shift,
-                     void* y, uint8_t* relu_mask, int64_t M, int32_t C, int relu, int dtype, void* stream);
-/* dx = A (dy - B1 - (x - mean) invstd B2) from coef5 = A | B1 | B2 | sum(dy) | sum(dy xhat) (dy already masked: the fused
- * path), and dbeta / dgamma (+)= the two sums: the apply pass of cnk_bn_bwd alone.  dx == NULL: only the sums are committed
- * (a folded layer whose gradients are not accumulated in place). */
-int cnk_bn_bwd_apply_coef(const void* dy, const void* x, const float* coef5, const float* save_mean, const float* save_invstd,
-                          void* dx, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, int dtype, void* stream);
 
 /* dw[Cout][Cin][kh][kw] (fp32) = sum over N,Ho,Wo of dy * x ; dbias[Cout] = sum dy (may be NULL).
  * accumulate != 0 adds into dw/dbias (torch's .grad accumulation), else overwrites.
@@ -286,11 +239,6 @@ int cnk_bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int
                     float* coef, int64_t M, int32_t C, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 int cnk_conv2d_bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean,
                               const float* save_invstd, const float* coef, void* w_fold, float* bias_fold, void* stream);
-/* The same launch, also committing the BN layer's parameter gradients from an in-kernel-finalised coef5 (cnk_bn_bwd_fuse
- * .final_coef): dbeta / dgamma (+)= coef5[3][.] / coef5[4][.] -- so a folded layer's backward needs no finalise launch. */
-int cnk_conv2d_bnfold_prepare_commit(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* save_mean,
-                                     const float* save_invstd, const float* coef5, void* w_fold, float* bias_fold,
-                                     float* dgamma, float* dbeta, int accumulate, void* stream);
 int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold,
                             const float* bias_fold, void* dx, const void* addend, const uint8_t* addend_mask,
                             const cnk_bn_bwd_fuse* bn, void* stream);

@@ -405,303 +405,3 @@ def test_train_model_with_a_collectively_built_graph_under_dp(tmp_path):
     assert r['graph']['replays'] == 4                                   # two full-size batches x two epochs; the small one ran eagerly
     assert r['graph']['epochs'] == r['eager']['epochs']                 # (epoch loss, epoch accuracy)
     assert torch.equal(r['graph']['flat_p'], r['eager']['flat_p'])
-
-
-# ---- in-kernel finalisation of BN partial lists (csrc/bn_tail.h; BatchNorm2d at /root/reference/src/basemodel.py:1008 behind the conv of
-# conv2d_block, :999-1015) ------------------------------------------------------------------------------------------------------------
-# (N, Cin, Cout, H, W, k, dtype, CNK_GEMM1X1, what it exercises)
-TAIL_FWD = {
-    'gather128_2level': (64, 64, 256, 56, 56, 1, 'bf16', '1'),       # 1568 row tiles: 25 level-1 groups (the last one partial), 128-wide tiles
-    'gather64_1group': (2, 64, 64, 14, 14, 1, 'bf16', '1'),          # 4 tiles (ragged last): one group, no level 2
-    'gather64_ragged': (5, 128, 192, 9, 13, 1, 'bf16', '1'),         # odd image, 64-wide tiles, 3 column tiles
-    'edge_c24': (8, 64, 24, 14, 14, 1, 'bf16', '1'),                 # EDGE kernel: 24 of 64 columns valid
-    'ring_256x128': (64, 1024, 256, 14, 14, 1, 'bf16', '2'),         # gemm1x1_kernel (512 threads, 256-row tiles): 49 tiles
-    'ring_2level': (256, 1024, 256, 14, 14, 1, 'bf16', '2'),         # 196 tiles: 4 groups
-    'halo_f32': (8, 64, 64, 28, 28, 3, 'f32', '1'),                  # 3x3 stride 1 in fp32: the halo kernel
-    'strided3x3': (16, 128, 128, 28, 28, 3, 'bf16', '1'),            # stride 2 (forward: one launch)
-}
-
-
-def _stats_fp64(y2):
-    m = y2.double().mean(0)
-    v = ((y2.double() - m) ** 2).mean(0)
-    return m, v
-
-
-@pytest.mark.parametrize('case', sorted(TAIL_FWD))
-def test_conv_forward_finalises_the_bn_behind_it(case):
-    """cnk_conv2d_fwd_bn_final against the partial-list path (cnk_conv2d_fwd + cnk_bn_fwd_train with y == NULL) and against fp64
-    statistics of the stored output: save_mean / save_invstd / scale | shift / running statistics; the conv output itself and
-    the partial list are bit-identical; five repeats with a busy second stream give the same bits; every ticket is back at zero."""
-    from convnets_amd import ops
-    _lib, lib, cnt = _lib_and_counter()
-    N, Cin, Cout, H, W, k, dt, g1 = TAIL_FWD[case]
-    stride = 2 if case == 'strided3x3' else 1
-    tdt = torch.bfloat16 if dt == 'bf16' else torch.float32
-    code = _lib.CNK_BF16 if dt == 'bf16' else _lib.CNK_F32
-    dev = 'cuda'
-    gen = torch.Generator(device=dev).manual_seed(len(case))
-    x = (torch.randn(N, H, W, Cin, generator=gen, device=dev) + 0.3).to(tdt).permute(0, 3, 1, 2)
-    w = torch.randn(Cout, Cin, k, k, generator=gen, device=dev) / math.sqrt(Cin * k * k)
-    d = ops.make_desc(x.shape, w.shape, (stride, stride), (k // 2, k // 2), code)
-    w_fwd = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_FWD), dtype=torch.uint8, device=dev)
-    _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(w), P(w_fwd), None, _st()))
-    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
-    M = N * Ho * Wo
-    gamma, beta = 0.5 + torch.rand(Cout, generator=gen, device=dev), 0.1 * torch.randn(Cout, generator=gen, device=dev)
-    tickets = torch.zeros(lib.cnk_bn_final_ticket_bytes(), dtype=torch.uint8, device=dev)
-    side = torch.cuda.Stream()
-    big = torch.randn(64 << 20, device=dev)
-    with _lib.switches(CNK_GEMM1X1=g1):
-        nsc = lib.cnk_conv2d_bn_final_scratch_bytes(ctypes.byref(d), _lib.PASS_FWD)
-        assert nsc > 0, 'this shape should finalise in its epilogue'
-        slices = lib.cnk_conv2d_fwd_bn_partial_slices(ctypes.byref(d))
-        # ---- reference: partial list + the separate finalise
-        y_a = torch.empty((N, Cout, Ho, Wo), dtype=tdt, device=dev, memory_format=CL)
-        part_a = torch.zeros(slices, Cout, 3, device=dev)
-        _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(x), P(w_fwd), None, P(y_a), P(part_a), None, 0, _st()))
-        nws = lib.cnk_bn_workspace_bytes(M, Cout)
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        rm_a, rv_a = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-        sm_a, si_a = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
-        _lib.check(lib.cnk_bn_fwd_train(None, P(gamma), P(beta), None, None, None, P(rm_a), P(rv_a), P(sm_a), P(si_a), P(part_a), slices, M, Cout,
-                                        1e-5, 0.1, 0, code, P(ws), nws, _st()))
-        ss_a = ws[:8 * Cout].view(torch.float32).clone()
-        # ---- in-kernel
-        outs = []
-        for rep in range(5):
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(4):
-                    big.mul_(1.0001)
-            y_b = torch.empty_like(y_a, memory_format=CL)
-            part_b = torch.zeros(slices, Cout, 3, device=dev)
-            scratch = torch.full((nsc // 4,), float('nan'), device=dev)
-            rm_b, rv_b = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-            pack = torch.full((4, Cout), float('nan'), device=dev)
-            fin = _lib.BnFwdFinal(gamma.data_ptr(), beta.data_ptr(), rm_b.data_ptr(), rv_b.data_ptr(), pack.data_ptr(),
-                                  pack.data_ptr() + 4 * Cout, pack.data_ptr() + 8 * Cout, 1e-5, 0.1, tickets.data_ptr(), scratch.data_ptr())
-            _lib.check(lib.cnk_conv2d_fwd_bn_final(ctypes.byref(d), P(x), P(w_fwd), None, P(y_b), P(part_b), ctypes.byref(fin), _st()))
-            torch.cuda.synchronize()
-            outs.append((y_b, part_b, pack, rm_b, rv_b))
-            assert int(tickets.view(torch.int32).abs().max()) == 0, 'a ticket counter was not reset'
-    y_b, part_b, pack, rm_b, rv_b = outs[0]
-    for o in outs[1:]:
-        assert all(torch.equal(a, b) for a, b in zip(o, outs[0])), 'repeats differ'
-    assert torch.equal(y_b, y_a) and torch.equal(part_b, part_a)
-    assert bool(torch.isfinite(pack).all())
-    y2 = y_a.permute(0, 2, 3, 1).reshape(M, Cout)
-    m64, v64 = _stats_fp64(y2)
-    scale = float(m64.abs().max()) + float(v64.sqrt().max())
-    assert float((pack[0].double() - m64).abs().max()) / scale < 2e-6
-    assert float((pack[1].double() * torch.sqrt(v64 + 1e-5) - 1).abs().max()) < 2e-5
-    # against the separate finalise: the same numbers up to fp32 summation order
-    assert float((pack[0] - sm_a).abs().max()) / scale < 2e-6
-    assert float((pack[1] / si_a - 1).abs().max()) < 2e-5
-    assert float((pack[2:4].reshape(-1) - ss_a).abs().max()) / float(ss_a.abs().max()) < 2e-5
-    assert float((rm_b - rm_a).abs().max()) / scale < 2e-6 and float((rv_b / rv_a - 1).abs().max()) < 2e-5
-    # scale | shift are what the saved statistics say
-    sc = gamma * pack[1]
-    assert torch.equal(pack[2], sc) and torch.equal(pack[3], beta - pack[0] * sc)
-
-
-def test_bn_fwd_apply_equals_the_apply_pass_of_bn_fwd_train():
-    """cnk_bn_fwd_apply (coefficients finalised elsewhere) writes what cnk_bn_fwd_train's own apply pass writes from the same
-    scale | shift: output and packed ReLU mask bit for bit -- with a residual, with a residual whose BN was deferred, without."""
-    _lib, lib, cnt = _lib_and_counter()
-    dev = 'cuda'
-    for tdt, code in ((torch.bfloat16, _lib.CNK_BF16), (torch.float32, _lib.CNK_F32)):
-        for has_res, raff, relu in ((True, False, 1), (True, True, 1), (False, False, 1), (False, False, 0)):
-            gen = torch.Generator(device=dev).manual_seed(3)
-            M, C = 5 * 9 * 13, 192
-            x = torch.randn(M, C, generator=gen, device=dev).to(tdt)
-            res = torch.randn(M, C, generator=gen, device=dev).to(tdt) if has_res else None
-            rcoef = torch.cat([0.5 + torch.rand(C, generator=gen, device=dev), 0.1 * torch.randn(C, generator=gen, device=dev)]) if raff else None
-            gamma, beta = 0.5 + torch.rand(C, generator=gen, device=dev), 0.1 * torch.randn(C, generator=gen, device=dev)
-            nws, nmask = lib.cnk_bn_workspace_bytes(M, C), lib.cnk_bn_mask_bytes(M, C, code)
-            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-            sm, si = torch.empty(C, device=dev), torch.empty(C, device=dev)
-            ya, yb = torch.empty_like(x), torch.full_like(x, float('nan'))
-            ma, mb = torch.zeros(nmask, dtype=torch.uint8, device=dev), torch.zeros(nmask, dtype=torch.uint8, device=dev)
-            want_mask = bool(has_res and relu)
-            if raff:
-                _lib.check(lib.cnk_bn_fwd_train_res_affine(P(x), P(gamma), P(beta), P(res), P(rcoef), P(ya), P(ma) if want_mask else None, None, None,
-                                                           P(sm), P(si), None, 0, M, C, 1e-5, 0.1, relu, code, P(ws), nws, _st()))
-            else:
-                _lib.check(lib.cnk_bn_fwd_train(P(x), P(gamma), P(beta), P(res), P(ya), P(ma) if want_mask else None, None, None, P(sm), P(si), None, 0,
-                                                M, C, 1e-5, 0.1, relu, code, P(ws), nws, _st()))
-            ss = ws[:8 * C].view(torch.float32).clone()
-            _lib.check(lib.cnk_bn_fwd_apply(P(x), P(ss), P(res), P(rcoef), P(yb), P(mb) if want_mask else None, M, C, relu, code, _st()))
-            torch.cuda.synchronize()
-            assert torch.equal(ya, yb), (tdt, has_res, raff, relu)
-            assert torch.equal(ma, mb)
-
-
-# (N, Cin, Cout, H, W, k, dtype, CNK_GEMM1X1): data gradients whose epilogue carries the backward reduction of the BN layer in front
-TAIL_BWD = {
-    'gather128_2level': (64, 256, 64, 56, 56, 1, 'bf16', '1'),       # dx has 256 channels: 1568 tiles x 2 column tiles
-    'gather64_1group': (2, 64, 64, 14, 14, 1, 'bf16', '1'),
-    'ring_mode2': (64, 256, 1024, 14, 14, 1, 'bf16', '1'),           # K = 1024: the ring GEMM's data-gradient epilogue
-    'halo3x3_bf16': (96, 128, 128, 28, 28, 3, 'bf16', '1'),          # 588 tiles > 256: the fused 3x3 gradient stays on the halo kernel
-    'halo3x3_f32': (8, 64, 64, 14, 14, 3, 'f32', '1'),
-}
-
-
-@pytest.mark.parametrize('case', sorted(TAIL_BWD))
-def test_conv_dgrad_finalises_the_fused_bn_backward(case):
-    """cnk_conv2d_dgrad with cnk_bn_bwd_fuse.final_coef: coef5 = A | B1 | B2 | sum(dx') | sum(dx' xhat) against cnk_bn_bwd_coef
-    on the partial list the same launch left, and against fp64 sums of the tensor it wrote; dx and the list are bit-identical to
-    the launch without the finalisation; cnk_bn_bwd_apply_coef then equals cnk_bn_bwd's fused apply pass bit for bit given the
-    same coefficients, and commits dbeta / dgamma (accumulate on and off)."""
-    from convnets_amd import ops
-    _lib, lib, cnt = _lib_and_counter()
-    N, Cin, Cout, H, W, k, dt, g1 = TAIL_BWD[case]
-    tdt = torch.bfloat16 if dt == 'bf16' else torch.float32
-    code = _lib.CNK_BF16 if dt == 'bf16' else _lib.CNK_F32
-    dev = 'cuda'
-    gen = torch.Generator(device=dev).manual_seed(len(case) + 7)
-    M = N * H * W
-    dy = torch.randn(N, H, W, Cout, generator=gen, device=dev).to(tdt).permute(0, 3, 1, 2)
-    w = torch.randn(Cout, Cin, k, k, generator=gen, device=dev) / math.sqrt(Cout * k * k)
-    xs = (N, Cin, H, W)
-    d = ops.make_desc(xs, w.shape, (1, 1), (k // 2, k // 2), code)
-    w_dgrad = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_DGRAD), dtype=torch.uint8, device=dev)
-    _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(w), None, P(w_dgrad), _st()))
-    u = (torch.randn(N, H, W, Cin, generator=gen, device=dev) * 1.2 + 0.1).to(tdt).permute(0, 3, 1, 2)       # the BN layer's input
-    mean2 = 0.1 * torch.randn(Cin, generator=gen, device=dev)
-    invstd2 = 0.8 + 0.4 * torch.rand(Cin, generator=gen, device=dev)
-    gamma2 = 0.5 + torch.rand(Cin, generator=gen, device=dev)
-    beta2 = 0.1 * torch.randn(Cin, generator=gen, device=dev)
-    tickets = torch.zeros(lib.cnk_bn_final_ticket_bytes(), dtype=torch.uint8, device=dev)
-    with _lib.switches(CNK_GEMM1X1=g1):
-        slices = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(d))
-        nsc = lib.cnk_conv2d_bn_final_scratch_bytes(ctypes.byref(d), _lib.PASS_DGRAD)
-        assert slices > 0 and nsc > 0
-        res = {}
-        for final in (False, True):
-            part = torch.zeros(slices, Cin, 2, device=dev)
-            coef5 = torch.full((5 * Cin,), float('nan'), device=dev)
-            scratch = torch.full((nsc // 4,), float('nan'), device=dev)
-            fuse = _lib.BnBwdFuse(u.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None, part.data_ptr(), 1,
-                                  coef5.data_ptr() if final else None, tickets.data_ptr() if final else None, scratch.data_ptr() if final else None)
-            dx = torch.empty(xs, dtype=tdt, device=dev, memory_format=CL)
-            _lib.check(lib.cnk_conv2d_dgrad(ctypes.byref(d), P(dy), P(w_dgrad), P(dx), None, None, ctypes.byref(fuse), None, 0, _st()))
-            torch.cuda.synchronize()
-            res[final] = (dx, part, coef5)
-    assert int(tickets.view(torch.int32).abs().max()) == 0
-    (dx0, part0, _), (dx1, part1, coef5) = res[False], res[True]
-    assert torch.equal(dx0, dx1) and torch.equal(part0, part1)
-    assert bool(torch.isfinite(coef5).all())
-    # the separate finalise on the same list
-    nws = lib.cnk_bn_workspace_bytes(M, Cin)
-    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    coef3 = torch.empty(3 * Cin, device=dev)
-    dg, db = torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
-    _lib.check(lib.cnk_bn_bwd_coef(None, None, P(part0), slices, P(gamma2), P(mean2), P(invstd2), P(dg), P(db), 0, P(coef3), M, Cin, code, P(ws), nws,
-                                   _st()))
-    torch.cuda.synchronize()
-    C = Cin
-    assert torch.equal(coef5[:C], coef3[:C])                                  # A = gamma * invstd
-    sref = max(float(db.abs().max()), float(dg.abs().max()), 1.0)
-    assert float((coef5[3 * C:4 * C] - db).abs().max()) / sref < 2e-5 and float((coef5[4 * C:] - dg).abs().max()) / sref < 2e-5
-    assert float((coef5[C:2 * C] - coef3[C:2 * C]).abs().max()) / (sref / M) < 2e-5
-    assert float((coef5[2 * C:3 * C] - coef3[2 * C:3 * C]).abs().max()) / (sref / M) < 2e-5
-    assert float((coef5[C:2 * C] * M - coef5[3 * C:4 * C]).abs().max()) / sref < 1e-6          # B1 = sum / M, B2 likewise
-    assert float((coef5[2 * C:3 * C] * M - coef5[4 * C:]).abs().max()) / sref < 1e-6
-    # fp64 sums of the written tensor
-    f2 = dx1.permute(0, 2, 3, 1).reshape(M, C).double()
-    u2 = u.permute(0, 2, 3, 1).reshape(M, C).double()
-    S = f2.sum(0)
-    Q = (f2 * (u2 - mean2.double())).sum(0) * invstd2.double()
-    assert float((coef5[3 * C:4 * C].double() - S).abs().max()) / sref < 5e-5 and float((coef5[4 * C:].double() - Q).abs().max()) / sref < 5e-5
-    # ---- the apply pass from coefficients: feed cnk_bn_bwd's own (coef3 + the sums it accumulated) to compare bit for bit
-    c5 = torch.cat([coef3, db, dg])
-    dx_a, dx_b = torch.empty_like(dx1), torch.full_like(dx1, float('nan'))
-    dg_a, db_a = torch.ones(C, device=dev), torch.ones(C, device=dev)
-    _lib.check(lib.cnk_bn_bwd(P(dx1), P(u), None, None, P(gamma2), P(beta2), P(mean2), P(invstd2), P(dx_a), None, P(dg_a), P(db_a), 1, P(part0), slices,
-                              M, C, 1, code, P(ws), nws, _st()))
-    for acc in (1, 0):
-        dg_b, db_b = torch.ones(C, device=dev), torch.ones(C, device=dev)
-        _lib.check(lib.cnk_bn_bwd_apply_coef(P(dx1), P(u), P(c5), P(mean2), P(invstd2), P(dx_b), P(dg_b), P(db_b), acc, M, C, code, _st()))
-        torch.cuda.synchronize()
-        assert torch.equal(dx_a, dx_b)
-        if acc:
-            assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
-        else:
-            assert torch.equal(dg_b, dg) and torch.equal(db_b, db)
-    # the sums alone (dx == NULL)
-    dg_c, db_c = torch.ones(C, device=dev), torch.ones(C, device=dev)
-    _lib.check(lib.cnk_bn_bwd_apply_coef(None, None, P(c5), None, None, None, P(dg_c), P(db_c), 1, M, C, code, _st()))
-    torch.cuda.synchronize()
-    assert torch.equal(dg_c, dg_a) and torch.equal(db_c, db_a)
-
-
-def test_folded_prepare_commits_the_bn_parameter_gradients():
-    """cnk_conv2d_bnfold_prepare_commit == cnk_conv2d_bnfold_prepare (image and bias bit for bit) + dbeta / dgamma += the two
-    raw sums behind the coefficients."""
-    from convnets_amd import ops
-    _lib, lib, cnt = _lib_and_counter()
-    dev = 'cuda'
-    gen = torch.Generator(device=dev).manual_seed(2)
-    Cin, Cout = 64, 256
-    w = torch.randn(Cout, Cin, 1, 1, generator=gen, device=dev) / 8
-    d = ops.make_desc((8, Cin, 14, 14), w.shape, (1, 1), (0, 0), _lib.CNK_BF16)
-    w_dgrad = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_DGRAD), dtype=torch.uint8, device=dev)
-    _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(w), None, P(w_dgrad), _st()))
-    mean, invstd = 0.1 * torch.randn(Cout, generator=gen, device=dev), 0.5 + torch.rand(Cout, generator=gen, device=dev)
-    coef5 = torch.randn(5 * Cout, generator=gen, device=dev)
-    nimg = lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d))
-    img_a, img_b = torch.zeros(nimg, dtype=torch.uint8, device=dev), torch.zeros(nimg, dtype=torch.uint8, device=dev)
-    b_a, b_b = torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
-    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(w), P(w_dgrad), P(mean), P(invstd), P(coef5), P(img_a), P(b_a), _st()))
-    dg, db = torch.full((Cout,), 2.0, device=dev), torch.full((Cout,), 3.0, device=dev)
-    _lib.check(lib.cnk_conv2d_bnfold_prepare_commit(ctypes.byref(d), P(w), P(w_dgrad), P(mean), P(invstd), P(coef5), P(img_b), P(b_b), P(dg), P(db), 1,
-                                                    _st()))
-    torch.cuda.synchronize()
-    assert torch.equal(img_a, img_b) and torch.equal(b_a, b_b)
-    assert torch.equal(db, 3.0 + coef5[3 * Cout:4 * Cout]) and torch.equal(dg, 2.0 + coef5[4 * Cout:])
-
-
-@pytest.mark.parametrize('mixed', [False, True])
-def test_model_step_with_and_without_the_in_kernel_finalisation(mixed):
-    """A bottleneck ResNet step with the BN partial lists finalised inside the conv launches equals the step with the separate
-    finalise launches up to fp32 summation order of the statistics (loss 1e-6; gradients: fp32 2e-4, bf16 -- where a rounding-
-    level change of a mean can flip ReLU masks -- the well-conditioned net's bound); the finalisation actually ran, in
-    both directions, and two runs with it give the same bits."""
-    import convnets_amd as ca
-    from convnets_amd import ops
-    from oracle import torch_ref as tr
-    prev, prev_min = ops.BN_TAIL, ops.BN_FOLD_MIN_ELEMS
-    ops.BN_FOLD_MIN_ELEMS = 0
-    res = []
-    try:
-        for tail in (True, False, True):
-            ops.BN_TAIL = tail
-            torch.manual_seed(21)
-            s = ca.Settings(kind=26, input_size=(3, 64, 64), num_classes=10, batch_size=32, dropout_rate=0, mixed_precision=mixed, device='cuda:0')
-            model = ca.ResNet(s)
-            tr.damp_residual_branches(model, 0.1)
-            model = model.cuda()
-            model.init_optimizer()
-            model.train()
-            x, y = tr.synthetic_batch(32, (3, 64, 64), 10, seed=21)
-            ops.TAIL_COUNTS.update(fwd=0, bwd=0)
-            loss, _ = model.train_batch((x, y))
-            torch.cuda.synchronize()
-            res.append((float(loss), model.optimizer.flat_g.clone(), {k: b.clone() for k, b in model.named_buffers()}, dict(ops.TAIL_COUNTS)))
-    finally:
-        ops.BN_TAIL, ops.BN_FOLD_MIN_ELEMS = prev, prev_min
-    (l1, g1, b1, c1), (l0, g0, b0, c0), (l2, g2, b2, c2) = res
-    assert c0 == {'fwd': 0, 'bwd': 0} and c1['fwd'] >= 15 and c1['bwd'] >= 10, c1
-    assert l1 == l2 and torch.equal(g1, g2), 'two runs with the in-kernel finalisation differ'
-    assert abs(l1 - l0) <= (2e-3 if mixed else 1e-5) * abs(l0), (l1, l0)
-    err = float((g1 - g0).norm() / g0.norm())
-    print('in-kernel finalisation on vs off (%s): loss %.7f / %.7f, whole-gradient L2-rel %.3e' % ('bf16' if mixed else 'fp32', l1, l0, err))
-    # fp32: the statistics differ in their last bits, the gradients by 1e-5.  bf16: the same last-bit change of scale | shift
-    # moves elements of the stored activations across bf16 rounding boundaries (and a few ReLU inputs across zero) -- two valid
-    # roundings of this net, for which DESIGN.md section 4 has measured what that does to whole-network gradients (0.12 between
-    # the bf16 emulation and fp32 on the same damped ResNet-26); 5.5e-2 measured here
-    assert err < (1e-1 if mixed else 2e-4)
-    for k in b0:
-        if b0[k].dtype.is_floating_point:
-            assert float((b1[k] - b0[k]).abs().max()) <= 1e-5 * max(float(b0[k].abs().max()), 1.0), k
