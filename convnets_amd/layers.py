@@ -114,11 +114,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                 if defer:
                     # statistics only: y aliases x; whoever adds it as a residual normalises it on the fly
                     y._cnk_defer = holder[0]
-            self._stats_epoch = getattr(self, '_stats_epoch', 0) + 1     # running statistics changed
-            if self._deferred_counter is not None:
-                self._deferred_counter[0] += 1        # flushed for all BN layers at once by the model
-            else:
-                self.num_batches_tracked += 1
+            self._after_training_forward()
             return y
         if residual is not None and getattr(residual, '_cnk_defer', None) is not None:
             #  the residual is a projection shortcut's UN-normalised conv output whose BN apply pass was left to
@@ -128,6 +124,18 @@ class BatchNorm2d(nn.BatchNorm2d):
                                'the shortcut block without defer_apply')
         return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var,
                                    float(self.eps), residual, relu)
+
+
+def _bn_after_training_forward(self):
+    """Book-keeping of one training-mode forward (also called by ConvBlock when conv + BN ran as one node)."""
+    self._stats_epoch = getattr(self, '_stats_epoch', 0) + 1     # running statistics changed
+    if self._deferred_counter is not None:
+        self._deferred_counter[0] += 1        # flushed for all BN layers at once by the model
+    else:
+        self.num_batches_tracked += 1
+
+
+BatchNorm2d._after_training_forward = _bn_after_training_forward
 
 
 class ReLU(nn.ReLU):
@@ -280,6 +288,7 @@ class SKConv(nn.Module):
 
 import os as _os
 DEFER_SHORTCUT_BN = _os.environ.get('CNK_DEFER_SHORTCUT_BN', '1') != '0'      # A/B switch
+FUSED_BLOCK_NODE = _os.environ.get('CNK_FUSED_BLOCK_NODE', '1') != '0'        # A/B switch: conv + BN of a ConvBlock as one autograd node
 
 
 class ConvBlock(nn.Sequential):
@@ -305,12 +314,31 @@ class ConvBlock(nn.Sequential):
                 # (fold: the BN backward's apply pass runs inside this conv's backward where the shape allows, ops.FoldRecord)
                 fold = ops.FoldRecord() if (ops.BN_FOLD and torch.is_grad_enabled()
                                             and isinstance(conv, Conv2d) and conv.kernel_size == (1, 1)) else None
-                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold)
                 pool = self._linked_pool()
+                defer = bool(defer_apply and not act and residual is None and torch.is_grad_enabled() and DEFER_SHORTCUT_BN)
+                if FUSED_BLOCK_NODE and pool is None and torch.is_grad_enabled() and self._one_node_ok(conv, bn, x):
+                    # conv -> BN (-> ReLU, + residual) as ONE autograd node (ops.ConvBnActFn): the same kernels in the same
+                    # order, one Function.apply / autograd node / Module call chain less per block (host time of the eager step)
+                    rec = ops.BnRecord() if (x.requires_grad or conv.weight.requires_grad) and not defer else None
+                    res_affine = getattr(residual, '_cnk_defer', None) if residual is not None else None
+                    holder = [] if defer else None
+                    y = ops.ConvBnActFn.apply(
+                        x, conv.weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                        (_pair(conv.stride), _pair(conv.padding), conv._packed, in_link, getattr(x, '_cnk_bn', None), conv.groups,
+                         conv._dil, fold),
+                        (float(bn.eps), float(bn.momentum), bool(False if defer else (act or relu_after_add)),
+                         None if defer else res_link, rec, holder, res_affine))
+                    if rec is not None and rec.x is not None:
+                        y._cnk_bn = rec
+                    if defer:
+                        y._cnk_defer = holder[0]
+                    bn._after_training_forward()
+                    return y
+                y, partial = conv(x, want_bn_partial=True, link=in_link, fold=fold)
                 if pool is not None and residual is None and torch.is_grad_enabled() and y.requires_grad:
                     # conv -> BN -> ReLU -> MaxPool2d (link_block_pools): one node, the pooled tensor comes back
                     return bn(y, relu=act, partial=partial, pool=pool)
-                if defer_apply and not act and residual is None and torch.is_grad_enabled() and DEFER_SHORTCUT_BN:
+                if defer:
                     return bn(y, partial=partial, defer=True, fold=fold if (fold is not None and fold.ok) else None)
                 return bn(y, residual=residual, relu=act or relu_after_add, partial=partial,
                           link=res_link, fold=fold if (fold is not None and fold.ok) else None)
@@ -330,6 +358,18 @@ class ConvBlock(nn.Sequential):
                 y = ops.ReLUFn.apply(y)
             return ops.AddReLUFn.apply(y, residual) if relu_after_add else y + residual
         return ops.ReLUFn.apply(y) if act else y
+
+
+def _one_node_ok(self, conv, bn, x):
+    """conv + BN of this block as ONE autograd node (ops.ConvBnActFn)?  The plain implicit-GEMM path only -- and only while
+    nobody has hooked the two child modules, whose __call__ the fused node bypasses."""
+    return (isinstance(conv, Conv2d) and conv.bias is None and not conv._depthwise and not conv._dense_grouped
+            and not (conv._f32_detour and x.dtype == torch.bfloat16) and bn.affine and bn.track_running_stats
+            and bn.momentum is not None and not conv._forward_hooks and not conv._forward_pre_hooks and not conv._backward_hooks
+            and not bn._forward_hooks and not bn._forward_pre_hooks and not bn._backward_hooks)
+
+
+ConvBlock._one_node_ok = _one_node_ok
 
 
 def _applies_deferred_residual(self):

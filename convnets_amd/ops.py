@@ -141,8 +141,6 @@ def side_streams(device):
 
 
 _join_queued = [False]
-
-
 def _join_at_end_of_backward():
     """Once per backward pass: when the autograd engine has run the whole graph, the compute stream
     waits for the weight-gradient stream, so `.grad` is safe to read on the compute stream as usual."""
@@ -530,6 +528,10 @@ class Conv2dFn(torch.autograd.Function):
                                                 _p(fold.coef), _p(w_fold), _p(bias_fold), _stream()))
         # dy is complete on the compute stream HERE: the weight gradient (issued below on the second
         # stream) waits for this point only, so it also overlaps this conv's own data gradient
+        # (Round 5: every such event is a fork of the captured graph, and the compute-stream kernel behind a fork starts ~4.4 us
+        # late -- 50-odd gaps per step in the kernel timeline.  Forking once per N convs, the weight gradients in between
+        # parked, was measured: 19.09-19.30 ms at N = 1, 19.22-19.28 at 2, 19.39 at 3, 19.43 at 4, 19.5-19.7 at 8 -- the later
+        # start of the side stream costs more than the gaps; not kept.)
         dy_ready = None
         # (bf16 path only: its kernels are latency/HBM-bound and gain from sharing the chip; the fp32
         # kernels run at 65-70 % of the fp32 MFMA peak and only contend -- AlexNet fp32 lost 4 %)
@@ -587,6 +589,8 @@ class Conv2dFn(torch.autograd.Function):
             nws = ctx.plan.wgrad_ws
             min_ws = ctx.plan.wgrad_min_ws_bias if ctx.has_bias else ctx.plan.wgrad_min_ws
 
+            fy, fmean, finv, fcoef = (fold.y, fold.mean, fold.invstd, fold.coef) if fold is not None else (None,) * 4
+
             def run_wgrad(share=1.0):
                 ws = workspace(nws, x.device)
                 budget = ws.numel()
@@ -594,9 +598,9 @@ class Conv2dFn(torch.autograd.Function):
                 # kernel that does not split; cnk_conv2d_wgrad_min_workspace_bytes)
                 if share < 1.0:
                     budget = min(budget, max(min_ws, int(nws * share) // 256 * 256))
-                if fold is not None:
-                    check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fold.y), _p(x), _p(fold.mean),
-                                                      _p(fold.invstd), _p(fold.coef), _p(dw_buf), int(direct), _p(ws),
+                if fy is not None:
+                    check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fy), _p(x), _p(fmean),
+                                                      _p(finv), _p(fcoef), _p(dw_buf), int(direct), _p(ws),
                                                       budget, _stream()))
                 else:
                     check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
@@ -620,8 +624,8 @@ class Conv2dFn(torch.autograd.Function):
                         _stamp('side_end')
                 dy.record_stream(side)
                 x.record_stream(side)
-                if fold is not None:
-                    for t in (fold.y, fold.mean, fold.invstd, fold.coef):
+                if fy is not None:
+                    for t in (fy, fmean, finv, fcoef):
                         t.record_stream(side)
                 _join_at_end_of_backward()
             else:
@@ -637,8 +641,10 @@ class BatchNormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu,
-                partial=None, link=None, rec=None, fold=None, defer=None, res_affine=None):
-        """defer (a list, or None): statistics only -- the apply pass of this layer (no activation, no residual: a projection
+                partial=None, link=None, rec=None, fold=None, defer=None, res_affine=None, x_needs_grad=None):
+        """x_needs_grad: set by ConvBnActFn, whose conv half produced x inside the same node (a tensor made under the
+        Function's no_grad carries no requires_grad flag).
+        defer (a list, or None): statistics only -- the apply pass of this layer (no activation, no residual: a projection
         shortcut, resnet.py:90-91) is left to the ONE consumer of its output, the `output += identity` of the block's last
         BN; the returned tensor aliases x (un-normalised) and the layer's scale | shift [2][C] are appended to the list
         (layers.BatchNorm2d.forward attaches them to the output as `_cnk_defer`).  res_affine: such a deferred layer's
@@ -646,7 +652,8 @@ class BatchNormActFn(torch.autograd.Function):
         sequence, without writing and re-reading the normalised shortcut tensor."""
         _require_gpu(x)
         lib = _lib.load()
-        x_needs_grad = x.requires_grad
+        if x_needs_grad is None:
+            x_needs_grad = x.requires_grad
         res_needs_grad = residual is not None and residual.requires_grad
         x = _nhwc(x)
         if residual is not None:
@@ -771,7 +778,7 @@ class BatchNormActFn(torch.autograd.Function):
             # identity shortcut: park the residual gradient for the block's first conv, whose
             # dgrad epilogue adds it (falls back to a plain add if this backward is the last one)
             dres = ctx.link.contribute(lambda parked: dres if parked is None else dres + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _backward_fused(ctx, lib, dy, x, gamma, beta, save_mean, save_invstd, dx, want_res, ext_partial, M, C):
@@ -810,7 +817,63 @@ class BatchNormActFn(torch.autograd.Function):
             dres = dy
             if ctx.link is not None:
                 dres = ctx.link.contribute(lambda parked: dy if parked is None else dy + parked)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
+
+
+class _HalfCtx:
+    """The autograd-context surface Conv2dFn / BatchNormActFn use (save_for_backward, saved_tensors, needs_input_grad, free
+    attributes), for running their forward / backward bodies as the two halves of ONE node (ConvBnActFn)."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+class ConvBnActFn(torch.autograd.Function):
+    """conv -> training-mode BatchNorm2d -> [ReLU] [+ residual] of one conv2d_block (basemodel.py:999-1015; resnet.py:191-194
+    for the residual tail) as ONE autograd node.  The arithmetic is Conv2dFn's and BatchNormActFn's --
+    their forward and backward bodies run here unchanged, on two half contexts, same kernels in the same order, so results are
+    bit-identical to the two-node chain -- what goes away is host work: one Function.apply, one autograd node, one Module
+    call chain less per block in each direction (ResNet-152's eager step issues 155 such blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, conv_args, bn_args):
+        stride, padding, packed, link, bn_rec, groups, dilation, fold = conv_args
+        eps, momentum, relu, res_link, rec, defer, res_affine = bn_args
+        ctx.set_materialize_grads(False)
+        c, b = _HalfCtx(), _HalfCtx()
+        conv_needs_grad = x.requires_grad or weight.requires_grad
+        y, partial = Conv2dFn.forward(c, x, weight, None, stride, padding, packed, True, link, bn_rec, groups, dilation, fold)
+        out = BatchNormActFn.forward(b, y, gamma, beta, residual, running_mean, running_var, eps, momentum, relu, partial, res_link,
+                                     rec, fold if (fold is not None and fold.ok) else None, defer, res_affine, conv_needs_grad)
+        nc = len(c.saved_tensors)
+        ctx.save_for_backward(*(tuple(c.saved_tensors) + tuple(b.saved_tensors)))
+        c.saved_tensors = b.saved_tensors = None
+        ctx.halves = (c, b, nc)
+        if defer is not None:
+            # the BN half returned an alias of the conv output (statistics only): hand on the conv output itself
+            return y
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 9
+        c, b, nc = ctx.halves
+        st = ctx.saved_tensors
+        c.saved_tensors, b.saved_tensors = st[:nc], st[nc:]
+        need = ctx.needs_input_grad                      # x, weight, gamma, beta, residual, ...
+        b.needs_input_grad = (need[0] or need[1], need[2], need[3], need[4]) + (False,) * 12
+        gb = BatchNormActFn.backward(b, dout)
+        c.needs_input_grad = (need[0], need[1], False) + (False,) * 10
+        gc = Conv2dFn.backward(c, gb[0])
+        c.saved_tensors = b.saved_tensors = None
+        return gc[0], gc[1], gb[1], gb[2], gb[3], None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, residual=None, relu=False):

@@ -405,3 +405,54 @@ def test_train_model_with_a_collectively_built_graph_under_dp(tmp_path):
     assert r['graph']['replays'] == 4                                   # two full-size batches x two epochs; the small one ran eagerly
     assert r['graph']['epochs'] == r['eager']['epochs']                 # (epoch loss, epoch accuracy)
     assert torch.equal(r['graph']['flat_p'], r['eager']['flat_p'])
+
+
+@pytest.mark.parametrize('kind,mixed', [(26, True), (26, False), (18, True)])
+def test_conv_bn_block_as_one_autograd_node_is_bit_identical(kind, mixed):
+    """conv -> BN (-> ReLU, + residual) of a conv2d_block (/root/reference/src/basemodel.py:999-1015) as ONE
+    autograd node (ops.ConvBnActFn) runs the same kernels in the same order as the Conv2dFn -> BatchNormActFn chain: two steps
+    give the same loss, gradients, parameters and BN buffers bit for bit -- bottleneck and basic blocks, bf16 (with the folded
+    BN backward, the deferred shortcut BN, the fused reductions) and fp32 -- and the graph has fewer nodes."""
+    import convnets_amd as ca
+    from convnets_amd import layers, ops
+    from oracle import torch_ref as tr
+    prev, prev_min = layers.FUSED_BLOCK_NODE, ops.BN_FOLD_MIN_ELEMS
+    ops.BN_FOLD_MIN_ELEMS = 0
+    res = {}
+    try:
+        for fused in (True, False):
+            layers.FUSED_BLOCK_NODE = fused
+            torch.manual_seed(21)
+            s = ca.Settings(kind=kind, input_size=(3, 64, 64), num_classes=10, batch_size=16, dropout_rate=0, mixed_precision=mixed,
+                            device='cuda:0')
+            model = ca.ResNet(s).cuda()
+            model.init_optimizer()
+            model.train()
+            x, y = tr.synthetic_batch(16, (3, 64, 64), 10, seed=21)
+            ops.FOLD_COUNTS['folded'] = 0
+            ops.FUSE_COUNTS.update(bn_bwd_fused=0, bn_bwd_unfused=0)
+            losses = [float(model.train_batch((x, y))[0]) for _ in range(2)]
+            torch.cuda.synchronize()
+            # nodes of one forward graph
+            out = model(x.cuda())
+            seen, stack = set(), [out.grad_fn]
+            while stack:
+                f = stack.pop()
+                if f is None or f in seen:
+                    continue
+                seen.add(f)
+                stack.extend(g for g, _ in f.next_functions)
+            names = [type(f).__name__ for f in seen]
+            res[fused] = (losses, model.optimizer.flat_g.clone(), model.optimizer.flat_p.clone(),
+                          {k: b.clone() for k, b in model.named_buffers()}, dict(ops.FOLD_COUNTS), dict(ops.FUSE_COUNTS), names)
+            del out
+    finally:
+        layers.FUSED_BLOCK_NODE, ops.BN_FOLD_MIN_ELEMS = prev, prev_min
+    (l1, g1, p1, b1, fo1, fu1, n1), (l0, g0, p0, b0, fo0, fu0, n0) = res[True], res[False]
+    assert l1 == l0 and torch.equal(g1, g0) and torch.equal(p1, p0)
+    for k in b0:
+        assert torch.equal(b1[k], b0[k]), k
+    assert fo1 == fo0 and fu1 == fu0                                  # the same backward paths ran (fold, fused reductions)
+    nf = sum(1 for n in n1 if n.startswith('ConvBnActFn'))
+    assert nf >= 15 and sum(1 for n in n0 if n.startswith('ConvBnActFn')) == 0
+    assert len(n1) < len(n0) - 10, (len(n1), len(n0))
