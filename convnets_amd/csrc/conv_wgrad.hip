@@ -520,6 +520,10 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
     if (fold) {
         CNK_CHECK_ARG(b && !grouped && d->Cout % 64 == 0 && d->Cin % 64 == 0, "wgrad_mfma: the folded BN backward needs a dense bf16 conv on the 64-channel grid");
         p.fy = fold->y; p.fcoef = fold->coef; p.fmean = fold->mean; p.finvstd = fold->invstd;
+        // (Round 5, measured and dropped: ONE staging buffer for the 512-thread tiles -- 56 instead of 112 KiB of LDS, so that a CU
+        // holding such a workgroup could admit two implicit-GEMM workgroups of the compute stream -- 19.10 / 19.26 ms against
+        // 19.36 / 19.26: nothing.  It is the registers that decide who shares a CU: two waves per SIMD of this kernel hold 2 x 168
+        // (FOLD: 2 x 208) of the 512 VGPRs, which leaves room for ONE 120-register implicit-GEMM wave per SIMD (FOLD: none).)
         if (bmw == 256) rc = launch_wgrad<bf16, 256, 128, 4, 2, true>(p, s);
         else if (bnw == 256) rc = launch_wgrad<bf16, 128, 256, 2, 4, true>(p, s);
         else if (bmw == 128 && bnw == 128) rc = launch_wgrad<bf16, 128, 128, 2, 2, true>(p, s);

@@ -71,14 +71,15 @@ _cur_device = getattr(torch._C, '_cuda_getDevice', None)
 
 def _stream():
     # raw handle of the current stream of the current device (torch.cuda.current_stream() costs ~1 us of Python
-    # per call, a tenth of the host time of a ResNet-50 step)
+    # per call, a tenth of the host time of a ResNet-50 step); a plain int: ctypes converts it for a c_void_p parameter
+    # (0 = the null stream) without a wrapper object per call (round 5: ~2,600 pointer arguments per ResNet-152 step)
     if _raw_stream is not None and _cur_device is not None:
-        return ctypes.c_void_p(_raw_stream(_cur_device()))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(_cur_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
 def _nhwc(t):
@@ -88,14 +89,20 @@ def _nhwc(t):
 _workspaces = {}
 
 
-def workspace(nbytes, device):
+def workspace(nbytes, device, stream=None):
     """One grow-only scratch buffer per (device, stream); kernels are stream-ordered on the caller's
-    stream, so successive ops on one stream can share it (the library itself never allocates)."""
-    key = (device, _raw_stream(device.index) if (_raw_stream is not None and device.index is not None)
+    stream, so successive ops on one stream can share it (the library itself never allocates).
+    stream: the torch stream the kernels will run on when that is not the current one."""
+    key = (device, stream.cuda_stream if stream is not None else
+           _raw_stream(device.index) if (_raw_stream is not None and device.index is not None)
            else torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if stream is not None:
+            # allocated from the CURRENT stream's pool but used on `stream`: when a bigger buffer replaces this one, the
+            # allocator must not hand its memory on before that stream is done with it
+            ws.record_stream(stream)
         _workspaces[key] = ws
     return ws
 
@@ -123,7 +130,7 @@ STAMP = [None]
 def _stamp(label):
     buf, log = STAMP[0]
     if len(log) < buf.numel():
-        _lib.load().cnk_debug_stamp(ctypes.c_void_p(buf.data_ptr() + 8 * len(log)), _stream())
+        _lib.load().cnk_debug_stamp(ctypes.c_void_p(buf.data_ptr() + 8 * len(log)), ctypes.c_void_p(_stream()))      # (a test hook without argtypes)
         log.append(label)
 
 
@@ -141,6 +148,7 @@ def side_streams(device):
 
 
 _join_queued = [False]
+_dy_event = {}                                # device -> the event eager steps fork the weight-gradient stream at
 def _join_at_end_of_backward():
     """Once per backward pass: when the autograd engine has run the whole graph, the compute stream
     waits for the weight-gradient stream, so `.grad` is safe to read on the compute stream as usual."""
@@ -536,7 +544,13 @@ class Conv2dFn(torch.autograd.Function):
         # (bf16 path only: its kernels are latency/HBM-bound and gain from sharing the chip; the fp32
         # kernels run at 65-70 % of the fp32 MFMA peak and only contend -- AlexNet fp32 lost 4 %)
         if WGRAD_STREAM and x.is_cuda and x.dtype == torch.bfloat16:
-            dy_ready = torch.cuda.Event()
+            # (eager steps re-record ONE event per device: a stream's wait refers to the record it was issued behind; a
+            # capture gets an event per fork)
+            dy_ready = _dy_event.get(x.device) if CAPTURE[0] is None else None
+            if dy_ready is None:
+                dy_ready = torch.cuda.Event()
+                if CAPTURE[0] is None:
+                    _dy_event[x.device] = dy_ready
             dy_ready.record(torch.cuda.current_stream(x.device))
         if ctx.needs_input_grad[0]:
             def dgrad(addend):
@@ -591,8 +605,11 @@ class Conv2dFn(torch.autograd.Function):
 
             fy, fmean, finv, fcoef = (fold.y, fold.mean, fold.invstd, fold.coef) if fold is not None else (None,) * 4
 
-            def run_wgrad(share=1.0):
-                ws = workspace(nws, x.device)
+            def run_wgrad(share=1.0, stream=None):
+                # stream: the weight-gradient stream, WITHOUT making it torch's current stream (`with torch.cuda.stream(..)`
+                # costs ~10 us of host time per conv: 1.5 ms of a ResNet-152 step)
+                st = _stream() if stream is None else stream.cuda_stream
+                ws = workspace(nws, x.device, stream)
                 budget = ws.numel()
                 # a share of the split-K depth: never below what the library says it needs (the whole workspace for every
                 # kernel that does not split; cnk_conv2d_wgrad_min_workspace_bytes)
@@ -601,10 +618,10 @@ class Conv2dFn(torch.autograd.Function):
                 if fy is not None:
                     check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fy), _p(x), _p(fmean),
                                                       _p(finv), _p(fcoef), _p(dw_buf), int(direct), _p(ws),
-                                                      budget, _stream()))
+                                                      budget, st))
                 else:
                     check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), _p(db_buf),
-                                               int(direct), _p(ws), budget, _stream()))
+                                               int(direct), _p(ws), budget, st))
                 if direct:
                     _grad_written(weight)
                     if ctx.has_bias:
@@ -614,14 +631,14 @@ class Conv2dFn(torch.autograd.Function):
                 # the main stream without knowing about the side stream
                 side = wgrad_stream(x.device)
                 side.wait_event(dy_ready)                                    # dy, x (and zero_grad) are ready
-                if STAMP[0] is not None:
+                if STAMP[0] is not None:                                     # (tools/probe_graph_schedule.py: the slow way)
                     _stamp('main')
-                with torch.cuda.stream(side):
-                    if STAMP[0] is not None:
+                    with torch.cuda.stream(side):
                         _stamp('side_begin')
-                    run_wgrad(WGRAD_SHARE[0])
-                    if STAMP[0] is not None:
+                        run_wgrad(WGRAD_SHARE[0])
                         _stamp('side_end')
+                else:
+                    run_wgrad(WGRAD_SHARE[0], side)
                 dy.record_stream(side)
                 x.record_stream(side)
                 if fy is not None:
