@@ -209,9 +209,9 @@ def test_integration_snippet_matches_header():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The newest committed bench line (profiles/r04e_bench.json, written by `python bench.py` on an MI355X) carries every field
+    """The newest committed bench line (profiles/r05*_bench.json, written by `python bench.py` on an MI355X) carries every field
     of the bench contract with the agreed types: one JSON object, metric / config of BASELINE.json's headline, a numeric
-    roofline.traffic, the cpu_baseline object."""
+    roofline.traffic, the cpu_baseline object (round 5: timed at the metric's batch), the whole-step numbers."""
     import glob
     import json
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_bench.json')))
@@ -233,6 +233,11 @@ def test_committed_bench_line_keeps_the_contract():
     c = d['cpu_baseline']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
     assert abs(d['value'] - 256 * 1000.0 / d['ms_per_step']) / d['value'] < 1e-2     # value and ms_per_step describe the same run
+    if os.path.basename(files[-1]) >= 'r05':
+        assert c['batch'] in (256, 64) and (c['batch'] == 256 or c['batch_fallback'])
+        sl = d['step_level']
+        assert 0 < sl['step_tflops_frac'] < 1 and 0 < sl['step_hbm_frac'] < 1
+        assert abs(sl['step_tflops'] - sl['step_algorithmic_tflop'] / d['ms_per_step'] * 1e3) / sl['step_tflops'] < 1e-2
 
 
 def test_graphed_batch_dispatch_under_data_parallelism():
