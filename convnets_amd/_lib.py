@@ -40,10 +40,18 @@ _vp, _i32, _i64, _f32, _sz = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c
                               ctypes.c_size_t)
 _dp = ctypes.POINTER(ConvDesc)
 
+class WgradPending(ctypes.Structure):
+    """cnk_wgrad_pending (include/cnk.h): the slab sum a chained weight gradient left to the next launch of its stream."""
+    _fields_ = [('slab', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('slab_stride', ctypes.c_uint64)] + \
+               [(n, ctypes.c_int32) for n in ('splits', 'Cout', 'Cin', 'ntaps', 'accumulate', 'lanes')]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/cnk.h
 SIGNATURES = {
     'cnk_version': (ctypes.c_int, []),
     'cnk_last_error': (ctypes.c_char_p, []),
+    'cnk_stream_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    'cnk_stream_destroy': (ctypes.c_int, [_vp]),
     'cnk_conv2d_out_hw': (ctypes.c_int, [_dp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     'cnk_conv2d_packed_bytes': (_sz, [_dp, ctypes.c_int]),
     'cnk_conv2d_workspace_bytes': (_sz, [_dp, ctypes.c_int]),
@@ -59,7 +67,18 @@ SIGNATURES = {
     'cnk_conv2d_dgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnBwdFuse), _vp, _sz, _vp]),
     'cnk_conv2d_wgrad': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, _vp]),
     'cnk_conv2d_wgrad_min_workspace_bytes': (_sz, [_dp, ctypes.c_int]),
+    'cnk_conv2d_wgrad_chain_supported': (ctypes.c_int, [_dp]),
+    'cnk_conv2d_wgrad_chain': (ctypes.c_int, [_dp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz, ctypes.POINTER(WgradPending),
+                                              ctypes.POINTER(WgradPending), _vp]),
+    'cnk_wgrad_reduce_pending': (ctypes.c_int, [ctypes.POINTER(WgradPending), _vp]),
+    'cnk_conv2d_wgrad_bnfold_chain': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _sz,
+                                                     ctypes.POINTER(WgradPending), ctypes.POINTER(WgradPending), _vp]),
     'cnk_conv2d_bnfold_supported': (ctypes.c_int, [_dp]),
+    'cnk_conv2d_bwd_bnfold_supported': (ctypes.c_int, [_dp]),
+    'cnk_conv2d_bwd_bnfold_workspace_bytes': (_sz, [_dp]),
+    'cnk_conv2d_bwd_bnfold_bn_slices': (ctypes.c_int64, [_dp]),
+    'cnk_conv2d_bwd_bnfold': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnBwdFuse), _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+                              _vp, _sz, _vp]),
     'cnk_conv2d_bnfold_image_bytes': (_sz, [_dp]),
     'cnk_bn_bwd_coef': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _i64, _i32, ctypes.c_int, _vp,
                                        _sz, _vp]),

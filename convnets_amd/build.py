@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libcnk.so')
-SOURCES = ['api.hip', 'conv_igemm.hip', 'conv_pp.hip', 'conv_gemm1x1.hip', 'bnfold.hip', 'conv_wgrad.hip', 'conv_wgrad3.hip', 'conv_direct.hip', 'conv_smallc.hip', 'conv_rowpatch.hip', 'bn.hip', 'misc.hip', 'head.hip', 'dwconv.hip', 'sk.hip']
+SOURCES = ['api.hip', 'conv_igemm.hip', 'conv_pp.hip', 'conv_gemm1x1.hip', 'bnfold.hip', 'conv_fold3.hip', 'conv_wgrad.hip', 'conv_wgrad3.hip', 'conv_direct.hip', 'conv_smallc.hip', 'conv_rowpatch.hip', 'bn.hip', 'misc.hip', 'head.hip', 'dwconv.hip', 'sk.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-ffp-contract=off']
 
@@ -30,7 +30,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'cnk.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'wgrad_chain.h'), os.path.join(HERE, '..', 'include', 'cnk.h')]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

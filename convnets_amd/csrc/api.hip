@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wgrad_chain.h"
 
 // ---- kernel families (other translation units) ---------------------------------------------------
 bool igemm_supported(const cnk_conv_desc* d, int pass);
@@ -19,6 +20,10 @@ int64_t igemm_fwd_stat_slices(const cnk_conv_desc* d);
 int igemm_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 int igemm_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x2, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const unsigned char* addend_mask, const cnk_bn_bwd_fuse* bn, hipStream_t s);
 bool bnfold_supported(const cnk_conv_desc* d);
+bool fold3_supported(const cnk_conv_desc* d);
+int fold3_workgroups(const cnk_conv_desc* d);
+size_t fold3_workspace(const cnk_conv_desc* d);
+int fold3_bwd(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, const float* w, const float* mean, const float* invstd, const float* coef, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t bnfold_image_bytes(const cnk_conv_desc* d);
 int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s);
 int bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* sm, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, int dtype, float* ws, hipStream_t s);
@@ -60,9 +65,10 @@ int dgrad_classes(const cnk_conv_desc* d, DgradClass* out);
 bool wgrad_mfma_supported(const cnk_conv_desc* d);
 bool wgrad3x3_supported(const cnk_conv_desc* d);
 size_t wgrad3x3_workspace(const cnk_conv_desc* d);
-int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s, const WgradPending* prev = nullptr, WgradPending* out = nullptr);
+int wgrad_pending_reduce(const WgradPending& q, hipStream_t s);
 size_t wgrad_mfma_workspace(const cnk_conv_desc* d);
-int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s, const WgradFold* fold = nullptr);
+int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s, const WgradFold* fold = nullptr, const WgradPending* prev = nullptr, WgradPending* out = nullptr);
 int direct_fwd(const cnk_conv_desc* d, const void* x, const void* w_t, const float* bias, void* y, hipStream_t s);
 int direct_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend, hipStream_t s);
 size_t direct_wgrad_workspace(const cnk_conv_desc* d);
@@ -231,6 +237,22 @@ extern "C" {
 
 int cnk_version(void) { return 100; }
 const char* cnk_last_error(void) { return g_err; }
+
+int cnk_stream_create(void** stream) {
+    CNK_CHECK_ARG(stream, "cnk_stream_create: null pointer");
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    CNK_CHECK_ARG(e == hipSuccess, "cnk_stream_create: %s", hipGetErrorString(e));
+    *stream = (void*)s;
+    return 0;
+}
+
+int cnk_stream_destroy(void* stream) {
+    CNK_CHECK_ARG(stream, "cnk_stream_destroy: null pointer");
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    CNK_CHECK_ARG(e == hipSuccess, "cnk_stream_destroy: %s", hipGetErrorString(e));
+    return 0;
+}
 
 int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo) {
     const int dl = conv_dil(d);
@@ -472,6 +494,40 @@ int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, floa
     return 0;
 }
 
+// ---- chained slab sums (csrc/wgrad_chain.h): cnk_wgrad_pending is WgradPending
+int cnk_conv2d_wgrad_chain_supported(const cnk_conv_desc* d) {
+    return check_desc(d, "cnk_conv2d_wgrad_chain_supported") == 0 && conv_groups(d) == 1 && d->Cin % 4 == 0 &&
+           (wgrad3x3_supported(d) || wgrad_mfma_supported(d));
+}
+
+int cnk_conv2d_wgrad_chain(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* workspace, size_t workspace_bytes, const cnk_wgrad_pending* prev, cnk_wgrad_pending* out, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_wgrad_chain")) return rc;
+    CNK_CHECK_ARG(dy && x && dw && out, "cnk_conv2d_wgrad_chain: null pointer");
+    CNK_CHECK_ARG(cnk_conv2d_wgrad_chain_supported(d), "cnk_conv2d_wgrad_chain: this conv has no chained slab sum (cnk_conv2d_wgrad_chain_supported == 0)");
+    const size_t least = cnk_conv2d_wgrad_min_workspace_bytes(d, 0);
+    CNK_CHECK_ARG(workspace && workspace_bytes >= least, "cnk_conv2d_wgrad_chain: workspace too small (%zu < %zu)", workspace_bytes, least);
+    if (prev && prev->slab) {
+        const char* a0 = (const char*)prev->slab; const char* a1 = a0 + (size_t)prev->splits * prev->slab_stride * sizeof(float);
+        const char* b0 = (const char*)workspace; const char* b1 = b0 + workspace_bytes;
+        CNK_CHECK_ARG(a1 <= b0 || b1 <= a0, "cnk_conv2d_wgrad_chain: the pending slabs overlap this call's workspace");
+    }
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    ProfScope ps(conv_cls(d, 2), S(stream), fl, by);
+    const bool w3 = wgrad3x3_supported(d);
+    const size_t planned = w3 ? wgrad3x3_workspace(d) : wgrad_mfma_workspace(d);
+    const size_t avail = workspace_bytes & ~(size_t)255;
+    const size_t a = avail < planned ? avail : planned;
+    const WgradPending* pv = reinterpret_cast<const WgradPending*>(prev);
+    WgradPending* po = reinterpret_cast<WgradPending*>(out);
+    return w3 ? wgrad3x3(d, dy, x, dw, accumulate, workspace, a, S(stream), pv, po) : wgrad_mfma(d, dy, x, dw, accumulate, workspace, a, S(stream), nullptr, pv, po);
+}
+
+int cnk_wgrad_reduce_pending(const cnk_wgrad_pending* pending, void* stream) {
+    CNK_CHECK_ARG(pending, "cnk_wgrad_reduce_pending: null pointer");
+    return wgrad_pending_reduce(*reinterpret_cast<const WgradPending*>(pending), S(stream));
+}
+
 int cnk_conv2d_bnfold_supported(const cnk_conv_desc* d) {
     return check_desc(d, "cnk_conv2d_bnfold_supported") == 0 && bnfold_supported(d) && igemm_supported(d, CNK_PASS_DGRAD) &&
            wgrad_mfma_supported(d);
@@ -539,6 +595,52 @@ int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y
     const size_t avail = workspace_bytes & ~(size_t)255;
     const WgradFold fold = {y, coef, save_mean, save_invstd};
     return wgrad_mfma(d, g, x, dw, accumulate, workspace, avail < planned ? avail : planned, S(stream), &fold);
+}
+
+int cnk_conv2d_wgrad_bnfold_chain(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, const cnk_wgrad_pending* prev, cnk_wgrad_pending* out, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_wgrad_bnfold_chain")) return rc;
+    CNK_CHECK_ARG(cnk_conv2d_bnfold_supported(d) && cnk_conv2d_wgrad_chain_supported(d), "cnk_conv2d_wgrad_bnfold_chain: this conv shape has no folded BN backward with a chained slab sum");
+    CNK_CHECK_ARG(g && y && x && save_mean && save_invstd && coef && dw && out, "cnk_conv2d_wgrad_bnfold_chain: null pointer");
+    const size_t slab = ((size_t)d->Cout * d->Cin * sizeof(float) + 255) & ~(size_t)255;
+    CNK_CHECK_ARG(workspace && workspace_bytes >= slab, "cnk_conv2d_wgrad_bnfold_chain: workspace too small (%zu < %zu)", workspace_bytes, slab);
+    if (prev && prev->slab) {
+        const char* a0 = (const char*)prev->slab; const char* a1 = a0 + (size_t)prev->splits * prev->slab_stride * sizeof(float);
+        const char* b0 = (const char*)workspace; const char* b1 = b0 + workspace_bytes;
+        CNK_CHECK_ARG(a1 <= b0 || b1 <= a0, "cnk_conv2d_wgrad_bnfold_chain: the pending slabs overlap this call's workspace");
+    }
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    {
+        int Ho, Wo;
+        cnk_conv2d_out_hw(d, &Ho, &Wo);
+        by += (double)d->N * Ho * Wo * d->Cout * esize(d->dtype);
+    }
+    ProfScope ps(conv_cls(d, 2), S(stream), fl, by);
+    const size_t planned = wgrad_mfma_workspace(d);
+    const size_t avail = workspace_bytes & ~(size_t)255;
+    const WgradFold fold = {y, coef, save_mean, save_invstd};
+    return wgrad_mfma(d, g, x, dw, accumulate, workspace, avail < planned ? avail : planned, S(stream), &fold,
+                      reinterpret_cast<const WgradPending*>(prev), reinterpret_cast<WgradPending*>(out));
+}
+
+// ---- folded data gradient + weight gradient in one pass (conv_fold3.hip)
+int cnk_conv2d_bwd_bnfold_supported(const cnk_conv_desc* d) {
+    return check_desc(d, "cnk_conv2d_bwd_bnfold_supported") == 0 && fold3_supported(d) && cnk_conv2d_bnfold_supported(d);
+}
+
+size_t cnk_conv2d_bwd_bnfold_workspace_bytes(const cnk_conv_desc* d) { return cnk_conv2d_bwd_bnfold_supported(d) ? fold3_workspace(d) : 0; }
+
+int64_t cnk_conv2d_bwd_bnfold_bn_slices(const cnk_conv_desc* d) { return cnk_conv2d_bwd_bnfold_supported(d) ? fold3_workgroups(d) : 0; }
+
+int cnk_conv2d_bwd_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, const float* w, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d, "cnk_conv2d_bwd_bnfold")) return rc;
+    CNK_CHECK_ARG(cnk_conv2d_bwd_bnfold_supported(d), "cnk_conv2d_bwd_bnfold: this conv shape has no one-pass folded backward (cnk_conv2d_bwd_bnfold_supported == 0)");
+    CNK_CHECK_ARG(g && x && w_fold && bias_fold && dx && w && save_mean && save_invstd && coef && dw, "cnk_conv2d_bwd_bnfold: null pointer");
+    CNK_CHECK_ARG(!bn || (bn->x && bn->mean && bn->invstd && bn->gamma && bn->beta && bn->partial), "cnk_conv2d_bwd_bnfold: incomplete cnk_bn_bwd_fuse");
+    double fl, by;
+    conv_cost(d, &fl, &by);
+    ProfScope ps(conv_cls(d, 1), S(stream), 2.0 * fl, by);
+    return fold3_bwd(d, g, x, w_fold, bias_fold, dx, bn, w, save_mean, save_invstd, coef, dw, accumulate, workspace, workspace_bytes, S(stream));
 }
 
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(M, C); }

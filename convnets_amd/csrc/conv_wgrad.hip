@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "wgrad_chain.h"
 
 namespace {
 
@@ -33,6 +34,7 @@ struct WgradParams {
     const float* fcoef;     // [3][Cout]: A = gamma * invstd, B1 = mean(dy), B2 = mean(dy * xhat)  (cnk_bn_bwd_coef)
     const float* fmean;
     const float* finvstd;
+    WgradPending prev;      // the slab sum of the PREVIOUS weight gradient of this stream, done in this launch's prologue (wgrad_chain.h)
 };
 
 template <typename T> struct WgCfg;
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NBUF != 2) ? 3 : 2) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                      // [NBUF][KP][ROWA]
     unsigned char* Bs = smem + NBUF * KP * ROWA;   // [NBUF][KP][ROWB]
+    wgrad_pending_sum<NT>(p.prev);                 // (nothing pending: one uniform branch)
 
     // XCD-aware order: blocks b, b+8, ... share an XCD (and its L2).  Give each XCD a contiguous run
     // of logical ids so the workgroups of ONE pixel split -- which re-read the same dy / x rows for
@@ -408,6 +411,21 @@ int launch_wgrad_reduce(const float* slab, float* dw, int splits, size_t slab_st
     return 0;
 }
 
+// the last sum of a chain (nothing launches behind it): the same device function on a launch of its own
+namespace {
+__global__ __launch_bounds__(256) void wgrad_pending_kernel(const WgradPending q) { wgrad_pending_sum<256>(q); }
+}  // namespace
+int wgrad_pending_reduce(const WgradPending& q, hipStream_t s) {
+    if (!q.slab) return 0;
+    const size_t lanes = (size_t)q.Cout * q.ntaps * (q.Cin / 4) * q.G;
+    int grid = (int)((lanes + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(wgrad_pending_kernel, dim3(grid), dim3(256), 0, s, q);
+    CNK_CHECK_LAUNCH("wgrad_pending");
+    return 0;
+}
+
 bool igemm_grouped_ok(const cnk_conv_desc* d);
 bool wgrad_mfma_supported(const cnk_conv_desc* d) {
     if (conv_groups(d) > 1 && !igemm_grouped_ok(d)) return false;
@@ -495,10 +513,12 @@ size_t wgrad_mfma_workspace(const cnk_conv_desc* d) {
 }
 
 int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate,
-               void* ws, size_t ws_bytes, hipStream_t s, const WgradFold* fold) {
+               void* ws, size_t ws_bytes, hipStream_t s, const WgradFold* fold, const WgradPending* prev, WgradPending* out) {
     int Ho, Wo;
     cnk_conv2d_out_hw(d, &Ho, &Wo);
     WgradParams p = {};
+    if (prev) p.prev = *prev;
+    CNK_CHECK_ARG(!out || conv_groups(d) == 1, "wgrad_mfma: grouped convs sum their slabs themselves (no chained sum)");
     int bmw, bnw;
     wgrad_plan(d, &bmw, &bnw, &p.splits, &p.ksteps, &p.ksteps_per_split);
     const bool grouped = conv_groups(d) > 1;
@@ -549,6 +569,11 @@ int wgrad_mfma(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
         return 0;
     }
     size_t per = (size_t)d->Cout * p.ntaps * d->Cin;
+    if (out) {                                   // chained: the sum is left to the next launch of the stream (wgrad_chain.h)
+        CNK_CHECK_ARG(d->Cin % 4 == 0, "wgrad_mfma: a chained slab sum needs Cin % 4 == 0");
+        wgrad_pending_fill(*out, p.slab, dw, p.splits, per, d->Cout, d->Cin, p.ntaps, accumulate);
+        return 0;
+    }
     return launch_wgrad_reduce(p.slab, dw, p.splits, per, d->Cout, d->Cin, p.ntaps,
                                (size_t)p.ntaps * d->Cin, (size_t)d->Cin, 1, 1, accumulate, s);
 }

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "wgrad_chain.h"
 
 #ifndef W3_ABL
 #define W3_ABL 0      // debug builds only (tools/ablate_w3.sh): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMA, 8 no slab store
@@ -47,6 +48,7 @@ struct W3Params {
     int tiles_co, tiles_ci;
     int toff[9];                                   // (kh-1)*P + (kw-1)
     FastDiv fd_hw, fd_w, fd_ip, fd_p;
+    WgradPending prev;       // the slab sum of the PREVIOUS weight gradient of this stream, done in this launch's prologue (wgrad_chain.h)
 };
 
 template <int TCO_, int KP_> struct W3Cfg {
@@ -101,6 +103,11 @@ __global__ __launch_bounds__(CFG::NT, CFG::NW == 8 ? 2 : 2) void wgrad3x3_kernel
     // (it starts at 0: the kernel has no static LDS)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     if (lds0 & (W3_RINGB - 1)) __builtin_trap();
+    // the previous layer's slab sum (compiler-visible loads / stores: retired here, before the hand-counted DMA pipeline starts)
+    if (p.prev.slab) {
+        wgrad_pending_sum<CFG::NT>(p.prev);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -356,8 +363,10 @@ size_t wgrad3x3_workspace(const cnk_conv_desc* d) {
     return (size_t)splits * d->Cout * 9 * d->Cin * sizeof(float);
 }
 
-int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s,
+             const WgradPending* prev, WgradPending* out) {
     W3Params p = {};
+    if (prev) p.prev = *prev;
     bool big;
     w3_plan(d, &big, &p.splits, &p.ksteps, &p.ksteps_per_split);
     const size_t slab_bytes = (size_t)d->Cout * 9 * d->Cin * sizeof(float);
@@ -394,5 +403,9 @@ int wgrad3x3(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, i
         CNK_CHECK_LAUNCH("wgrad3x3");
     }
     const size_t per = (size_t)d->Cout * 9 * d->Cin;
+    if (out) {                                   // chained: the sum is left to the next launch of the stream (wgrad_chain.h)
+        wgrad_pending_fill(*out, p.slab, dw, p.splits, per, d->Cout, d->Cin, 9, accumulate);
+        return 0;
+    }
     return launch_wgrad_reduce(p.slab, dw, p.splits, per, d->Cout, d->Cin, 9, (size_t)9 * d->Cin, (size_t)d->Cin, 1, 1, accumulate, s);
 }

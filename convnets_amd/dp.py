@@ -31,7 +31,11 @@ class GradReducer:
         self.cuda = flat_grad.is_cuda
         import os
         self.force = os.environ.get('CNK_DP_FORCE') == '1'      # run the collective even on 1 rank (path test)
-        self.side = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        if self.cuda:
+            from . import ops as _o
+            self.side = _o.comm_stream(flat_grad.device)       # (not torch.cuda.Stream(): pool streams repeat, ops.wgrad_stream)
+        else:
+            self.side = None
         # buckets from the END of the arena (last layers first)
         self.buckets = []            # (start_elem, end_elem, [param indices])
         idxs, nbytes, end = [], 0, None
@@ -77,7 +81,12 @@ class GradReducer:
             self._launch(b)
 
     def _make_hook(self, i):
-        return lambda _param: self._param_ready(i)
+        from . import ops
+
+        def hook(param):
+            if not ops.grad_sum_pending(param):          # (a chained slab sum: ops reports the gradient once it is issued)
+                self._param_ready(i)
+        return hook
 
     def begin_step(self):
         self._compute_stream = torch.cuda.current_stream(self.flat_grad.device) if self.cuda else None
@@ -106,6 +115,11 @@ class GradReducer:
                 ev = torch.cuda.Event()
                 ev.record(st)
                 self.side.wait_event(ev)
+            if ops.CAPTURE[0] is not None and not ops._is_capturing(self.side):
+                # (the collective would run eagerly beside the capture, on a communicator stream that IS capturing: the
+                # process group's watchdog then aborts the process on the captured event -- fail here, with a traceback)
+                raise RuntimeError('GradReducer: a bucket became ready during a hipGraph capture on a stream outside the capture '
+                                   '(current %s, compute %s)' % (torch.cuda.current_stream(dev), self._compute_stream))
             with torch.cuda.stream(self.side):
                 w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._works.append((w, None))

@@ -155,7 +155,11 @@ class GraphedTrainStep:
         # device table up to date BEFORE the capture (the upload is a host-to-device copy), and keep the collector off
         # while capturing so the registered set cannot change under it
         ops.packer_for(self.x.device).sync_table()
+        # (a chained slab sum left pending by a backward pass that raised is performed HERE, eagerly -- inside the capture it
+        # would be replayed with every step, into buffers that are released once it has run)
+        ops.join_side_streams(self.x.device)
         torch.cuda.synchronize()
+        self._drain_collective_watchdog()
         gc_was_on = gc.isenabled()
         gc.disable()
         try:
@@ -167,6 +171,23 @@ class GraphedTrainStep:
                 gc.enable()
         # capture ran the Python side of one step without executing it
         opt.step_count, ops._dropout_calls[0] = step0, drop0
+
+    @staticmethod
+    def _drain_collective_watchdog():
+        """The process group's watchdog thread keeps every EAGER collective (the warm-up steps' bucket all-reduces) in a list
+        and polls its completion event every 100 ms until it has seen it complete.  Once the capture's first all-reduce has
+        pulled the communicator's stream into the capture, HIP refuses a query of an event that was last recorded on that
+        stream -- although it was recorded long before the capture -- with hipErrorCapturedEvent, and the watchdog aborts the
+        process (seen in ~40 % of the runs of test_graphed_dp_step_with_rccl_allreduce_equals_eager whenever the host reached
+        that all-reduce within one polling interval of the device synchronisation above).  All those collectives HAVE
+        completed (device synchronised): give the watchdog two polling intervals to drop them before the capture starts."""
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and 'nccl' in str(dist.get_backend()):
+                import time
+                time.sleep(0.25)
+        except (RuntimeError, ValueError):
+            pass
 
     def _drop_stale_autograd_state(self):
         """Nothing of an earlier eager step may survive into the capture: the loss module's references to its last

@@ -89,13 +89,14 @@ def _nhwc(t):
 _workspaces = {}
 
 
-def workspace(nbytes, device, stream=None):
+def workspace(nbytes, device, stream=None, slot=0):
     """One grow-only scratch buffer per (device, stream); kernels are stream-ordered on the caller's
     stream, so successive ops on one stream can share it (the library itself never allocates).
-    stream: the torch stream the kernels will run on when that is not the current one."""
+    stream: the torch stream the kernels will run on when that is not the current one.  slot: a second buffer of the same
+    stream (chained weight gradients alternate between two: the slabs of one launch are summed by the next)."""
     key = (device, stream.cuda_stream if stream is not None else
            _raw_stream(device.index) if (_raw_stream is not None and device.index is not None)
-           else torch.cuda.current_stream(device).cuda_stream)
+           else torch.cuda.current_stream(device).cuda_stream, slot)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -136,10 +137,34 @@ def _stamp(label):
 
 
 def wgrad_stream(device):
+    """The device's weight-gradient stream: a HIP stream of our own (cnk_stream_create), wrapped for torch.  NOT
+    torch.cuda.Stream(): those objects are dealt from a pool of 32 streams per device, round-robin, so after 32 more of them --
+    one per GraphedTrainStep, per reducer, per test -- a "new" compute stream is this very stream: the step then runs on one
+    stream, and the compute-stream scratch (keyed by stream handle) aliases the slabs a chained weight gradient has left
+    for the next launch (found as a wrong hipGraph replay that only the full test suite could produce)."""
     st = _side_streams.get(device)
     if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
+        st = _side_streams[device] = own_stream(device)
     return st
+
+
+_comm_streams = {}
+
+
+def comm_stream(device):
+    """The device's stream for gradient collectives (dp.GradReducer), for the same reason a stream of our own."""
+    st = _comm_streams.get(device)
+    if st is None:
+        st = _comm_streams[device] = own_stream(device)
+    return st
+
+
+def own_stream(device):
+    """A HIP stream no other stream object of the process shares (see wgrad_stream); lives as long as the process."""
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(_lib.load().cnk_stream_create(ctypes.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def side_streams(device):
@@ -148,6 +173,37 @@ def side_streams(device):
 
 
 _join_queued = [False]
+# Chained slab sums (csrc/wgrad_chain.h): on the weight-gradient stream the fp32 slabs of conv k are summed by the workgroups of
+# conv k + 1's kernel instead of by a launch of their own (52 latency-bound launches per ResNet-50 step: 0.4-0.55 ms of it);
+# the last sum of a backward pass is flushed before the streams join.  device -> [pending descriptor, parameters to report, slot,
+# tensors the descriptor points into].  The last entry keeps the slabs and the gradient buffer alive: a backward pass that
+# raised half-way leaves its last sum pending, and the next pass (possibly of another model, after this one was freed) performs
+# it -- into memory that must still belong to the dead step, not to whoever got it from the allocator since.
+WGRAD_CHAIN = os.environ.get('CNK_WGRAD_CHAIN', '1') != '0'
+_wgrad_chain = {}
+_grad_sum_pending = set()              # id(parameter): its gradient kernel has run but the slab sum has not been issued yet
+
+
+def grad_sum_pending(param):
+    """True while `param.grad` is still waiting for a chained slab sum: autograd's own post-accumulate hook fires when the
+    conv's backward returns, which is too early for anything that reads the gradient (dp.GradReducer); _grad_written follows."""
+    return id(param) in _grad_sum_pending
+
+
+def _flush_wgrad_chain(device):
+    """Sums the slabs the last chained weight gradient left behind (on the weight-gradient stream) and reports its gradient."""
+    st = _wgrad_chain.get(device)
+    if st is None or st[0] is None:
+        return
+    pending, params = st[0], st[1]
+    st[0], st[1] = None, ()
+    check(_lib.load().cnk_wgrad_reduce_pending(ctypes.byref(pending), wgrad_stream(device).cuda_stream))
+    st[3] = None
+    for prm in params:
+        _grad_sum_pending.discard(id(prm))
+        _grad_written(prm)
+
+
 _dy_event = {}                                # device -> the event eager steps fork the weight-gradient stream at
 def _join_at_end_of_backward():
     """Once per backward pass: when the autograd engine has run the whole graph, the compute stream
@@ -169,8 +225,10 @@ def _is_capturing(stream):
 
 def join_side_streams(device=None):
     """Makes the current stream wait for everything issued on the weight-gradient stream(s)."""
+    _join_queued[0] = False                   # (whoever joins after a backward pass that raised: the flag must not stay set)
     for dev, st in _side_streams.items():
         if device is None or dev == device:
+            _flush_wgrad_chain(dev)           # (the last chained slab sum has no launch behind it to ride in)
             cur = torch.cuda.current_stream(dev)
             if CAPTURE[0] is not None and not _is_capturing(st):
                 continue              # hipGraph capture: nothing of this capture has been forked to that stream
@@ -183,7 +241,7 @@ def join_side_streams(device=None):
 # ~1,900 launches from Python).  _lib.reload_switches() (tests, A/B tools) moves the epoch and drops them.
 class ConvPlan:
     __slots__ = ('desc', 'Ho', 'Wo', 'fwd_slices', 'dgrad_slices', 'wgrad_ws', 'wgrad_min_ws', 'wgrad_min_ws_bias', 'accepts_mask',
-                 'bnfold', 'fold_bytes')
+                 'bnfold', 'fold_bytes', 'wgrad_chain', 'fold1', 'fold1_ws', 'fold1_slices')
 
 
 _conv_plans = {}
@@ -208,6 +266,10 @@ def conv_plan(x_shape, weight_shape, stride, padding, dtype_code, groups, dilati
         pl.accepts_mask = bool(lib.cnk_conv2d_dgrad_accepts_mask(ctypes.byref(d)))
         pl.bnfold = bool(lib.cnk_conv2d_bnfold_supported(ctypes.byref(d)))
         pl.fold_bytes = lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)) if pl.bnfold else 0
+        pl.wgrad_chain = bool(lib.cnk_conv2d_wgrad_chain_supported(ctypes.byref(d)))
+        pl.fold1 = pl.bnfold and bool(lib.cnk_conv2d_bwd_bnfold_supported(ctypes.byref(d)))
+        pl.fold1_ws = lib.cnk_conv2d_bwd_bnfold_workspace_bytes(ctypes.byref(d)) if pl.fold1 else 0
+        pl.fold1_slices = lib.cnk_conv2d_bwd_bnfold_bn_slices(ctypes.byref(d)) if pl.fold1 else 0
         if len(_conv_plans) > 4096:
             _conv_plans.clear()
         _conv_plans[key] = pl
@@ -271,6 +333,10 @@ class FoldRecord:
 
 
 BN_FOLD = os.environ.get('CNK_BN_FOLD', '1') != '0'
+# Round 5: where the library has it (64 -> 256 channels: the first ResNet stage, where the backward is HBM-bound on both streams),
+# the folded data gradient and the folded weight gradient are ONE pass over g and the conv input on the compute stream
+# (cnk_conv2d_bwd_bnfold, csrc/conv_fold3.hip) -- the weight-gradient stream loses its 925-MB launches.
+FOLD_ONE_PASS = os.environ.get('CNK_FOLD_ONE_PASS', '1') != '0'
 # The fold pays where the apply pass it removes (3 * M * Cout elements of HBM traffic) outweighs what it adds to the critical
 # path (the finalise + image launches, ~20-30 us, and K + Cin/Cout in the data gradient) and to the weight-gradient stream (the
 # BN input read beside the gradient): measured per ResNet-50 stage at batch 256 (tools/bench_fold.py) 366 -> 163 / 203 -> 110 /
@@ -280,7 +346,7 @@ BN_FOLD_MIN_ELEMS = float(os.environ.get('CNK_BN_FOLD_MIN', '4e7'))
 # projection shortcuts, and LazyConvOut (the conv output of a bottleneck's last block left out of the forward and replayed in
 # the backward).  Each measured slower or neutral in the ResNet-50 step -- 19.80 -> 19.95, 19.23 vs 19.26, 19.65 -> 19.88 ms,
 # DESIGN.md 7b / 9 -- and was removed in round 5: one folded path in Conv2dFn.backward.)
-FOLD_COUNTS = {'folded': 0}               # folded conv backward passes (tests read this)
+FOLD_COUNTS = {'folded': 0, 'one_pass': 0}               # folded conv backward passes (tests read this)
 BN_BWD_FUSE = os.environ.get('CNK_BN_BWD_FUSE', '1') != '0'
 # the same fusion for the stride-1 3x3 convs only (A/B switch, DESIGN.md: break-even per layer, see there)
 BN_BWD_FUSE_3X3 = os.environ.get('CNK_BN_BWD_FUSE_3X3', '1') != '0'
@@ -552,8 +618,10 @@ class Conv2dFn(torch.autograd.Function):
                 if CAPTURE[0] is None:
                     _dy_event[x.device] = dy_ready
             dy_ready.record(torch.cuda.current_stream(x.device))
+        wgrad_done = False
         if ctx.needs_input_grad[0]:
             def dgrad(addend):
+                nonlocal wgrad_done
                 amask = None
                 if isinstance(addend, tuple):        # (block-output gradient, its packed ReLU mask)
                     addend, amask = addend
@@ -565,17 +633,31 @@ class Conv2dFn(torch.autograd.Function):
                 # x is the output of a BN(+ReLU) layer and `out` the TOTAL gradient w.r.t. it: run the
                 # first pass of that layer's backward in this epilogue (BnRecord)
                 rec, fuse, partial = ctx.bn_rec, None, None
-                if rec is not None and (ctx.link is None or ctx.link.final) and rec.x is not None \
-                        and rec.x.shape == x.shape and rec.x.dtype == x.dtype \
-                        and (BN_BWD_FUSE_3X3 or desc.kh != 3 or desc.stride_h != 1):
-                    slices = ctx.plan.dgrad_slices
+                fuse_ok = rec is not None and (ctx.link is None or ctx.link.final) and rec.x is not None \
+                    and rec.x.shape == x.shape and rec.x.dtype == x.dtype \
+                    and (BN_BWD_FUSE_3X3 or desc.kh != 3 or desc.stride_h != 1)
+                # both folded gradients in one pass: plain data gradient (no residual sum), arena weight gradient, re-derived mask
+                gw1 = None
+                if fold is not None and FOLD_ONE_PASS and ctx.plan.fold1 and addend is None and not ctx.has_bias \
+                        and ctx.needs_input_grad[1] and not (fuse_ok and rec.mask is not None) and ctx.params[0].is_contiguous():
+                    gw1 = _arena_grad(ctx.params[0])
+                if fuse_ok:
+                    slices = ctx.plan.fold1_slices if gw1 is not None else ctx.plan.dgrad_slices
                     if slices > 0:
                         partial = torch.empty((slices, desc.Cin, 2), dtype=torch.float32, device=x.device)
                         fuse = _lib.BnBwdFuse(rec.x.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr(),
                                               rec.gamma.data_ptr(), rec.beta.data_ptr(),
                                               rec.mask.data_ptr() if rec.mask is not None else None,
                                               partial.data_ptr(), int(rec.relu))
-                if fold is not None:
+                if gw1 is not None:
+                    ws1 = workspace(ctx.plan.fold1_ws, x.device)
+                    check(lib.cnk_conv2d_bwd_bnfold(ctypes.byref(desc), _p(dy), _p(x), _p(w_fold), _p(bias_fold), _p(out),
+                                                    ctypes.byref(fuse) if fuse else None, _p(w), _p(fold.mean), _p(fold.invstd),
+                                                    _p(fold.coef), _p(gw1), 1, _p(ws1), ws1.numel(), _stream()))
+                    FOLD_COUNTS['one_pass'] += 1
+                    wgrad_done = True
+                    _grad_written(ctx.params[0])
+                elif fold is not None:
                     check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(desc), _p(dy), _p(x),
                                                       _p(w_fold), _p(bias_fold), _p(out), _p(addend), _p(amask),
                                                       ctypes.byref(fuse) if fuse else None, _stream()))
@@ -587,7 +669,7 @@ class Conv2dFn(torch.autograd.Function):
                     rec.fused = (out, partial)
                 return out
             dx = ctx.link.contribute(dgrad) if ctx.link is not None else dgrad(None)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not wgrad_done:
             weight, bias = ctx.params
             # accumulate straight into .grad when it is a dense fp32 buffer (the flat arena): same
             # result as autograd's `grad += dw`, without the extra kernel and tensor per parameter
@@ -609,12 +691,35 @@ class Conv2dFn(torch.autograd.Function):
                 # stream: the weight-gradient stream, WITHOUT making it torch's current stream (`with torch.cuda.stream(..)`
                 # costs ~10 us of host time per conv: 1.5 ms of a ResNet-152 step)
                 st = _stream() if stream is None else stream.cuda_stream
-                ws = workspace(nws, x.device, stream)
+                chain = WGRAD_CHAIN and stream is not None and direct and not ctx.has_bias and ctx.plan.wgrad_chain
+                cst = _wgrad_chain.setdefault(x.device, [None, (), 0, None]) if stream is not None else None
+                if chain:
+                    cst[2] ^= 1               # the other workspace: the pending slabs sit in the one the last launch used
+                elif cst is not None:
+                    _flush_wgrad_chain(x.device)          # (an unchained launch on that stream would overwrite pending slabs)
+                ws = workspace(nws, x.device, stream, cst[2] if chain else 0)
                 budget = ws.numel()
                 # a share of the split-K depth: never below what the library says it needs (the whole workspace for every
                 # kernel that does not split; cnk_conv2d_wgrad_min_workspace_bytes)
                 if share < 1.0:
                     budget = min(budget, max(min_ws, int(nws * share) // 256 * 256))
+                if chain:
+                    # this launch sums the slabs of the PREVIOUS weight gradient of the stream in its prologue and leaves its own
+                    prev, prev_params = cst[0], cst[1]
+                    out = _lib.WgradPending()
+                    if fy is not None:
+                        check(lib.cnk_conv2d_wgrad_bnfold_chain(ctypes.byref(desc), _p(dy), _p(fy), _p(x), _p(fmean), _p(finv),
+                                                                _p(fcoef), _p(dw_buf), 1, _p(ws), budget,
+                                                                ctypes.byref(prev) if prev is not None else None, ctypes.byref(out), st))
+                    else:
+                        check(lib.cnk_conv2d_wgrad_chain(ctypes.byref(desc), _p(dy), _p(x), _p(dw_buf), 1, _p(ws), budget,
+                                                         ctypes.byref(prev) if prev is not None else None, ctypes.byref(out), st))
+                    cst[0], cst[1], cst[3] = out, (weight,), (dw_buf, ws)
+                    _grad_sum_pending.add(id(weight))
+                    for prm in prev_params:
+                        _grad_sum_pending.discard(id(prm))
+                        _grad_written(prm)    # its sum has been issued (inside the launch above)
+                    return
                 if fy is not None:
                     check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(desc), _p(dy), _p(fy), _p(x), _p(fmean),
                                                       _p(finv), _p(fcoef), _p(dw_buf), int(direct), _p(ws),

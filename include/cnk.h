@@ -52,6 +52,14 @@ typedef struct cnk_conv_desc {
 int cnk_version(void);
 const char* cnk_last_error(void);
 
+/* A HIP stream of the caller's own (hipStreamNonBlocking) on the current device, for the second stream the backward pass runs
+ * its weight gradients on (autograd issues both gradients of a conv from one node, basemodel.py:278; the host side overlaps
+ * them).  Why the library hands it out: a host framework's stream objects may share handles -- torch.cuda.Stream() deals the
+ * 32 streams of a per-device pool round-robin, so the 33rd object of a process IS the first again -- and a "second" stream
+ * that silently equals the compute stream serialises the step and lets both sides' scratch buffers alias. */
+int cnk_stream_create(void** stream);
+int cnk_stream_destroy(void* stream);
+
 /* Output spatial size, floor((H + 2p - dilation*(k-1) - 1)/s) + 1 -- the reference's shape tracker formula
  * (basemodel.py:770-771). */
 int cnk_conv2d_out_hw(const cnk_conv_desc* d, int32_t* Ho, int32_t* Wo);
@@ -153,6 +161,26 @@ int cnk_conv2d_dgrad(const cnk_conv_desc* d, const void* dy, const void* w_dgrad
 int cnk_conv2d_wgrad(const cnk_conv_desc* d, const void* dy, const void* x, float* dw,
                      float* dbias, int accumulate, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* Chained slab sums (round 5; csrc/wgrad_chain.h).  A split-K weight gradient leaves fp32 slabs in its workspace that a second,
+ * tiny launch sums into dw: 52 latency-bound launches per ResNet-50 step on the weight-gradient stream (basemodel.py:278 runs
+ * all of them inside loss.backward()).  The _chain entry points run the kernel WITHOUT that sum and describe it in `*out`;
+ * handed as `prev` to the NEXT weight-gradient call on the same stream, that launch's workgroups sum it in their prologue (no
+ * launch of its own); the last one of a chain goes to cnk_wgrad_reduce_pending.  The caller keeps `workspace` untouched until
+ * the call that received the descriptor as `prev` (or cnk_wgrad_reduce_pending) has been issued, i.e. consecutive calls
+ * alternate between two workspaces.  Same results as cnk_conv2d_wgrad up to the fp32 summation order of the slabs;
+ * bit-reproducible.  _supported: dense convs on the MFMA weight-gradient kernels, Cin % 4 == 0, no dbias. */
+typedef struct cnk_wgrad_pending {
+    const float* slab;         /* NULL: nothing pending */
+    float* dw;
+    uint64_t slab_stride;      /* floats between two slabs */
+    int32_t splits, Cout, Cin, ntaps, accumulate;
+    int32_t lanes;             /* lanes that share a 4-channel group of the sum (chosen by the producing call) */
+} cnk_wgrad_pending;
+int cnk_conv2d_wgrad_chain_supported(const cnk_conv_desc* d);
+int cnk_conv2d_wgrad_chain(const cnk_conv_desc* d, const void* dy, const void* x, float* dw, int accumulate, void* workspace,
+                           size_t workspace_bytes, const cnk_wgrad_pending* prev, cnk_wgrad_pending* out, void* stream);
+int cnk_wgrad_reduce_pending(const cnk_wgrad_pending* pending, void* stream);
+
 /* The smallest workspace cnk_conv2d_wgrad accepts for this shape (has_bias: dbias != NULL): one slab (+ the bias sum's
  * scratch) for the split-K kernels, cnk_conv2d_workspace_bytes(d, CNK_PASS_WGRAD) for every other kernel. */
 size_t cnk_conv2d_wgrad_min_workspace_bytes(const cnk_conv_desc* d, int has_bias);
@@ -245,6 +273,26 @@ int cnk_conv2d_dgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* x
 int cnk_conv2d_wgrad_bnfold(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean,
                             const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* ... with its slab sum chained like cnk_conv2d_wgrad_chain (declared above) */
+int cnk_conv2d_wgrad_bnfold_chain(const cnk_conv_desc* d, const void* g, const void* y, const void* x, const float* save_mean,
+                                  const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace,
+                                  size_t workspace_bytes, const struct cnk_wgrad_pending* prev, struct cnk_wgrad_pending* out,
+                                  void* stream);
+
+/* Both gradients of the folded conv -> BN pair in ONE pass over the operands (csrc/conv_fold3.hip): the 64 -> 256-channel 1x1 convs
+ * of ResNet's first stage (resnet.py:172-176 and the projection shortcut 160-166 at 56x56; autograd's backward, basemodel.py:278).
+ * dx as cnk_conv2d_dgrad_bnfold (same arguments; `bn`, when given, re-derives its ReLU mask: relu_mask must be NULL; its
+ * `partial` holds cnk_conv2d_bwd_bnfold_bn_slices(d) records).  dw as cnk_conv2d_wgrad_bnfold, from the Gram products g^T x and
+ * x^T x instead of the BN input:  dw[k][j] (+)= A_k (G[k][j] - B1_k S_j) - A_k invstd_k B2_k ((bf16(w) X)[k][j] - mean_k S_j),
+ * so the conv output is never read (it is bf16(w) x up to the rounding of the stored tensor) and neither operand is read twice.
+ * w: the fp32 master weights [Cout][Cin].  save_mean / save_invstd / coef as for cnk_conv2d_wgrad_bnfold.  Everything runs on
+ * `stream`, in order.  workspace: cnk_conv2d_bwd_bnfold_workspace_bytes(d). */
+int cnk_conv2d_bwd_bnfold_supported(const cnk_conv_desc* d);
+size_t cnk_conv2d_bwd_bnfold_workspace_bytes(const cnk_conv_desc* d);
+int64_t cnk_conv2d_bwd_bnfold_bn_slices(const cnk_conv_desc* d);
+int cnk_conv2d_bwd_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx,
+                          const cnk_bn_bwd_fuse* bn, const float* w, const float* save_mean, const float* save_invstd,
+                          const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.AvgPool2d (avgpool2d, basemodel.py:1026-1033; DenseNet's transition block, densenet.py:129): floor mode,
  * count_include_pad=True (every window divides by kh*kw), zero padding.  SURVEY.md 8f n4. */

@@ -650,6 +650,32 @@ def test_graph_replay_follows_a_learning_rate_change_without_recapture():
     torch.cuda.synchronize()
     assert g.graph is graph_obj, 'no re-capture'
     pa, pb = a.optimizer.flat_p, b.optimizer.flat_p
+    # (shown when the assertion below fails: which tensors differ, and the process-wide state the two paths share)
+    from convnets_amd import ops
+    off, dgr, dpa = 0, (a.optimizer.flat_g - b.optimizer.flat_g).abs(), (pa - pb).abs()
+    for n, prm in a.named_parameters():
+        k = prm.numel()
+        if k and float(dpa[off:off + k].max()) > 0:
+            print('differs: %-40s %-18s grad %.3e param %.3e' % (n, tuple(prm.shape), float(dgr[off:off + k].max()), float(dpa[off:off + k].max())))
+        off += k
+    print('WGRAD_SHARE', ops.WGRAD_SHARE, 'WGRAD_CHAIN', ops.WGRAD_CHAIN, 'chain', {k: (v[0] is not None, v[2]) for k, v in ops._wgrad_chain.items()},
+          'join queued', ops._join_queued, 'BN_FOLD_MIN_ELEMS', ops.BN_FOLD_MIN_ELEMS)
+    if float(dpa.max()) > 0:
+        print('workspaces', [(k[1] & 0xffff, k[2], v.numel(), hex(v.data_ptr())) for k, v in ops._workspaces.items() if v.numel() > (4 << 20)])
+        keep = ops.WGRAD_CHAIN
+        for chain in (False, True):
+            ops.WGRAD_CHAIN = chain
+            torch.manual_seed(21)
+            c = ca.ResNet(s).cuda()
+            c.init_optimizer()
+            c.train()
+            for lr in (1e-3, 1e-3, 1e-4, 1e-4):
+                c.optimizer.param_groups[0]['lr'] = lr
+                c.train_batch((x, y))
+                torch.cuda.synchronize()
+            print('a third model, eager with a sync per step, chain %s: graph model differs by %.3e, eager model by %.3e'
+                  % (chain, float((pa - c.optimizer.flat_p).abs().max()), float((pb - c.optimizer.flat_p).abs().max())))
+        ops.WGRAD_CHAIN = keep
     assert ((pa - pb).abs().max() / pb.abs().max()).item() < 1e-6
     step_a = (pa - models[0].optimizer.flat_p).abs().max()
     assert a.optimizer.step_count == b.optimizer.step_count == 4

@@ -429,7 +429,7 @@ def test_conv_bn_block_as_one_autograd_node_is_bit_identical(kind, mixed):
             model.init_optimizer()
             model.train()
             x, y = tr.synthetic_batch(16, (3, 64, 64), 10, seed=21)
-            ops.FOLD_COUNTS['folded'] = 0
+            ops.FOLD_COUNTS.update(folded=0, one_pass=0)
             ops.FUSE_COUNTS.update(bn_bwd_fused=0, bn_bwd_unfused=0)
             losses = [float(model.train_batch((x, y))[0]) for _ in range(2)]
             torch.cuda.synchronize()
@@ -456,3 +456,325 @@ def test_conv_bn_block_as_one_autograd_node_is_bit_identical(kind, mixed):
     nf = sum(1 for n in n1 if n.startswith('ConvBnActFn'))
     assert nf >= 15 and sum(1 for n in n0 if n.startswith('ConvBnActFn')) == 0
     assert len(n1) < len(n0) - 10, (len(n1), len(n0))
+
+
+def test_chained_slab_sum_over_the_c_abi():
+    """include/cnk.h cnk_conv2d_wgrad_chain / cnk_wgrad_reduce_pending: the fp32 slabs of weight gradient k are summed in the
+    prologue of launch k + 1 (any shape, any kernel family of the chain), the last one by cnk_wgrad_reduce_pending.  Every dw
+    equals the fp64 weight gradient (torch.nn.grad.conv2d_weight; the reference's is F.conv2d's autograd,
+    /root/reference/src/basemodel.py:999) as closely as the unchained call does, run to run bit-identical, `accumulate` kept;
+    pending slabs inside the next call's workspace are refused."""
+    from convnets_amd import _lib, ops
+    lib = _lib.load()
+    N = 32
+    shapes = [(64, 256, 56, 1), (128, 128, 28, 3), (512, 128, 28, 1), (64, 64, 56, 3), (256, 1024, 14, 1)]
+    g = torch.Generator().manual_seed(5)
+    convs = []
+    for Cin, Cout, H, k in shapes:
+        xb = torch.randn(N, Cin, H, H, generator=g).cuda().bfloat16().contiguous(memory_format=CL)
+        dyb = (torch.randn(N, Cout, H, H, generator=g) * 0.1).cuda().bfloat16().contiguous(memory_format=CL)
+        desc = ops.make_desc(xb.shape, (Cout, Cin, k, k), (1, 1), (k // 2, k // 2), _lib.CNK_BF16)
+        assert lib.cnk_conv2d_wgrad_chain_supported(ctypes.byref(desc)) == 1
+        convs.append((desc, xb, dyb, (Cout, Cin, k, k)))
+    nws = max(lib.cnk_conv2d_workspace_bytes(ctypes.byref(c[0]), 2) for c in convs)
+    wss = [torch.empty(nws, dtype=torch.uint8, device='cuda') for _ in range(2)]
+    st = _st()
+    runs = []
+    for _ in range(2):
+        dws = [torch.ones(c[3], device='cuda') for c in convs]                     # accumulate = 1 onto ones
+        prev = None
+        for i, (desc, xb, dyb, _) in enumerate(convs):
+            out = _lib.WgradPending()
+            _lib.check(lib.cnk_conv2d_wgrad_chain(ctypes.byref(desc), P(dyb), P(xb), P(dws[i]), 1, P(wss[i & 1]), nws,
+                                                  ctypes.byref(prev) if prev is not None else None, ctypes.byref(out), st))
+            assert out.slab and out.splits >= 1
+            prev = out
+        # nothing has summed the last one yet
+        torch.cuda.synchronize()
+        assert torch.equal(dws[-1], torch.ones_like(dws[-1]))
+        _lib.check(lib.cnk_wgrad_reduce_pending(ctypes.byref(prev), st))
+        torch.cuda.synchronize()
+        runs.append([d.clone() for d in dws])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    for (desc, xb, dyb, wshape), dw in zip(convs, runs[0]):
+        k = wshape[2]
+        ref = torch.nn.grad.conv2d_weight(xb.double().cpu(), wshape, dyb.double().cpu(), padding=k // 2)
+        un = torch.ones(wshape, device='cuda')
+        _lib.check(lib.cnk_conv2d_wgrad(ctypes.byref(desc), P(dyb), P(xb), P(un), None, 1, P(wss[0]), nws, st))
+        torch.cuda.synchronize()
+        e_chain, e_un = rel_l2(dw.cpu().numpy() - 1.0, ref.numpy()), rel_l2(un.cpu().numpy() - 1.0, ref.numpy())
+        print(wshape, 'chained %.2e unchained %.2e' % (e_chain, e_un))
+        assert e_chain < 2e-6 and e_un < 2e-6                 # fp32 accumulation of exact bf16 products; the sums differ in order only
+    # the pending slabs of a launch live in ITS workspace: handing the same one to the next call must be refused
+    desc, xb, dyb, wshape = convs[0]
+    dw = torch.zeros(wshape, device='cuda')
+    out, out2 = _lib.WgradPending(), _lib.WgradPending()
+    _lib.check(lib.cnk_conv2d_wgrad_chain(ctypes.byref(desc), P(dyb), P(xb), P(dw), 0, P(wss[0]), nws, None, ctypes.byref(out), st))
+    assert lib.cnk_conv2d_wgrad_chain(ctypes.byref(desc), P(dyb), P(xb), P(dw), 0, P(wss[0]), nws, ctypes.byref(out),
+                                      ctypes.byref(out2), st) != 0
+    assert b'overlap' in lib.cnk_last_error()
+    _lib.check(lib.cnk_wgrad_reduce_pending(ctypes.byref(out), st))
+    _lib.check(lib.cnk_wgrad_reduce_pending(ctypes.byref(_lib.WgradPending()), st))      # nothing pending: a no-op
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('kind', [26, 18])
+def test_train_step_with_chained_slab_sums(kind):
+    """ops.WGRAD_CHAIN: on the weight-gradient stream every split-K slab sum rides in the next weight gradient's launch.  Two
+    training steps of a ResNet (bottleneck: with the folded BN backward; basic blocks: 3x3 kernels only) give the same loss
+    bits on step one, gradients equal to the unchained step's within fp32 summation order, and the chained step is run-to-run
+    bit-identical; no gradient is left unsummed when backward returns."""
+    import convnets_amd as ca
+    from convnets_amd import ops
+    from oracle import torch_ref as tr
+    prev, prev_min = ops.WGRAD_CHAIN, ops.BN_FOLD_MIN_ELEMS
+    ops.BN_FOLD_MIN_ELEMS = 0
+    res = []
+    try:
+        for chain in (True, True, False):
+            ops.WGRAD_CHAIN = chain
+            torch.manual_seed(33)
+            s = ca.Settings(kind=kind, input_size=(3, 64, 64), num_classes=10, batch_size=32, dropout_rate=0, mixed_precision=True,
+                            device='cuda:0')
+            model = ca.ResNet(s).cuda()
+            model.init_optimizer()
+            model.train()
+            x, y = tr.synthetic_batch(32, (3, 64, 64), 10, seed=33)
+            l1 = float(model.train_batch((x, y))[0])
+            g1 = model.optimizer.flat_g.clone()
+            l2 = float(model.train_batch((x, y))[0])
+            torch.cuda.synchronize()
+            assert not ops._grad_sum_pending and all(st[0] is None for st in ops._wgrad_chain.values())
+            res.append((l1, g1, l2, model.optimizer.flat_g.clone(), model.optimizer.flat_p.clone()))
+    finally:
+        ops.WGRAD_CHAIN, ops.BN_FOLD_MIN_ELEMS = prev, prev_min
+    a, b, u = res
+    assert a[0] == b[0] and a[2] == b[2] and all(torch.equal(p, q) for p, q in zip(a[1:], b[1:]) if torch.is_tensor(p))
+    assert a[0] == u[0]                                           # the first forward pass is the same computation
+    e = float((a[1] - u[1]).norm() / u[1].norm())
+    print('chained vs unchained gradients of step 1: L2-rel %.2e' % e)
+    assert e < 1e-5
+
+
+@pytest.mark.parametrize('N,H,bn_fuse,load', [(3, 37, True, False), (16, 28, False, False), (256, 56, True, True)])
+def test_one_pass_folded_backward(N, H, bn_fuse, load):
+    """include/cnk.h cnk_conv2d_bwd_bnfold (csrc/conv_fold3.hip): data gradient AND weight gradient of the folded conv -> BN pair of
+    a 64 -> 256-channel 1x1 conv (/root/reference/src/resnet.py:172-176 at 56x56; autograd at basemodel.py:278) from one pass over
+    g and the conv input.  dx and the fused BN-backward sums against cnk_conv2d_dgrad_bnfold (same image, same epilogue
+    arithmetic: equal up to the fp32 summation order before the bf16 rounding) and against fp64 on sampled rows; dw -- the Gram
+    form, which never reads the conv output -- against fp64 of the BN backward + conv weight gradient on sampled channels, at
+    least as close as cnk_conv2d_wgrad_bnfold; ragged M (4107 = 128 * 32 + 11), the benchmark's size beside a busy second stream,
+    `accumulate`, five repeats bit-identical."""
+    from convnets_amd import ops
+    _lib, lib, cnt = _lib_and_counter()
+    Cin, Cout, W = 64, 256, H
+    M = N * H * W
+    dev = 'cuda'
+    gen = torch.Generator(device=dev).manual_seed(77 + H)
+    a = torch.randn(N, H, W, Cin, generator=gen, device=dev).relu_().bfloat16().permute(0, 3, 1, 2)
+    w = torch.randn(Cout, Cin, 1, 1, generator=gen, device=dev) / math.sqrt(Cin)
+    d = ops.make_desc(a.shape, w.shape, (1, 1), (0, 0), _lib.CNK_BF16)
+    assert lib.cnk_conv2d_bwd_bnfold_supported(ctypes.byref(d)) == 1
+    w_fwd = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_FWD), dtype=torch.uint8, device=dev)
+    w_dgrad = torch.empty(lib.cnk_conv2d_packed_bytes(ctypes.byref(d), _lib.PASS_DGRAD), dtype=torch.uint8, device=dev)
+    _lib.check(lib.cnk_conv2d_pack_weights(ctypes.byref(d), P(w), P(w_fwd), P(w_dgrad), _st()))
+    y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=dev, memory_format=CL)
+    _lib.check(lib.cnk_conv2d_fwd(ctypes.byref(d), P(a), P(w_fwd), None, P(y), None, None, 0, _st()))
+    y2 = y.permute(0, 2, 3, 1).reshape(M, Cout)
+    mean64 = y2.double().mean(0)
+    invstd64 = 1.0 / torch.sqrt(((y2.double() - mean64) ** 2).mean(0) + 1e-5)
+    mean, invstd = mean64.float(), invstd64.float()
+    gamma = 0.5 + torch.rand(Cout, generator=gen, device=dev)
+    g = torch.randn(M, Cout, generator=gen, device=dev) * 0.5 + 0.1 * torch.randn(Cout, generator=gen, device=dev)
+    g += 0.2 * ((y2.float() - mean) * invstd) * torch.randn(Cout, generator=gen, device=dev)
+    g *= torch.rand(M, Cout, generator=gen, device=dev) > 0.4
+    g = g.bfloat16().reshape(N, H, W, Cout).permute(0, 3, 1, 2)
+    g2 = g.permute(0, 2, 3, 1).reshape(M, Cout)
+    S = g2.double().sum(0)
+    Q = (g2.double() * (y2.double() - mean.double())).sum(0) * invstd.double()
+    partial = torch.stack([S, Q], 1).reshape(1, Cout, 2).float().contiguous()
+    nbn = lib.cnk_bn_workspace_bytes(M, Cout)
+    bws = torch.empty(nbn, dtype=torch.uint8, device=dev)
+    coef = torch.empty(3 * Cout, device=dev)
+    dgamma, dbeta = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+    _lib.check(lib.cnk_bn_bwd_coef(None, None, P(partial), 1, P(gamma), P(mean), P(invstd), P(dgamma), P(dbeta), 0, P(coef), M, Cout,
+                                   _lib.CNK_BF16, P(bws), nbn, _st()))
+    u = (torch.randn(N, H, W, Cin, generator=gen, device=dev) * 1.2 + 0.1).bfloat16().permute(0, 3, 1, 2)
+    mean2 = 0.1 * torch.randn(Cin, generator=gen, device=dev)
+    invstd2 = 0.8 + 0.4 * torch.rand(Cin, generator=gen, device=dev)
+    gamma2 = 0.5 + torch.rand(Cin, generator=gen, device=dev)
+    beta2 = 0.1 * torch.randn(Cin, generator=gen, device=dev)
+    w_fold = torch.empty(lib.cnk_conv2d_bnfold_image_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    bias_fold = torch.empty(Cin, device=dev)
+    _lib.check(lib.cnk_conv2d_bnfold_prepare(ctypes.byref(d), P(w), P(w_dgrad), P(mean), P(invstd), P(coef), P(w_fold), P(bias_fold), _st()))
+    nws = lib.cnk_conv2d_workspace_bytes(ctypes.byref(d), _lib.PASS_WGRAD)
+    ws_w = torch.empty(nws, dtype=torch.uint8, device=dev)
+    nws1 = lib.cnk_conv2d_bwd_bnfold_workspace_bytes(ctypes.byref(d))
+    ws1 = torch.empty(nws1, dtype=torch.uint8, device=dev)
+    sl_old = lib.cnk_conv2d_dgrad_bn_slices(ctypes.byref(d))
+    sl_new = lib.cnk_conv2d_bwd_bnfold_bn_slices(ctypes.byref(d))
+    assert sl_new > 0 and nws1 > 0
+
+    side = torch.cuda.Stream()
+    if load:
+        la = torch.randn(128, 56, 56, 64, generator=gen, device=dev).bfloat16().permute(0, 3, 1, 2)
+        ldy = torch.randn(128, 56, 56, 64, generator=gen, device=dev).bfloat16().permute(0, 3, 1, 2)
+        ld = ops.make_desc(la.shape, (64, 64, 3, 3), (1, 1), (1, 1), _lib.CNK_BF16)
+        lws_n = lib.cnk_conv2d_workspace_bytes(ctypes.byref(ld), _lib.PASS_WGRAD)
+        lws = torch.empty(lws_n, dtype=torch.uint8, device=dev)
+        ldw = torch.zeros(64, 64, 3, 3, device=dev)
+    torch.cuda.synchronize()
+
+    def busy(reps):
+        if not load:
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        for _ in range(reps):
+            _lib.check(lib.cnk_conv2d_wgrad(ctypes.byref(ld), P(ldy), P(la), P(ldw), None, 0, P(lws), lws_n, _st(side)))
+
+    def fuse_of(part):
+        return _lib.BnBwdFuse(u.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None,
+                              part.data_ptr(), 1) if bn_fuse else None
+
+    # the two folded launches of round 4
+    part_o = torch.zeros(max(sl_old, 1), Cin, 2, device=dev)
+    fo = fuse_of(part_o)
+    da_o = torch.empty_like(a, memory_format=CL)
+    _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(g), P(a), P(w_fold), P(bias_fold), P(da_o), None, None,
+                                           ctypes.byref(fo) if fo else None, _st()))
+    dw_o = torch.ones(Cout, Cin, 1, 1, device=dev)
+    _lib.check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(d), P(g), P(y), P(a), P(mean), P(invstd), P(coef), P(dw_o), 1, P(ws_w), nws, _st()))
+    torch.cuda.synchronize()
+    runs = []
+    for rep in range(5):
+        busy(8)
+        part_n = torch.zeros(sl_new, Cin, 2, device=dev)
+        fn = fuse_of(part_n)
+        da_n = torch.full_like(a, float('nan'), memory_format=CL)
+        dw_n = torch.ones(Cout, Cin, 1, 1, device=dev)
+        _lib.check(lib.cnk_conv2d_bwd_bnfold(ctypes.byref(d), P(g), P(a), P(w_fold), P(bias_fold), P(da_n), ctypes.byref(fn) if fn else None,
+                                             P(w), P(mean), P(invstd), P(coef), P(dw_n), 1, P(ws1), nws1, _st()))
+        torch.cuda.synchronize()
+        runs.append((da_n, dw_n, part_n))
+    for da_n, dw_n, part_n in runs[1:]:
+        assert torch.equal(da_n, runs[0][0]) and torch.equal(dw_n, runs[0][1]) and torch.equal(part_n, runs[0][2]), 'repeats differ'
+    da_n, dw_n, part_n = runs[0]
+    assert bool(torch.isfinite(da_n.float()).all()) and bool(torch.isfinite(dw_n).all())
+    # ---- data gradient: against the round-4 launch and against fp64 on sampled rows
+    n2, o2 = da_n.permute(0, 2, 3, 1).reshape(M, Cin), da_o.permute(0, 2, 3, 1).reshape(M, Cin)
+    e_no = rel_l2(n2.double().cpu().numpy(), o2.double().cpu().numpy())
+    idx = torch.randperm(M, generator=torch.Generator().manual_seed(7))[:4096].to(dev)
+    c64 = coef.double()
+    A, B1, B2 = c64[:Cout], c64[Cout:2 * Cout], c64[2 * Cout:]
+    dxc64 = A * (g2[idx].double() - B1 - (y2[idx].double() - mean.double()) * invstd.double() * B2)
+    da64 = dxc64 @ w.double().reshape(Cout, Cin)
+    u2 = u.permute(0, 2, 3, 1).reshape(M, Cin)
+    if bn_fuse:
+        sc = (gamma2 * invstd2).double()
+        keep = (u2[idx].double() * sc + (beta2.double() - mean2.double() * sc)) > 0
+        da64 = da64 * keep
+        assert bool((n2[idx][~keep] == 0).all())
+    e_n, e_o = rel_l2(n2[idx].double().cpu().numpy(), da64.cpu().numpy()), rel_l2(o2[idx].double().cpu().numpy(), da64.cpu().numpy())
+    print('dx: one-pass %.2e two launches %.2e (vs fp64, 4096 rows); one vs the other %.2e' % (e_n, e_o, e_no))
+    assert e_n < 4e-3 and e_no < 4e-3
+    if bn_fuse:
+        f2 = n2.double()
+        S2 = f2.sum(0)
+        Q2 = (f2 * (u2.double() - mean2.double())).sum(0) * invstd2.double()
+        pf = part_n.double().sum(0)
+        scale = max(float(S2.abs().max()), float(Q2.abs().max()), 1.0)
+        assert float((pf[:, 0] - S2).abs().max()) / scale < 5e-5 and float((pf[:, 1] - Q2).abs().max()) / scale < 5e-5
+    # ---- weight gradient against fp64 (BN backward on the stored conv output, then the conv's weight gradient)
+    ch = torch.arange(0, Cout, 8, device=dev)
+    dxc_all = A[ch] * (g2[:, ch].double() - B1[ch] - (y2[:, ch].double() - mean.double()[ch]) * invstd.double()[ch] * B2[ch])
+    dw64 = (dxc_all.t() @ a.permute(0, 2, 3, 1).reshape(M, Cin).double()).cpu().numpy()
+    e_wn = rel_l2(dw_n.reshape(Cout, Cin)[ch].double().cpu().numpy() - 1.0, dw64)
+    e_wo = rel_l2(dw_o.reshape(Cout, Cin)[ch].double().cpu().numpy() - 1.0, dw64)
+    print('dw: one-pass (Gram form) %.2e, cnk_conv2d_wgrad_bnfold %.2e vs fp64' % (e_wn, e_wo))
+    assert e_wn < 4e-3 and e_wn < max(2.0 * e_wo, 1e-3)
+
+
+def test_backward_that_raises_leaves_no_dangling_slab_sum():
+    """ops.WGRAD_CHAIN: a backward pass that raises half-way (here: a tensor hook) leaves its last slab sum pending and the
+    end-of-backward join unqueued.  The next pass -- of another model, after the first was freed -- performs that sum: it must
+    land in memory the dead step still owns.  The second model's steps equal the same steps taken in a clean state."""
+    import gc
+    import convnets_amd as ca
+    from convnets_amd import ops
+    from oracle import torch_ref as tr
+    assert ops.WGRAD_CHAIN
+
+    def make(seed):
+        torch.manual_seed(seed)
+        s = ca.Settings(kind=18, input_size=(3, 32, 32), num_classes=10, batch_size=16, dropout_rate=0, mixed_precision=True, device='cuda:0')
+        m = ca.ResNet(s).cuda()
+        m.init_optimizer()
+        m.train()
+        return m
+
+    x, y = tr.synthetic_batch(16, (3, 32, 32), 10, seed=3)
+
+    def two_steps(m):
+        out = [float(m.train_batch((x, y))[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        return out, m.optimizer.flat_p.clone()
+
+    clean = two_steps(make(5))
+    doomed = make(9)
+    mid = []
+    h = doomed.features[2].register_forward_hook(lambda mod, i, o: mid.append(o))
+    out = doomed(x.cuda())
+    h.remove()
+
+    def boom(grad):
+        raise RuntimeError('hook')
+    mid[0].register_hook(boom)
+    with pytest.raises(RuntimeError, match='hook'):
+        out.float().sum().backward()
+    torch.cuda.synchronize()
+    assert any(st[0] is not None for st in ops._wgrad_chain.values()), 'the scenario needs a pending sum (layers behind the hook ran)'
+    del doomed, out, mid
+    gc.collect()
+    torch.cuda.empty_cache()
+    after = two_steps(make(5))
+    assert after[0] == clean[0] and torch.equal(after[1], clean[1])
+    assert not ops._grad_sum_pending and all(st[0] is None for st in ops._wgrad_chain.values())
+
+
+def test_second_streams_are_not_pool_streams():
+    """torch.cuda.Stream() deals a per-device pool of 32 streams round-robin: the weight-gradient stream and the collectives'
+    stream must never be one of them, or the 33rd stream object of a process -- a GraphedTrainStep's capture stream, say -- IS
+    the weight-gradient stream: one stream for both halves of the step, and the compute-stream scratch buffer (keyed by stream
+    handle) aliasing the slabs a chained weight gradient left pending.  (That is how it was found: a hipGraph replay that was
+    wrong only when the whole suite ran before it.)"""
+    from convnets_amd import ops
+    dev = torch.device('cuda', 0)
+    mine = {ops.wgrad_stream(dev).cuda_stream, ops.comm_stream(dev).cuda_stream}
+    assert len(mine) == 2
+    pool = {torch.cuda.Stream(device=dev).cuda_stream for _ in range(80)}
+    pool |= {torch.cuda.Stream(device=dev, priority=-1).cuda_stream for _ in range(80)}
+    assert len(pool) < 80, 'torch no longer pools its streams?'
+    assert not (mine & pool) and torch.cuda.default_stream(dev).cuda_stream not in mine
+    # and it works as a stream: ordering through events, captured fork and join
+    a = torch.zeros(1 << 20, device=dev)
+    side = ops.wgrad_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        a += 1
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream(device=dev)
+    cap.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+        ev = torch.cuda.Event()
+        ev.record(cap)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            a += 1
+        cap.wait_stream(side)
+        a *= 2
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert bool((a == 10).all())          # ((1 + 1) * 2 + 1) * 2

@@ -53,6 +53,15 @@ for Cin, Cout, H, count in LAYERS:
         'dgrad_f': lambda i: lib.cnk_conv2d_dgrad_bnfold(D, P(g[i]), P(a[i]), P(w_fold), P(bias_fold), P(da[i]), None, None, ctypes.byref(fuses[i]), st()),
         'wgrad_f': lambda i: lib.cnk_conv2d_wgrad_bnfold(D, P(g[i]), P(y[i]), P(a[i]), P(mean), P(invstd), P(coef), P(dw), 0, P(ws), nws, st()),
     }
+    if lib.cnk_conv2d_bwd_bnfold_supported(D):
+        # round 5: both folded gradients in one pass (conv_fold3.hip); its fused-reduction partials have their own slice count
+        n1 = lib.cnk_conv2d_bwd_bnfold_workspace_bytes(D)
+        ws1 = torch.empty(n1, dtype=torch.uint8, device='cuda')
+        bpart1 = torch.zeros(lib.cnk_conv2d_bwd_bnfold_bn_slices(D) * Cin * 2, device='cuda')
+        fuses1 = [_lib.BnBwdFuse(u[i].data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None,
+                                 bpart1.data_ptr(), 1) for i in range(copies)]
+        runs['one_pass'] = lambda i: lib.cnk_conv2d_bwd_bnfold(D, P(g[i]), P(a[i]), P(w_fold), P(bias_fold), P(da[i]), ctypes.byref(fuses1[i]),
+                                                              P(w), P(mean), P(invstd), P(coef), P(dw), 0, P(ws1), n1, st())
     res = {}
     for rnd in range(3):
         for name, run in runs.items():
@@ -72,6 +81,9 @@ for Cin, Cout, H, count in LAYERS:
     print('%4d->%4d @%2d x%d | bn_bwd %6.1f dgrad %6.1f wgrad %6.1f | coef %5.1f prep %5.1f dgrad %6.1f wgrad %6.1f | main stream %6.1f -> %6.1f, side %6.1f -> %6.1f us'
           % (Cin, Cout, H, count, r['bn_bwd'], r['dgrad'], r['wgrad'], r['coef'], r['prep'], r['dgrad_f'], r['wgrad_f'], unf_main, fold_main,
              r['wgrad'], r['wgrad_f']), flush=True)
+    if 'one_pass' in r:
+        print('           one pass (data gradient + weight gradient, csrc/conv_fold3.hip): %6.1f us  (the two folded launches: %6.1f + %6.1f)'
+              % (r['one_pass'], r['dgrad_f'], r['wgrad_f']), flush=True)
     for k, v in (('main_unf', unf_main), ('main_fold', fold_main), ('side_unf', r['wgrad']), ('side_fold', r['wgrad_f'])):
         tot[k] = tot.get(k, 0.0) + v * count
 print('per step (count-weighted): main stream %.0f -> %.0f us, side stream %.0f -> %.0f us' % (tot['main_unf'], tot['main_fold'], tot['side_unf'], tot['side_fold']))
