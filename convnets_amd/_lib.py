@@ -77,7 +77,7 @@ SIGNATURES = {
     'cnk_conv2d_bwd_bnfold_supported': (ctypes.c_int, [_dp]),
     'cnk_conv2d_bwd_bnfold_workspace_bytes': (_sz, [_dp]),
     'cnk_conv2d_bwd_bnfold_bn_slices': (ctypes.c_int64, [_dp]),
-    'cnk_conv2d_bwd_bnfold': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnBwdFuse), _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+    'cnk_conv2d_bwd_bnfold': (ctypes.c_int, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(BnBwdFuse), _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                               _vp, _sz, _vp]),
     'cnk_conv2d_bnfold_image_bytes': (_sz, [_dp]),
     'cnk_bn_bwd_coef': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _i64, _i32, ctypes.c_int, _vp,

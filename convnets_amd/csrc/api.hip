@@ -23,7 +23,7 @@ bool bnfold_supported(const cnk_conv_desc* d);
 bool fold3_supported(const cnk_conv_desc* d);
 int fold3_workgroups(const cnk_conv_desc* d);
 size_t fold3_workspace(const cnk_conv_desc* d);
-int fold3_bwd(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, const float* w, const float* mean, const float* invstd, const float* coef, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int fold3_bwd(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const cnk_bn_bwd_fuse* bn, const float* w, const float* mean, const float* invstd, const float* coef, float* dw, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 size_t bnfold_image_bytes(const cnk_conv_desc* d);
 int bnfold_prepare(const cnk_conv_desc* d, const float* w, const void* w_dgrad, const float* mean, const float* invstd, const float* coef, void* w_fold, float* bias_fold, hipStream_t s);
 int bn_bwd_coef(const void* dy, const void* x, const float* ext_partial, int64_t ext_slices, const float* gamma, const float* sm, const float* si, float* dgamma, float* dbeta, int accumulate, float* coef, int64_t M, int C, int dtype, float* ws, hipStream_t s);
@@ -132,6 +132,7 @@ static CnkSwitches read_switches() {
     w.wgrad3_slots_pct = env("CNK_WGRAD3_SLOTS_PCT", -1);
     w.bn_pool_elementwise = getenv("CNK_BN_POOL_ELEMENTWISE") ? 1 : 0;
     w.bn_fused_final = env("CNK_BN_FUSED_FINAL", 1);
+    w.fold3_nwg = env("CNK_FOLD3_NWG", 512);
     return w;
 }
 static CnkSwitches g_switches = read_switches();          // dynamic initialiser: runs when the library is loaded
@@ -632,7 +633,7 @@ size_t cnk_conv2d_bwd_bnfold_workspace_bytes(const cnk_conv_desc* d) { return cn
 
 int64_t cnk_conv2d_bwd_bnfold_bn_slices(const cnk_conv_desc* d) { return cnk_conv2d_bwd_bnfold_supported(d) ? fold3_workgroups(d) : 0; }
 
-int cnk_conv2d_bwd_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const cnk_bn_bwd_fuse* bn, const float* w, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+int cnk_conv2d_bwd_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend, const cnk_bn_bwd_fuse* bn, const float* w, const float* save_mean, const float* save_invstd, const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(d, "cnk_conv2d_bwd_bnfold")) return rc;
     CNK_CHECK_ARG(cnk_conv2d_bwd_bnfold_supported(d), "cnk_conv2d_bwd_bnfold: this conv shape has no one-pass folded backward (cnk_conv2d_bwd_bnfold_supported == 0)");
     CNK_CHECK_ARG(g && x && w_fold && bias_fold && dx && w && save_mean && save_invstd && coef && dw, "cnk_conv2d_bwd_bnfold: null pointer");
@@ -640,7 +641,8 @@ int cnk_conv2d_bwd_bnfold(const cnk_conv_desc* d, const void* g, const void* x, 
     double fl, by;
     conv_cost(d, &fl, &by);
     ProfScope ps(conv_cls(d, 1), S(stream), 2.0 * fl, by);
-    return fold3_bwd(d, g, x, w_fold, bias_fold, dx, bn, w, save_mean, save_invstd, coef, dw, accumulate, workspace, workspace_bytes, S(stream));
+    CNK_CHECK_ARG(!bn || !addend, "cnk_conv2d_bwd_bnfold: a gradient addend or the fused BN backward, not both");
+    return fold3_bwd(d, g, x, w_fold, bias_fold, dx, addend, bn, w, save_mean, save_invstd, coef, dw, accumulate, workspace, workspace_bytes, S(stream));
 }
 
 size_t cnk_bn_workspace_bytes(int64_t M, int32_t C) { return bn_workspace_bytes(M, C); }

@@ -58,6 +58,7 @@ struct CnkSwitches {
     int wgrad_slots_pct;       // CNK_WGRAD_SLOTS_PCT (-1: all): A/B override of the share of the workgroup slots the weight gradients' split-K fills
     int bn_pool_elementwise;   // CNK_BN_POOL_ELEMENTWISE (0)
     int bn_fused_final;        // CNK_BN_FUSED_FINAL (1): finalisation of the BN partials inside the merge launch
+    int fold3_nwg;             // CNK_FOLD3_NWG (512): workgroups of the one-pass folded backward (conv_fold3.hip; A/B)
 };
 const CnkSwitches& cnk_sw();
 

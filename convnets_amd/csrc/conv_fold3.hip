@@ -16,6 +16,9 @@
 // as both operands of the two Gram products.  Traffic per launch: g + a + the BN-2 input of the fused reduction in, da out --
 // what the folded data gradient alone moves today; the weight gradient's 925 MB (and its 13 MB of slabs) disappear.
 //
+// A gradient addend (the projection shortcut's data gradient joins the first conv's: no fused reduction there) takes the BN
+// input's place in the stage.
+//
 // Structure (HBM-bound by a factor of 6 over its MFMA time: everything is arranged for bytes in flight, not for the matrix pipe):
 //   * 256 threads, two workgroups per CU; a workgroup owns a contiguous run of 32-pixel steps.
 //   * three LDS stages of (g 16 KiB | a 4 KiB | BN-2 input 4 KiB), filled by LDS-DMA two steps ahead, counted vmcnt (loads only:
@@ -50,6 +53,7 @@ struct F3Params {
     const unsigned char* g;        // [M][256] bf16
     const unsigned char* x;        // [M][64] bf16 (the conv input a)
     const unsigned char* y2;       // [M][64] bf16: input of the BN layer that produced a (fused reduction), or nullptr
+    const unsigned char* addend;   // [M][64] bf16: the gradient arriving at a through another branch, or nullptr (not with y2)
     const bf16* wf;                // [64][320]: bnfold_prepare's image
     const float* bias;             // [64]
     unsigned char* dx;             // [M][64] bf16
@@ -93,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void fold3_kernel(const F3Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ks0 = (int)((long long)blockIdx.x * p.ksteps / p.nwg), ks1 = (int)((long long)(blockIdx.x + 1) * p.ksteps / p.nwg);
-    const bool bnf = p.y2 != nullptr;
+    const bool bnf = p.y2 != nullptr, has_add = p.addend != nullptr;
+    const unsigned char* side_src = bnf ? p.y2 : p.addend;          // what the third image of a stage holds
 
     // ---- per-lane constants
     // data gradient: this wave's 16 x 320 slice of the image, the row operand of every step
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void fold3_kernel(const F3Params p) {
         }
         const bool okx = live && m0 + xrow < p.M;
         f3_dma16(okx ? p.x + (size_t)m0 * 128 + xoff : zsrc, st + F3_X + wave * 1024);
-        f3_dma16(okx && bnf ? p.y2 + (size_t)m0 * 128 + yoff : zsrc, st + F3_Y + wave * 1024);
+        f3_dma16(okx && side_src ? side_src + (size_t)m0 * 128 + yoff : zsrc, st + F3_Y + wave * 1024);
     };
 
     // Gram fragments: lane l supplies the address of row q of a 4 x 16 block (ds_read_b64_tr_b16); k slot (h, read, q) of a
@@ -273,6 +278,12 @@ __global__ __launch_bounds__(256, 2) void fold3_kernel(const F3Params p) {
                 q8[e] += dv * (yf - bmu[e]);
             }
         }
+        if (has_add) {
+            // same rounding as a separate add kernel: round(round(conv) + addend), as igemm_epilogue
+            const bf16x8 av = *(const bf16x8*)(st + F3_Y + erow * 128 + echunk * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)av[e]);
+        }
         if (m < p.M) {
             const unsigned char* dst = p.dx + (size_t)m * 128 + echunk * 16;
             const u32x4 vv = __builtin_bit_cast(u32x4, v);
@@ -360,20 +371,25 @@ bool fold3_supported(const cnk_conv_desc* d) {
 
 int fold3_workgroups(const cnk_conv_desc* d) {
     const int ksteps = (int)(((int64_t)d->N * d->H * d->W + F3_KP - 1) / F3_KP);
-    return ksteps < 512 ? ksteps : 512;
+    int n = cnk_sw().fold3_nwg;
+    if (n < 1) n = 1;
+    if (n > 2048) n = 2048;
+    return ksteps < n ? ksteps : n;
 }
 
 size_t fold3_workspace(const cnk_conv_desc* d) { return ((size_t)fold3_workgroups(d) + 1) * F3_ROWS * F3_CIN * sizeof(float); }
 
-int fold3_bwd(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx,
+int fold3_bwd(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx, const void* addend,
               const cnk_bn_bwd_fuse* bn, const float* w, const float* mean, const float* invstd, const float* coef, float* dw, int accumulate,
               void* ws, size_t ws_bytes, hipStream_t s) {
     CNK_CHECK_ARG(fold3_supported(d), "fold3_bwd: a dense bf16 1x1 / stride-1 conv of 64 -> 256 channels");
     CNK_CHECK_ARG(!bn || !bn->relu_mask, "fold3_bwd: the fused BN backward re-derives its ReLU mask (no packed mask)");
+    CNK_CHECK_ARG(!bn || !addend, "fold3_bwd: a gradient addend OR the fused BN backward, not both");
     CNK_CHECK_ARG(ws && ws_bytes >= fold3_workspace(d), "fold3_bwd: workspace too small (%zu < %zu)", ws_bytes, fold3_workspace(d));
     F3Params p = {};
     p.g = (const unsigned char*)g; p.x = (const unsigned char*)x; p.wf = (const bf16*)w_fold; p.bias = bias_fold;
     p.dx = (unsigned char*)dx;
+    p.addend = (const unsigned char*)addend;
     if (bn) {
         p.y2 = (const unsigned char*)bn->x; p.bnf_mean = bn->mean; p.bnf_invstd = bn->invstd; p.bnf_gamma = bn->gamma; p.bnf_beta = bn->beta;
         p.bnf_partial = bn->partial; p.bnf_relu = bn->relu;
@@ -385,7 +401,7 @@ int fold3_bwd(const cnk_conv_desc* d, const void* g, const void* x, const void* 
     float* sums = p.slab + (size_t)p.nwg * F3_ROWS * F3_CIN;
     {
         ProfScope kscope(CNK_KF_GATHER, s, 2.0 * p.M * (double)F3_KF * F3_CIN * 2.0,
-                         (double)p.M * (F3_COUT + 2 * F3_CIN + (bn ? F3_CIN : 0)) * 2.0);
+                         (double)p.M * (F3_COUT + 2 * F3_CIN + (bn || addend ? F3_CIN : 0)) * 2.0);
         CNK_LDS_OPTIN(fold3_kernel, F3_LDS, "fold3");
         hipLaunchKernelGGL(fold3_kernel, dim3(p.nwg), dim3(256), F3_LDS, s, p);
         CNK_CHECK_LAUNCH("fold3");

@@ -636,10 +636,11 @@ class Conv2dFn(torch.autograd.Function):
                 fuse_ok = rec is not None and (ctx.link is None or ctx.link.final) and rec.x is not None \
                     and rec.x.shape == x.shape and rec.x.dtype == x.dtype \
                     and (BN_BWD_FUSE_3X3 or desc.kh != 3 or desc.stride_h != 1)
-                # both folded gradients in one pass: plain data gradient (no residual sum), arena weight gradient, re-derived mask
+                # both folded gradients in one pass: a gradient addend OR the fused reduction (with a re-derived mask), arena weight gradient
                 gw1 = None
-                if fold is not None and FOLD_ONE_PASS and ctx.plan.fold1 and addend is None and not ctx.has_bias \
-                        and ctx.needs_input_grad[1] and not (fuse_ok and rec.mask is not None) and ctx.params[0].is_contiguous():
+                if fold is not None and FOLD_ONE_PASS and ctx.plan.fold1 and amask is None and not ctx.has_bias \
+                        and ctx.needs_input_grad[1] and not (fuse_ok and (rec.mask is not None or addend is not None)) \
+                        and ctx.params[0].is_contiguous():
                     gw1 = _arena_grad(ctx.params[0])
                 if fuse_ok:
                     slices = ctx.plan.fold1_slices if gw1 is not None else ctx.plan.dgrad_slices
@@ -651,7 +652,7 @@ class Conv2dFn(torch.autograd.Function):
                                               partial.data_ptr(), int(rec.relu))
                 if gw1 is not None:
                     ws1 = workspace(ctx.plan.fold1_ws, x.device)
-                    check(lib.cnk_conv2d_bwd_bnfold(ctypes.byref(desc), _p(dy), _p(x), _p(w_fold), _p(bias_fold), _p(out),
+                    check(lib.cnk_conv2d_bwd_bnfold(ctypes.byref(desc), _p(dy), _p(x), _p(w_fold), _p(bias_fold), _p(out), _p(addend),
                                                     ctypes.byref(fuse) if fuse else None, _p(w), _p(fold.mean), _p(fold.invstd),
                                                     _p(fold.coef), _p(gw1), 1, _p(ws1), ws1.numel(), _stream()))
                     FOLD_COUNTS['one_pass'] += 1

@@ -281,8 +281,8 @@ int cnk_conv2d_wgrad_bnfold_chain(const cnk_conv_desc* d, const void* g, const v
 
 /* Both gradients of the folded conv -> BN pair in ONE pass over the operands (csrc/conv_fold3.hip): the 64 -> 256-channel 1x1 convs
  * of ResNet's first stage (resnet.py:172-176 and the projection shortcut 160-166 at 56x56; autograd's backward, basemodel.py:278).
- * dx as cnk_conv2d_dgrad_bnfold (same arguments; `bn`, when given, re-derives its ReLU mask: relu_mask must be NULL; its
- * `partial` holds cnk_conv2d_bwd_bnfold_bn_slices(d) records).  dw as cnk_conv2d_wgrad_bnfold, from the Gram products g^T x and
+ * dx as cnk_conv2d_dgrad_bnfold (`addend` without a mask, or `bn` -- not both; `bn` re-derives its ReLU mask: relu_mask must be
+ * NULL; its `partial` holds cnk_conv2d_bwd_bnfold_bn_slices(d) records).  dw as cnk_conv2d_wgrad_bnfold, from the Gram products g^T x and
  * x^T x instead of the BN input:  dw[k][j] (+)= A_k (G[k][j] - B1_k S_j) - A_k invstd_k B2_k ((bf16(w) X)[k][j] - mean_k S_j),
  * so the conv output is never read (it is bf16(w) x up to the rounding of the stored tensor) and neither operand is read twice.
  * w: the fp32 master weights [Cout][Cin].  save_mean / save_invstd / coef as for cnk_conv2d_wgrad_bnfold.  Everything runs on
@@ -291,7 +291,7 @@ int cnk_conv2d_bwd_bnfold_supported(const cnk_conv_desc* d);
 size_t cnk_conv2d_bwd_bnfold_workspace_bytes(const cnk_conv_desc* d);
 int64_t cnk_conv2d_bwd_bnfold_bn_slices(const cnk_conv_desc* d);
 int cnk_conv2d_bwd_bnfold(const cnk_conv_desc* d, const void* g, const void* x, const void* w_fold, const float* bias_fold, void* dx,
-                          const cnk_bn_bwd_fuse* bn, const float* w, const float* save_mean, const float* save_invstd,
+                          const void* addend, const cnk_bn_bwd_fuse* bn, const float* w, const float* save_mean, const float* save_invstd,
                           const float* coef, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.AvgPool2d (avgpool2d, basemodel.py:1026-1033; DenseNet's transition block, densenet.py:129): floor mode,

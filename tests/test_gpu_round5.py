@@ -565,7 +565,7 @@ def test_one_pass_folded_backward(N, H, bn_fuse, load):
     arithmetic: equal up to the fp32 summation order before the bf16 rounding) and against fp64 on sampled rows; dw -- the Gram
     form, which never reads the conv output -- against fp64 of the BN backward + conv weight gradient on sampled channels, at
     least as close as cnk_conv2d_wgrad_bnfold; ragged M (4107 = 128 * 32 + 11), the benchmark's size beside a busy second stream,
-    `accumulate`, five repeats bit-identical."""
+    `accumulate`, a gradient addend in place of the fused reduction, five repeats bit-identical."""
     from convnets_amd import ops
     _lib, lib, cnt = _lib_and_counter()
     Cin, Cout, W = 64, 256, H
@@ -637,11 +637,13 @@ def test_one_pass_folded_backward(N, H, bn_fuse, load):
         return _lib.BnBwdFuse(u.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None,
                               part.data_ptr(), 1) if bn_fuse else None
 
+    # without the fused reduction: a gradient addend (the projection shortcut's case), rounded in as a separate add would
+    add_t = None if bn_fuse else (torch.randn(N, H, W, Cin, generator=gen, device=dev) * 0.3).bfloat16().permute(0, 3, 1, 2)
     # the two folded launches of round 4
     part_o = torch.zeros(max(sl_old, 1), Cin, 2, device=dev)
     fo = fuse_of(part_o)
     da_o = torch.empty_like(a, memory_format=CL)
-    _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(g), P(a), P(w_fold), P(bias_fold), P(da_o), None, None,
+    _lib.check(lib.cnk_conv2d_dgrad_bnfold(ctypes.byref(d), P(g), P(a), P(w_fold), P(bias_fold), P(da_o), P(add_t), None,
                                            ctypes.byref(fo) if fo else None, _st()))
     dw_o = torch.ones(Cout, Cin, 1, 1, device=dev)
     _lib.check(lib.cnk_conv2d_wgrad_bnfold(ctypes.byref(d), P(g), P(y), P(a), P(mean), P(invstd), P(coef), P(dw_o), 1, P(ws_w), nws, _st()))
@@ -653,7 +655,7 @@ def test_one_pass_folded_backward(N, H, bn_fuse, load):
         fn = fuse_of(part_n)
         da_n = torch.full_like(a, float('nan'), memory_format=CL)
         dw_n = torch.ones(Cout, Cin, 1, 1, device=dev)
-        _lib.check(lib.cnk_conv2d_bwd_bnfold(ctypes.byref(d), P(g), P(a), P(w_fold), P(bias_fold), P(da_n), ctypes.byref(fn) if fn else None,
+        _lib.check(lib.cnk_conv2d_bwd_bnfold(ctypes.byref(d), P(g), P(a), P(w_fold), P(bias_fold), P(da_n), P(add_t), ctypes.byref(fn) if fn else None,
                                              P(w), P(mean), P(invstd), P(coef), P(dw_n), 1, P(ws1), nws1, _st()))
         torch.cuda.synchronize()
         runs.append((da_n, dw_n, part_n))
@@ -670,6 +672,9 @@ def test_one_pass_folded_backward(N, H, bn_fuse, load):
     dxc64 = A * (g2[idx].double() - B1 - (y2[idx].double() - mean.double()) * invstd.double() * B2)
     da64 = dxc64 @ w.double().reshape(Cout, Cin)
     u2 = u.permute(0, 2, 3, 1).reshape(M, Cin)
+    if add_t is not None:
+        # round(round(conv) + addend): the fp64 restatement adds the exact addend (one more bf16 rounding in the kernels)
+        da64 = da64 + add_t.permute(0, 2, 3, 1).reshape(M, Cin)[idx].double()
     if bn_fuse:
         sc = (gamma2 * invstd2).double()
         keep = (u2[idx].double() * sc + (beta2.double() - mean2.double() * sc)) > 0

@@ -60,7 +60,7 @@ for Cin, Cout, H, count in LAYERS:
         bpart1 = torch.zeros(lib.cnk_conv2d_bwd_bnfold_bn_slices(D) * Cin * 2, device='cuda')
         fuses1 = [_lib.BnBwdFuse(u[i].data_ptr(), mean2.data_ptr(), invstd2.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), None,
                                  bpart1.data_ptr(), 1) for i in range(copies)]
-        runs['one_pass'] = lambda i: lib.cnk_conv2d_bwd_bnfold(D, P(g[i]), P(a[i]), P(w_fold), P(bias_fold), P(da[i]), ctypes.byref(fuses1[i]),
+        runs['one_pass'] = lambda i: lib.cnk_conv2d_bwd_bnfold(D, P(g[i]), P(a[i]), P(w_fold), P(bias_fold), P(da[i]), None, ctypes.byref(fuses1[i]),
                                                               P(w), P(mean), P(invstd), P(coef), P(dw), 0, P(ws1), n1, st())
     res = {}
     for rnd in range(3):
