@@ -32,7 +32,7 @@ def load_counter(d, cname):
 
 # bench.py's roofline objects are per libcnk ProfScope family (csrc/common.h CNK_KF_*): the launches of one family are the
 # same population here (traffic and algorithmic bytes must describe the same launches)
-FAMILY = {'gemm1x1_kernel': 'igemm_gather_kernel',                                       # CNK_KF_GATHER
+FAMILY = {'gemm1x1_kernel': 'igemm_gather_kernel', 'fold3_kernel': 'igemm_gather_kernel',          # CNK_KF_GATHER
           'igemm_halo3x3_pf_kernel': 'igemm_halo3x3_kernel', 'pp3x3_kernel': 'igemm_halo3x3_kernel',      # CNK_KF_HALO
           'wgrad3x3_kernel': 'wgrad_mfma_kernel'}                                        # CNK_KF_WGRAD
 
