@@ -1,13 +1,15 @@
 // The slab sum of one weight gradient, done by the workgroups of the NEXT weight-gradient launch (round 5).
 //
 // Every split-K weight-gradient kernel leaves fp32 slabs [split][Cout][taps][Cin] that a second, tiny launch summed into
-// dw (wgrad_reduce4_kernel): 52 such launches per ResNet-50 step on the weight-gradient stream, 22-37 us each there -- latency,
-// not work -- and 0.4-0.55 ms of the step (timing probe with the sums skipped, profiles/r05_probe_skip_wgrad_reduce.txt).  The
+// dw (wgrad_reduce4_kernel): 52 such launches per ResNet-50 step on the weight-gradient stream, 22-37 us each there.  The
 // weight-gradient stream runs one such kernel after the other, so the sum of layer k rides in the prologue of layer k + 1's
 // kernel: every workgroup of that launch takes a grid-stride share of it before it starts on its own tile
-// (cdna_hip_programming.md 5, "combine in the NEXT kernel's prologue (the launch-boundary reduce), which costs nothing extra when
-// that kernel exists anyway"); only a chain's last sum needs the stand-alone kernel.  Same element-wise summation order whoever
-// runs it (lane q of a G-lane group takes slabs q, q + G, ... with eight loads in flight, xor-shuffle tree): bit-reproducible.
+// (cdna_hip_programming.md 5, "combine in the NEXT kernel's prologue (the launch-boundary reduce)"); only a chain's last sum
+// needs the stand-alone kernel.  Same element-wise summation order whoever runs it (lane q of a G-lane group takes slabs
+// q, q + G, ... with eight loads in flight, xor-shuffle tree): bit-reproducible.
+// Measured (profiles/r05_ab_wgrad_chain.txt): 0.05 ms of the step.  A timing probe with the sums skipped altogether had
+// promised 0.4-0.55 ms (profiles/r05_probe_skip_wgrad_reduce.txt): the launches were the small part of that, the slabs' own
+// traffic (2.2 GB per step at full split depth, written and read back) is the rest and stays.
 #pragma once
 #include "common.h"
 
