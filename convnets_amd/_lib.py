@@ -52,6 +52,7 @@ SIGNATURES = {
     'cnk_last_error': (ctypes.c_char_p, []),
     'cnk_stream_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     'cnk_stream_destroy': (ctypes.c_int, [_vp]),
+    'cnk_graph_anchor': (ctypes.c_int, [_vp]),
     'cnk_conv2d_out_hw': (ctypes.c_int, [_dp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     'cnk_conv2d_packed_bytes': (_sz, [_dp, ctypes.c_int]),
     'cnk_conv2d_workspace_bytes': (_sz, [_dp, ctypes.c_int]),

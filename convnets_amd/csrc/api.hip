@@ -248,6 +248,14 @@ int cnk_stream_create(void** stream) {
     return 0;
 }
 
+// An empty launch: its only use is its place in a captured graph (include/cnk.h).
+namespace { __global__ void graph_anchor_kernel() {} }
+int cnk_graph_anchor(void* stream) {
+    hipLaunchKernelGGL(graph_anchor_kernel, dim3(1), dim3(64), 0, S(stream));
+    CNK_CHECK_LAUNCH("graph_anchor");
+    return 0;
+}
+
 int cnk_stream_destroy(void* stream) {
     CNK_CHECK_ARG(stream, "cnk_stream_destroy: null pointer");
     const hipError_t e = hipStreamDestroy((hipStream_t)stream);

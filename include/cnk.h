@@ -58,6 +58,13 @@ const char* cnk_last_error(void);
  * 32 streams of a per-device pool round-robin, so the 33rd object of a process IS the first again -- and a "second" stream
  * that silently equals the compute stream serialises the step and lets both sides' scratch buffers alias. */
 int cnk_stream_create(void** stream);
+/* An empty kernel launch on `stream`.  For hosts that capture the two-stream step into a hipGraph: the runtime's graph executor
+ * continues a hardware queue along the FIRST child of a node, so when a fork point (event record on the compute stream + wait on
+ * the second stream) is followed by a launch on the SECOND stream before the compute stream's next launch, the two chains
+ * swap queues at every such point and the replay degrades to worse than one stream (26-30 ms instead of 18.6 for the ResNet-50
+ * step, measured with two different changes).  Launch this on the compute stream right behind such an event
+ * record when the compute stream's own next kernel would otherwise come later than the second stream's. */
+int cnk_graph_anchor(void* stream);
 int cnk_stream_destroy(void* stream);
 
 /* Output spatial size, floor((H + 2p - dilation*(k-1) - 1)/s) + 1 -- the reference's shape tracker formula

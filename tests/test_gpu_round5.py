@@ -396,6 +396,10 @@ def _graph_dp_worker(rank, world, port, out):
 
 
 def test_train_model_with_a_collectively_built_graph_under_dp(tmp_path):
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()               # (a child process on the same GPU: tests/test_gpu_dp.py, the autouse fixture)
     import torch.multiprocessing as mp
     out = str(tmp_path / 'gdp%d.pt')
     mp.start_processes(_graph_dp_worker, args=(1, _free_port(), out), nprocs=1, join=True, start_method='spawn')
@@ -783,3 +787,31 @@ def test_second_streams_are_not_pool_streams():
     g.replay()
     torch.cuda.synchronize()
     assert bool((a == 10).all())          # ((1 + 1) * 2 + 1) * 2
+
+
+def test_graph_anchor_launches_inside_and_outside_a_capture():
+    """include/cnk.h cnk_graph_anchor: an empty launch whose only use is its PLACE in a captured graph (the compute-stream node
+    that must be the first child of a fork point).  It launches eagerly and as a graph node, and changes nothing."""
+    from convnets_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    a = torch.ones(1 << 16, device=dev)
+    _lib.check(lib.cnk_graph_anchor(_st()))
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream(device=dev)
+    side = ops.wgrad_stream(dev)
+    cap.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+        a += 1
+        ev = torch.cuda.Event()
+        ev.record(cap)
+        _lib.check(lib.cnk_graph_anchor(_st(cap)))             # the fork node's first child: a compute-stream node
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            b = a * 2
+        a2 = a + 0
+        cap.wait_stream(side)
+        c = b + a2
+    g.replay()
+    torch.cuda.synchronize()
+    assert bool((c == 6).all())
