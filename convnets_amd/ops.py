@@ -737,9 +737,9 @@ class Conv2dFn(torch.autograd.Function):
                 # the main stream without knowing about the side stream
                 side = wgrad_stream(x.device)
                 # (ORDER MATTERS under capture: the data gradient above was launched on the compute stream BEFORE the first launch
-                # on the side stream below.  The graph executor continues a hardware queue along the FIRST child of the fork
-                # node; a side-stream launch created first makes the two chains swap queues at every such point -- replays of
-                # 26-30 ms instead of 18.6; cnk_graph_anchor exists for hosts that cannot keep this order)
+                # on the side stream below.  The graph executor derives its hardware queues from the creation order of a fork
+                # node's children; with the side-stream launch first, replays took 26-30 ms instead of 18.6 -- DESIGN.md 7c;
+                # cnk_graph_anchor is the remedy measured for that pattern)
                 side.wait_event(dy_ready)                                    # dy, x (and zero_grad) are ready
                 if STAMP[0] is not None:                                     # (tools/probe_graph_schedule.py: the slow way)
                     _stamp('main')

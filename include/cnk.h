@@ -59,11 +59,11 @@ const char* cnk_last_error(void);
  * that silently equals the compute stream serialises the step and lets both sides' scratch buffers alias. */
 int cnk_stream_create(void** stream);
 /* An empty kernel launch on `stream`.  For hosts that capture the two-stream step into a hipGraph: the runtime's graph executor
- * continues a hardware queue along the FIRST child of a node, so when a fork point (event record on the compute stream + wait on
- * the second stream) is followed by a launch on the SECOND stream before the compute stream's next launch, the two chains
- * swap queues at every such point and the replay degrades to worse than one stream (26-30 ms instead of 18.6 for the ResNet-50
- * step, measured with two different changes).  Launch this on the compute stream right behind such an event
- * record when the compute stream's own next kernel would otherwise come later than the second stream's. */
+ * derives its hardware queues from the order in which a node's children were created.  When a fork point (event record on the
+ * compute stream + wait on the weight-gradient stream) is followed by a weight-gradient launch BEFORE the compute stream's next
+ * launch, the replay of the ResNet-50 step degraded from 18.6 to 26-30 ms (two different changes); this launch
+ * on the compute stream right behind the event record restored it.  An empirical remedy for that pattern -- measure the
+ * replay after any change of launch order (behind the all-reduce forks of a data-parallel step it made things worse). */
 int cnk_graph_anchor(void* stream);
 int cnk_stream_destroy(void* stream);
 
